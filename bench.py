@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the imgcomp hot path on MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic input: BASELINE.json configs[1]
+(Kodak-shaped image 1x3x512x768, ae_configs/cvpr/low + pc_configs/cvpr/res_shallow, batch 1):
+    encode (normalise, 35 convs, importance map, quantiser) -> context-model bit cost for all symbols
+    in parallel + bpp -> decode(qhard) (35 convs, de-normalise, clip)          [val.py:85-89 wiring]
+Inputs and weights are resident in HBM before the timed region.  Data: seeded synthetic image and
+random-init weights (no network for Kodak or the 0515_1103 checkpoint).
+
+  python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by torch.distributed.run, one rank per GPU; the path shards by image (independent
+units, no data-path collective), so every rank runs the same per-GPU workload: weak scaling.
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel (3x3 128->128 conv on the fp32 matrix cores): algorithmic FLOP per
+                  launch / average launch duration measured with HIP events on the launch stream
+  cpu_baseline -- the CPU oracle (torch fp32 restatement of the reference, all host cores) timed on a
+                  bounded sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+# algorithmic work per input pixel, C = 32 (FLOP = 2 MAC, dense, mask-agnostic, halo-free)
+FLOP_PER_PX_ENC = 621124.0
+FLOP_PER_PX_DEC = 618976.0
+FLOP_PER_SYMBOL_PC = 47520.0
+CONV3_FLOP_PER_OUT_PX = 2.0 * 9 * 128 * 128      # per 128-channel output pixel of one 3x3 layer
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--warmup', type=int, default=3)
+    p.add_argument('--height', type=int, default=512)
+    p.add_argument('--width', type=int, default=768)
+    p.add_argument('--batch', type=int, default=1)
+    p.add_argument('--ae_config', default='low')
+    p.add_argument('--no_cpu_baseline', action='store_true')
+    a = p.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    assert world == a.gpus, 'WORLD_SIZE {} != --gpus {}'.format(world, a.gpus)
+    assert torch.cuda.is_available(), 'bench.py needs a HIP device'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    from imgcomp_cvpr_amd import autoencoder, probclass, bits, config_parser as cp, weights as W, _lib
+    lib = _lib.lib
+    ae_cfg, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', a.ae_config))
+    pc_cfg, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
+    wts = W.synthetic_weights(ae_cfg, pc_cfg)
+    ae = autoencoder.get_network_cls(ae_cfg)(ae_cfg).load_weights(wts, dev)
+    pc = probclass.get_network_cls(pc_cfg)(pc_cfg, num_centers=ae_cfg.num_centers).load_weights(wts, dev)
+    N, H, Wd = a.batch, a.height, a.width
+    x_np = W.synthetic_image((N, 3, H, Wd), 'natural', seed=rank)
+    x = torch.as_tensor(x_np).float().to(dev)
+    pad_value = float(wts['autoencoder/encoder/centers'][0])
+
+    def step():
+        enc = ae.encode(x, is_training=False)
+        bc = pc.bitcost(enc.qbar, enc.symbols, is_training=False, pad_value=pad_value)
+        bpp = bits.bitcost_to_bpp(bc, x)
+        x_out = ae.decode(enc.qhard, is_training=False)
+        return bpp, x_out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        bpp, x_out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    pixels_per_step = N * H * Wd * world
+    value = pixels_per_step * a.steps / elapsed / 1e6
+
+    # ---- stage split and the dominant kernel, HIP events on the launch stream (rank 0) ----
+    extra = {}
+    roofline = None
+    if rank == 0:
+        st = _lib.current_stream(dev)
+        ev = [ctypes.c_void_p() for _ in range(2)]
+        for e in ev:
+            _lib.check(lib.ic_event_create(ctypes.byref(e)))
+
+        def timed(fn, reps):
+            fn()
+            torch.cuda.synchronize(dev)
+            _lib.check(lib.ic_event_record(ev[0], st))
+            for _ in range(reps):
+                fn()
+            _lib.check(lib.ic_event_record(ev[1], st))
+            ms = ctypes.c_float()
+            _lib.check(lib.ic_event_elapsed_ms(ev[0], ev[1], ctypes.byref(ms)))
+            return ms.value / reps
+
+        enc = ae.encode(x, False)
+        ms_enc = timed(lambda: ae.encode(x, False), 5)
+        ms_pc = timed(lambda: pc.bitcost(enc.qbar, enc.symbols, False, pad_value=pad_value), 5)
+        ms_dec = timed(lambda: ae.decode(enc.qhard, False), 5)
+        extra = {'ms_encode': round(ms_enc, 4), 'ms_pc_bitcost': round(ms_pc, 4), 'ms_decode': round(ms_dec, 4),
+                 'bpp_synthetic': round(float(bpp), 5)}
+        # dominant kernel: the shape the residual stacks run at, (N,128,H/4,W/4)
+        h4, w4 = H // 4, Wd // 4
+        xin = torch.randn((N, 128, h4, w4), device=dev)
+        res = torch.randn((N, 128, h4, w4), device=dev)
+        yout = torch.empty_like(xin)
+        wpk, sc, sh = ae._plan['autoencoder/encoder/res_block_enc_0/enc_0_1/conv2']
+        def conv():
+            _lib.check(lib.ic_conv3x3_c128_bn_act_f32(_lib.ptr(xin), _lib.ptr(wpk), _lib.ptr(sc), _lib.ptr(sh),
+                                                      _lib.ptr(res), None, _lib.ptr(yout), N, h4, w4, 0, st))
+        ms_conv = timed(conv, 64)
+        flop = CONV3_FLOP_PER_OUT_PX * N * h4 * w4
+        achieved = flop / (ms_conv * 1e-3) / 1e12
+        roofline = {'kernel': 'conv3x3_c128_kernel (ic_conv3x3_c128_bn_act_f32)', 'bound': 'mfma',
+                    'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                    'avg_launch_us': round(ms_conv * 1e3, 2), 'flop_per_launch': flop,
+                    'launches_per_step': 2 * (6 * int(ae_cfg.arch_param_B) + 2)}
+        for e in ev:
+            lib.ic_event_destroy(e)
+
+    # ---- CPU baseline: the oracle on the host cores (rank 0, N == 1 only) ----
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from oracle import oracle as O
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        sample = x_np[:1]
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            O.validate_forward(sample, wts, ae_cfg.as_dict(), torch.float32)
+        dt = time.perf_counter() - t1
+        cpu = {'value': round(sample.shape[2] * sample.shape[3] / dt / 1e6, 4), 'unit': 'Mpix/s', 'cores': cores,
+               'kind': 'port', 'sample': '1 image 3x{}x{} through the torch-CPU fp32 oracle '
+               '(encode + bitcost + decode), single run, {:.1f} s'.format(sample.shape[2], sample.shape[3], dt)}
+
+    if rank == 0:
+        C = int(ae_cfg.num_chan_bn)
+        flop_step = N * H * Wd * (FLOP_PER_PX_ENC + FLOP_PER_PX_DEC + FLOP_PER_SYMBOL_PC * C / 64.0)
+        out = {
+            'metric': 'Megapixels/s encode+pc-logits (and decode) per node',
+            'value': round(value, 3), 'unit': 'Mpix/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(elapsed / a.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: Kodak-shaped image {}x3x{}x{} per GPU per step, '
+                                   'ae_configs/cvpr/{} + pc_configs/cvpr/res_shallow, encode + parallel '
+                                   'context-model bitcost + decode(qhard); random-init weights'.format(
+                                       N, H, Wd, a.ae_config),
+                       'batch_per_gpu': N, 'height': H, 'width': Wd, 'parallelism': 'image-sharded x{}'.format(world)},
+            'model_tflops_per_s': round(flop_step * world * a.steps / elapsed / 1e12, 2),
+            'roofline': roofline, 'cpu_baseline': cpu,
+        }
+        out.update(extra)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

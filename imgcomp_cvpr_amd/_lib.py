@@ -1,0 +1,110 @@
+"""ctypes binding of libimgcomp_hip.so (the C ABI declared in include/imgcomp_hip.h).
+
+The HIP library IS the product: there is no CPU or eager-PyTorch fallback anywhere in this
+package.  If the shared object is missing or a symbol cannot be resolved, importing this module
+raises -- run ``python -c "import __graft_entry__ as g; g.build()"`` (or ``make -C
+imgcomp_cvpr_amd/csrc``) first.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_longlong, c_size_t, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libimgcomp_hip.so')
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); mirrors include/imgcomp_hip.h one-to-one (tests/test_abi.py checks
+# that every ic_* prototype of the header is listed here and exported by the .so).
+PROTOTYPES = {
+    'ic_abi_version': (c_int, []),
+    'ic_strerror': (c_char_p, [c_int]),
+    'ic_conv2d_bn_act_f32': (c_int, [c_void_p] * 7 + [c_int] * 9 + [c_void_p, c_void_p, c_void_p]),
+    'ic_deconv2d_bn_act_f32': (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p, c_void_p, c_void_p]),
+    'ic_conv3x3_c128_packed_floats': (c_size_t, []),
+    'ic_pack_conv3x3_c128_f32': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'ic_conv3x3_c128_bn_act_f32': (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_void_p]),
+    'ic_conv3x3_c128_set_variant': (c_int, [c_int]),
+    'ic_quantize_f32': (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                c_longlong, c_void_p]),
+    'ic_heatmap_quantize_f32': (c_int, [c_void_p, c_void_p, c_int, c_float] + [c_void_p] * 6 +
+                                [c_int] * 4 + [c_void_p]),
+    'ic_pc_workspace_bytes': (c_size_t, [c_int] * 5),
+    'ic_pc_logits_f32': (c_int, [c_void_p, POINTER(c_void_p), c_int, c_int, c_float, c_void_p] +
+                         [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),
+    'ic_pc_logits_padded_f32': (c_int, [c_void_p, POINTER(c_void_p), c_int, c_int, c_void_p] +
+                                [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),
+    'ic_pc_bitcost_f32': (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_int, c_int, c_float,
+                                  c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),
+    'ic_sum_f32': (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p]),
+    'ic_ae_workspace_bytes': (c_size_t, [c_int] * 4),
+    'ic_ae_encode_f32': (c_int, [c_void_p, POINTER(c_void_p)] + [c_int] * 5 + [c_void_p] * 6 +
+                         [c_int] * 3 + [c_void_p, c_size_t, c_void_p]),
+    'ic_ae_decode_f32': (c_int, [c_void_p, POINTER(c_void_p)] + [c_int] * 3 + [c_void_p] +
+                         [c_int] * 3 + [c_void_p, c_size_t, c_void_p]),
+    'ic_event_create': (c_int, [POINTER(c_void_p)]),
+    'ic_event_destroy': (c_int, [c_void_p]),
+    'ic_event_record': (c_int, [c_void_p, c_void_p]),
+    'ic_event_elapsed_ms': (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+}
+
+
+def _load():
+    if not os.path.isfile(LIB_PATH):
+        raise HipLibraryError(
+            'HIP extension not built: {} is missing.  Build it with '
+            '`make -C {}` (hipcc --offload-arch=gfx950).  There is no CPU fallback.'.format(
+                LIB_PATH, os.path.join(_HERE, 'csrc')))
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise HipLibraryError('cannot load {}: {}'.format(LIB_PATH, e))
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise HipLibraryError('{} does not export {}'.format(LIB_PATH, name))
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib.ic_strerror(rc)
+        raise HipLibraryError('{} failed with code {}: {}'.format(
+            what or 'libimgcomp_hip call', rc, msg.decode() if msg else '?'))
+
+
+def ptr(t):
+    """device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'C ABI takes dense tensors'
+    return c_void_p(t.data_ptr())
+
+
+def ptr_table(tensors):
+    """host array of device pointers (keeps no reference: caller must keep tensors alive)."""
+    arr = (c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def current_stream(device=None):
+    import torch
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(t, name='tensor'):
+    if not t.is_cuda:
+        raise HipLibraryError(
+            '{} lives on {}; the imgcomp hot path runs only on a HIP device (no CPU fallback)'.format(
+                name, t.device))

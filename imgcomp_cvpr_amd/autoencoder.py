@@ -1,0 +1,238 @@
+"""Convolutional autoencoder plugin -- MI355X mirror of the reference's code/autoencoder.py.
+
+Same plugin surface (reference code/autoencoder.py:26-29, :33-86, :214-216):
+
+    cls = get_network_cls(ae_config)            # keyed by config.arch ('CVPR')
+    ae = cls(ae_config)
+    enc = ae.encode(x, is_training=False)       # EncoderOutput(qbar, qhard, symbols, z, heatmap)
+    x_out = ae.decode(enc.qhard, is_training=False)
+    ae.get_centers_variable(); ae.get_subsampling_factor(); ae.encoder_variables(); ...
+
+but on torch tensors that live on a HIP device, with every op executed by libimgcomp_hip.so
+(hand-written gfx950 kernels behind the C ABI of include/imgcomp_hip.h).  TF's implicit variable
+store is replaced by an explicit ``load_weights(dict)`` (names/layouts = the reference's checkpoint
+variables).  There is no CPU path: tensors on the CPU raise.
+"""
+from collections import namedtuple, OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import quantizer
+from . import weights as _weights
+from ._lib import lib, check, ptr
+
+# reference: code/autoencoder.py:15,18
+EncoderOutput = namedtuple('EncoderOutput', ['qbar', 'qhard', 'symbols', 'z', 'heatmap'])
+_QuantizerOutput = namedtuple('_QuantizerOutput', ['qbar', 'qsoft', 'qhard', 'symbols'])
+
+SCOPE_AE = 'autoencoder'
+SCOPE_AE_ENC = SCOPE_AE + '/encoder'
+SCOPE_AE_DEC = SCOPE_AE + '/decoder'
+
+BN_EPSILON = 1e-5      # reference: code/autoencoder.py:118
+BN_DECAY = 0.9         # reference: code/autoencoder.py:117
+arch_param_n = 128     # reference: code/autoencoder.py:211
+
+
+def get_network_cls(config):
+    """reference: code/autoencoder.py:26-29."""
+    return {
+        'CVPR': _CVPR,
+    }[config.arch]
+
+
+def fold_batch_norm(gamma, beta, moving_mean, moving_variance, eps=BN_EPSILON):
+    """Inference BatchNorm as y = x * scale + shift (float64 math, rounded once to fp32)."""
+    g, b, m, v = (np.asarray(a, np.float64) for a in (gamma, beta, moving_mean, moving_variance))
+    scale = g / np.sqrt(v + eps)
+    shift = b - m * scale
+    return scale.astype(np.float32), shift.astype(np.float32)
+
+
+class _Network(object):
+    def __init__(self, config, quantize=True):
+        self.config = config
+        self.quantize = quantize
+        self.num_chan_bn_including_heatmap = config.num_chan_bn + 1
+        self._centers = None       # set by load_weights(); access with get_centers_variable()
+        self._params = None        # OrderedDict name -> device tensor (reference layouts)
+        self._device = None
+
+    # -- plugin surface -----------------------------------------------------------------------
+
+    @staticmethod
+    def get_subsampling_factor():
+        raise NotImplementedError()
+
+    def encode(self, x, is_training):
+        """x: (N,3,H,W) float32 in 0..255 on the HIP device.  -> EncoderOutput."""
+        assert x.dtype == torch.float32, 'Expected float32 for x, got {}'.format(x.dtype)
+        self._require_weights()
+        return self._encode(x, is_training)
+
+    def decode(self, q, is_training):
+        self._require_weights()
+        return self._decode(q, is_training)
+
+    def get_centers_variable(self):
+        if self._centers is None:
+            raise ValueError('Call load_weights(...) before trying to access centers')
+        return self._centers
+
+    def encoder_variables(self):
+        """Trainable encoder variables, centres included (reference :70-73)."""
+        return self._trainable(SCOPE_AE_ENC)
+
+    def decoder_variables(self):
+        return self._trainable(SCOPE_AE_DEC)
+
+    def encoder_regularization_loss(self):
+        """factor * l2_loss(conv weights) + centres term (reference :79-82, quantizer.py:18-24)."""
+        return self._reg_loss(SCOPE_AE_ENC)
+
+    def decoder_regularization_loss(self):
+        return self._reg_loss(SCOPE_AE_DEC)
+
+    # -- weights ------------------------------------------------------------------------------
+
+    def load_weights(self, weights, device='cuda'):
+        """weights: dict name -> array in the reference's TF layouts (checkpoint variable names)."""
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise _lib.HipLibraryError('the autoencoder runs only on a HIP device, got {}'.format(device))
+        self._device = device
+        self._params = OrderedDict()
+        for name, arr in weights.items():
+            if name.startswith(SCOPE_AE + '/'):
+                self._params[name] = torch.as_tensor(np.ascontiguousarray(arr), dtype=torch.float32).to(device)
+        self._centers = self._params[SCOPE_AE_ENC + '/centers']
+        self._prepare(weights)
+        return self
+
+    def init_weights(self, pc_config=None, seed=1234, device='cuda'):
+        raise NotImplementedError('use weights.synthetic_weights(ae_config, pc_config) + load_weights')
+
+    def _require_weights(self):
+        if self._params is None:
+            raise ValueError('no weights: call load_weights(dict) first (replaces TF variable init / Saver.restore)')
+
+    def _trainable(self, scope):
+        self._require_weights()
+        return [t for n, t in self._params.items()
+                if n.startswith(scope + '/') and 'moving_' not in n]
+
+    def _reg_loss(self, scope):
+        self._require_weights()
+        total = torch.zeros((), dtype=torch.float32, device=self._device)
+        f = float(self.config.regularization_factor)
+        for n, t in self._params.items():
+            if n.startswith(scope + '/') and n.endswith('/weights'):
+                total = total + f * 0.5 * (t * t).sum()
+        if scope == SCOPE_AE_ENC and self.config.regularization_factor_centers != 0:
+            total = total + quantizer.create_centers_regularization_term(self.config, self._centers)
+        return total
+
+    def _prepare(self, weights):
+        raise NotImplementedError()
+
+    def _encode(self, x, is_training):
+        raise NotImplementedError()
+
+    def _decode(self, q, is_training):
+        raise NotImplementedError()
+
+
+class _CVPR(_Network):
+    """reference: code/autoencoder.py:214-268."""
+
+    @staticmethod
+    def get_subsampling_factor():
+        return 8
+
+    # -- device-side plan: packed filters, folded BN, pointer tables -------------------------------
+
+    def _prepare(self, weights):
+        cfg = self.config
+        self._B = int(cfg.arch_param_B)
+        self._C = int(cfg.num_chan_bn)
+        self._L = int(cfg.num_centers)
+        dev = self._device
+        st = _lib.current_stream(dev)
+        specs = _weights.ae_conv_specs(self._C, self._B, bool(cfg.heatmap))
+        self._plan = {}           # scope -> (w_dev, scale_dev, shift_dev); keeps tensors alive
+        enc_tab, dec_tab = [], []
+        packed_n = lib.ic_conv3x3_c128_packed_floats()
+        for scope, kind, shape in specs:
+            w = self._params[scope + '/weights']
+            scale, shift = fold_batch_norm(*(weights[scope + '/BatchNorm/' + k] for k in
+                                             ('gamma', 'beta', 'moving_mean', 'moving_variance')))
+            scale_d = torch.from_numpy(scale).to(dev)
+            shift_d = torch.from_numpy(shift).to(dev)
+            if kind == 'conv' and tuple(shape) == (3, 3, arch_param_n, arch_param_n):
+                wp = torch.empty(packed_n, dtype=torch.float32, device=dev)
+                check(lib.ic_pack_conv3x3_c128_f32(ptr(w), ptr(wp), st), 'ic_pack_conv3x3_c128_f32')
+                w_use = wp
+            else:
+                w_use = w
+            self._plan[scope] = (w_use, scale_d, shift_d)
+            (enc_tab if scope.startswith(SCOPE_AE_ENC) else dec_tab).extend([w_use, scale_d, shift_d])
+        enc_tab.append(self._centers)
+        torch.cuda.synchronize(dev)
+        self._enc_tab = _lib.ptr_table(enc_tab)
+        self._dec_tab = _lib.ptr_table(dec_tab)
+        self._ws = None
+
+    def _workspace(self, N, H, W):
+        need = lib.ic_ae_workspace_bytes(N, H, W, self._C)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self._device)
+        return self._ws, need
+
+    # -- forward -----------------------------------------------------------------------------------
+
+    def _encode(self, x, is_training):
+        if is_training:
+            raise NotImplementedError('training-mode BatchNorm / backward kernels are not built yet (DESIGN.md)')
+        _lib.require_cuda(x, 'x')
+        x = x.contiguous()
+        N, three, H, W = x.shape
+        assert three == 3, 'Expected N3HW, got {}'.format(tuple(x.shape))
+        f = self.get_subsampling_factor()
+        if H % f or W % f:
+            raise ValueError('H and W must be multiples of {} (val.py pads images first), got {}x{}'.format(f, H, W))
+        C, hh, ww = self._C, H // f, W // f
+        mk = lambda: torch.empty((N, C, hh, ww), dtype=torch.float32, device=x.device)
+        heat_on = bool(self.config.heatmap)
+        if not self.quantize:
+            raise NotImplementedError('quantize=False is not used by val.py/train.py')
+        z, qsoft, qhard = mk(), mk(), mk()
+        qbar = mk() if heat_on else None
+        heatmap = mk() if heat_on else None
+        symbols = torch.empty((N, C, hh, ww), dtype=torch.int64, device=x.device)
+        ws, need = self._workspace(N, H, W)
+        check(lib.ic_ae_encode_f32(ptr(x), self._enc_tab, self._B, C, self._L, int(heat_on),
+                                   int(self.config.normalization == 'FIXED'),
+                                   ptr(heatmap), ptr(z), ptr(qsoft), ptr(qhard), ptr(qbar), ptr(symbols),
+                                   N, H, W, ptr(ws), need, _lib.current_stream(x.device)), 'ic_ae_encode_f32')
+        if qbar is None:
+            qbar = qhard      # forward value of qsoft + stop_gradient(qhard - qsoft)
+        self._last_qsoft = qsoft
+        return EncoderOutput(qbar, qhard, symbols, z, heatmap)
+
+    def _decode(self, q, is_training):
+        if is_training:
+            raise NotImplementedError('training-mode BatchNorm / backward kernels are not built yet (DESIGN.md)')
+        _lib.require_cuda(q, 'q')
+        q = q.contiguous()
+        N, C, hh, ww = q.shape
+        assert C == self._C, 'Expected {} bottleneck channels, got {}'.format(self._C, C)
+        f = self.get_subsampling_factor()
+        H, W = hh * f, ww * f
+        x_out = torch.empty((N, 3, H, W), dtype=torch.float32, device=q.device)
+        ws, need = self._workspace(N, H, W)
+        check(lib.ic_ae_decode_f32(ptr(q), self._dec_tab, self._B, C, int(self.config.normalization == 'FIXED'),
+                                   ptr(x_out), N, H, W, ptr(ws), need, _lib.current_stream(q.device)),
+              'ic_ae_decode_f32')
+        return x_out

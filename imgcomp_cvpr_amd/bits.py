@@ -1,0 +1,25 @@
+"""bit cost -> bits per pixel; mirror of the reference's code/bits.py."""
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr
+
+
+def num_pixels_in_input_batch(input_batch):
+    """N*H*W of an N3HW batch (reference code/bits.py:17-20)."""
+    assert input_batch.dim() == 4 and int(input_batch.shape[1]) == 3, 'Expected N3HW, got {}'.format(
+        tuple(input_batch.shape))
+    return input_batch.numel() // 3
+
+
+def bitcost_to_bpp(bit_cost, input_batch):
+    """sum(bit_cost) / num_pixels -> 0-d float32 device tensor (reference code/bits.py:4-14).
+    The sum is a deterministic two-stage tree reduction on the device (ic_sum_f32)."""
+    assert bit_cost.dim() == input_batch.dim() == 4, 'Expected NChw and N3HW'
+    _lib.require_cuda(bit_cost, 'bit_cost')
+    bit_cost = bit_cost.contiguous()
+    partial = torch.empty(1024, dtype=torch.float32, device=bit_cost.device)
+    out = torch.empty(1, dtype=torch.float32, device=bit_cost.device)
+    check(lib.ic_sum_f32(ptr(bit_cost), bit_cost.numel(), ptr(partial), ptr(out),
+                         _lib.current_stream(bit_cost.device)), 'ic_sum_f32')
+    return out[0] / float(num_pixels_in_input_batch(input_batch))

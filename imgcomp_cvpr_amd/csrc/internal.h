@@ -1,0 +1,16 @@
+// Internal (non-ABI) declarations shared between the translation units of libimgcomp_hip.so.
+#pragma once
+#include "common.h"
+
+struct ConvArgs {
+    const float* x; const float* w; const float* scale; const float* shift;
+    const float* res1; const float* res2; float* y;
+    const float* in_mean; const float* in_std; const float* out_mean; const float* out_std;
+    int N, Cin, H, W, Cout, OH, OW, KH, KW, stride, pt, pl, relu;
+    int w_sci, w_sco;   // filter strides (in floats) of the ci and co axes inside one tap
+    int builtin_norm;   // bit 0: normalise the input with the reference's fixed image statistics,
+                        // bit 1: de-normalise + clip the output with them (autoencoder.py:136-169), bit 2: clip only
+};
+
+// fills OH/OW/pads/filter strides for a TF-SAME conv (transposed = stride-2 conv2d_transpose) and launches
+int icx_conv2d(ConvArgs a, bool transposed, hipStream_t st);

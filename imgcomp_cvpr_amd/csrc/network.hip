@@ -1,0 +1,177 @@
+// Whole-network entry points for the CVPR autoencoder + library plumbing (version, errors, events).
+//   reference: code/autoencoder.py:218-244 (_CVPR._encode), :246-268 (_CVPR._decode)
+// One host call enqueues all 36 stages of encode (or decode) on the caller's stream: batch-1 inference
+// (val.py runs one image per step, code/val.py:157-158) is otherwise bound by per-op host overhead.
+#include "internal.h"
+
+// ---- residual stack shared by encoder and decoder (autoencoder.py:224-234 / :252-262) ----
+// tab: 3 pointers {packed filter, scale, shift} per conv, 6B+2 convs.  bufs[0] holds the stack input
+// (kept for the global skip), bufs[4] is the temporary.  Returns the buffer index holding the output.
+static int res_stack(const void* const* tab, int B, float* const bufs[5], int N, int H, int W,
+                     hipStream_t st, int* out_idx) {
+    int cur = 0, li = 0, rc;
+    float* T = bufs[4];
+    for (int b = 0; b < B; ++b) {
+        const int G = cur;
+        for (int i = 0; i < 3; ++i) {
+            int O = 1;
+            while (O == G || O == cur) ++O;              // one of {1,2,3} is always free
+            const float* const* l1 = (const float* const*)tab + 3 * li;
+            const float* const* l2 = l1 + 3;
+            if ((rc = ic_conv3x3_c128_bn_act_f32(bufs[cur], l1[0], l1[1], l1[2], nullptr, nullptr, T, N, H, W, 1, st)))
+                return rc;
+            if ((rc = ic_conv3x3_c128_bn_act_f32(T, l2[0], l2[1], l2[2], bufs[cur], i == 2 ? bufs[G] : nullptr,
+                                                 bufs[O], N, H, W, 0, st)))
+                return rc;
+            cur = O; li += 2;
+        }
+    }
+    // final block: both convs linear, + block input + stack input
+    {
+        int O = 1;
+        while (O == cur) ++O;
+        const float* const* l1 = (const float* const*)tab + 3 * li;
+        const float* const* l2 = l1 + 3;
+        if ((rc = ic_conv3x3_c128_bn_act_f32(bufs[cur], l1[0], l1[1], l1[2], nullptr, nullptr, T, N, H, W, 0, st)))
+            return rc;
+        if ((rc = ic_conv3x3_c128_bn_act_f32(T, l2[0], l2[1], l2[2], bufs[cur], bufs[0], bufs[O], N, H, W, 0, st)))
+            return rc;
+        cur = O;
+    }
+    *out_idx = cur;
+    return IC_OK;
+}
+
+static size_t ae_ws_floats(int N, int H, int W, int C) {
+    const size_t hw = (size_t)H * W;
+    // 5 x (N,128,H/4,W/4) + (N,64,H/2,W/2) + bottleneck (N,C+1,H/8,W/8)
+    return (size_t)N * (5 * 8 * hw + 16 * hw + (size_t)(C + 1) * hw / 64);
+}
+
+extern "C" size_t ic_ae_workspace_bytes(int N, int H, int W, int C) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    return ae_ws_floats(N, H, W, C) * sizeof(float);
+}
+
+static void carve(void* ws, int N, int H, int W, float* bufs[5], float** half, float** bott) {
+    const size_t hw = (size_t)H * W;
+    float* p = (float*)ws;
+    for (int i = 0; i < 5; ++i) { bufs[i] = p; p += (size_t)N * 8 * hw; }
+    *half = p; p += (size_t)N * 16 * hw;
+    *bott = p;
+}
+
+extern "C" int ic_ae_encode_f32(const float* x, const void* const* tab, int B, int C, int L, int heatmap_on,
+                                int normalize_on, float* heatmap, float* z, float* qsoft, float* qhard, float* qbar,
+                                int64_t* symbols, int N, int H, int W,
+                                void* workspace, size_t workspace_bytes, ic_stream_t stream) {
+    IC_CHECK_ARG(x && tab && workspace && N > 0 && H > 0 && W > 0 && B >= 0 && C > 0 && L > 0);
+    if (H % 8 || W % 8) return IC_ERR_UNSUPPORTED;          // callers pad to the subsampling factor (val.py:157)
+    if (workspace_bytes < ic_ae_workspace_bytes(N, H, W, C)) return IC_ERR_WORKSPACE;
+    const int nconv = 6 * B + 2;
+    for (int i = 0; i < 3 * (nconv + 3) + 1; ++i) IC_CHECK_ARG(tab[i] != nullptr);
+    hipStream_t st = (hipStream_t)stream;
+    float* bufs[5]; float* half; float* bott;
+    carve(workspace, N, H, W, bufs, &half, &bott);
+    int rc;
+    const float* const* t = (const float* const*)tab;
+    ConvArgs a{};
+    // h1: 3 -> 64, 5x5 / 2, BN, ReLU, input normalisation folded into the load
+    a.x = x; a.w = t[0]; a.scale = t[1]; a.shift = t[2]; a.y = half;
+    a.N = N; a.Cin = 3; a.H = H; a.W = W; a.Cout = 64; a.KH = 5; a.KW = 5; a.stride = 2; a.relu = 1;
+    a.builtin_norm = normalize_on ? 1 : 0;
+    if ((rc = icx_conv2d(a, false, st))) return rc;
+    // h2: 64 -> 128, 5x5 / 2, BN, ReLU
+    a = ConvArgs{};
+    a.x = half; a.w = t[3]; a.scale = t[4]; a.shift = t[5]; a.y = bufs[0];
+    a.N = N; a.Cin = 64; a.H = H / 2; a.W = W / 2; a.Cout = 128; a.KH = 5; a.KW = 5; a.stride = 2; a.relu = 1;
+    if ((rc = icx_conv2d(a, false, st))) return rc;
+    int o;
+    if ((rc = res_stack(tab + 6, B, bufs, N, H / 4, W / 4, st, &o))) return rc;
+    // to_bn: 128 -> C(+1), 5x5 / 2, BN, linear
+    const float* const* tb = t + 6 + 3 * nconv;
+    const int Cb = C + (heatmap_on ? 1 : 0);
+    a = ConvArgs{};
+    a.x = bufs[o]; a.w = tb[0]; a.scale = tb[1]; a.shift = tb[2]; a.y = bott;
+    a.N = N; a.Cin = 128; a.H = H / 4; a.W = W / 4; a.Cout = Cb; a.KH = 5; a.KW = 5; a.stride = 2; a.relu = 0;
+    if ((rc = icx_conv2d(a, false, st))) return rc;
+    const float* centers = tb[3];
+    if (heatmap_on)
+        return ic_heatmap_quantize_f32(bott, centers, L, 1.0f, heatmap, z, qsoft, qhard, qbar, symbols,
+                                       N, C, H / 8, W / 8, stream);
+    // no importance map: z is the bottleneck itself
+    const long long cnt = (long long)N * C * (H / 8) * (W / 8);
+    if (z) {
+        hipError_t e = hipMemcpyAsync(z, bott, cnt * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (qbar) return IC_ERR_UNSUPPORTED;   // qbar == qhard in value; request qhard instead
+    return ic_quantize_f32(bott, centers, L, 1.0f, qsoft, qhard, symbols, cnt, stream);
+}
+
+extern "C" int ic_ae_decode_f32(const float* q, const void* const* tab, int B, int C, int normalize_on,
+                                float* x_out, int N, int H, int W,
+                                void* workspace, size_t workspace_bytes, ic_stream_t stream) {
+    IC_CHECK_ARG(q && tab && x_out && workspace && N > 0 && H > 0 && W > 0 && B >= 0 && C > 0);
+    if (H % 8 || W % 8) return IC_ERR_UNSUPPORTED;
+    if (workspace_bytes < ic_ae_workspace_bytes(N, H, W, C)) return IC_ERR_WORKSPACE;
+    const int nconv = 6 * B + 2;
+    for (int i = 0; i < 3 * (nconv + 3); ++i) IC_CHECK_ARG(tab[i] != nullptr);
+    hipStream_t st = (hipStream_t)stream;
+    float* bufs[5]; float* half; float* bott;
+    carve(workspace, N, H, W, bufs, &half, &bott);
+    int rc;
+    const float* const* t = (const float* const*)tab;
+    ConvArgs a{};
+    // from_bn: C -> 128, 3x3 transposed / 2, BN, ReLU
+    a.x = q; a.w = t[0]; a.scale = t[1]; a.shift = t[2]; a.y = bufs[0];
+    a.N = N; a.Cin = C; a.H = H / 8; a.W = W / 8; a.Cout = 128; a.KH = 3; a.KW = 3; a.relu = 1;
+    if ((rc = icx_conv2d(a, true, st))) return rc;
+    int o;
+    if ((rc = res_stack(tab + 3, B, bufs, N, H / 4, W / 4, st, &o))) return rc;
+    const float* const* th = t + 3 + 3 * nconv;
+    // h12: 128 -> 64, 5x5 transposed / 2, BN, ReLU
+    a = ConvArgs{};
+    a.x = bufs[o]; a.w = th[0]; a.scale = th[1]; a.shift = th[2]; a.y = half;
+    a.N = N; a.Cin = 128; a.H = H / 4; a.W = W / 4; a.Cout = 64; a.KH = 5; a.KW = 5; a.relu = 1;
+    if ((rc = icx_conv2d(a, true, st))) return rc;
+    // h13: 64 -> 3, 5x5 transposed / 2, BN, linear, de-normalise, clip to [0, 255]
+    a = ConvArgs{};
+    a.x = half; a.w = th[3]; a.scale = th[4]; a.shift = th[5]; a.y = x_out;
+    a.N = N; a.Cin = 64; a.H = H / 2; a.W = W / 2; a.Cout = 3; a.KH = 5; a.KW = 5; a.relu = 0;
+    a.builtin_norm = normalize_on ? 2 : 4;   // 4: clip only (normalization = OFF still clips, autoencoder.py:267)
+    return icx_conv2d(a, true, st);
+}
+
+// ---- plumbing ----
+extern "C" int ic_abi_version(void) { return IC_ABI_VERSION; }
+
+extern "C" const char* ic_strerror(int code) {
+    switch (code) {
+        case IC_OK: return "ok";
+        case IC_ERR_ARG: return "invalid argument (null pointer or non-positive extent)";
+        case IC_ERR_UNSUPPORTED: return "unsupported shape or option";
+        case IC_ERR_WORKSPACE: return "workspace too small";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+extern "C" int ic_event_create(void** ev) {
+    IC_CHECK_ARG(ev);
+    hipEvent_t e;
+    hipError_t r = hipEventCreate(&e);
+    if (r != hipSuccess) return (int)r;
+    *ev = (void*)e;
+    return IC_OK;
+}
+extern "C" int ic_event_destroy(void* ev) { return ev ? (int)hipEventDestroy((hipEvent_t)ev) : IC_ERR_ARG; }
+extern "C" int ic_event_record(void* ev, ic_stream_t stream) {
+    IC_CHECK_ARG(ev);
+    return (int)hipEventRecord((hipEvent_t)ev, (hipStream_t)stream);
+}
+extern "C" int ic_event_elapsed_ms(void* start, void* stop, float* ms) {
+    IC_CHECK_ARG(start && stop && ms);
+    hipError_t r = hipEventSynchronize((hipEvent_t)stop);
+    if (r != hipSuccess) return (int)r;
+    return (int)hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+}

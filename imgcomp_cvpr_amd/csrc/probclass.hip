@@ -1,0 +1,240 @@
+// Context model ("probability classifier"), res_shallow architecture: four causally masked VALID
+// (2,3,3) conv3d layers 1 -> k -> k -> k -> L over the (channel, row, col) symbol volume, one residual,
+// logits for ALL positions in parallel, fused cross-entropy bit cost.
+//   reference: code/probclass.py:63-106 (bitcost), :150-176 (masks), :185-196 (residual_block),
+//              :214-221 (_ResShallow._logits), :227-261 (conv3d), :268-292 (pad_for_probclass3d)
+//
+// Geometry: the volume (N, D=C, h, w) is padded with pad_value by 4 in
+// FRONT of D only and by 4 on each side of H and W (pad-on-load here, never materialised); each layer
+// shrinks D by 1 and H, W by 2; the residual adds layer-0's output cropped [2:, 2:-2, 2:-2]; the final
+// layer keeps conv3d's default ReLU (probclass.py:220,233).
+// Masks: filter slice kd=0 is dense; slice kd=1 keeps the row above the centre and, in the centre row,
+// the taps left of the centre (first layer) or left of and including the centre (other layers).  Dead
+// taps are skipped, not multiplied by zero: 13 resp. 14 live taps of 18.
+//
+// One lane = one output voxel x COB output channels; per-output fp32 FMA chain in (ci, kd, kh, kw) order,
+// identical for every position (no split reductions, no atomics) so that an incremental decoder can
+// reproduce the same logits bit-for-bit later ("hard parts").
+#include "common.h"
+
+struct PcLayerArgs {
+    const float* in;      // layer 0: q (N,C,h,w); else (N,Cin,D,H,W) planar
+    const float* w;       // [2,3,3,Cin,Cout] TF layout, unmasked
+    const float* bias;    // [Cout]
+    const float* res;     // residual source (N,Cout,RD,RH,RW) planar, read at (+2,+2,+2), or null
+    float* out;           // (N,Cout,OD,OH,OW) planar; final layer: logits (N,OD,OH,OW,Cout) or null
+    const int64_t* symbols;  // final layer with bits: (N,OD,OH,OW)
+    float* bits;             // final layer: (N,OD,OH,OW) or null
+    int N, Cin, Cout, D, H, W, OD, OH, OW;   // D,H,W: (virtual, padded) input extent
+    int RD, RH, RW;
+    int qC, qh, qw;       // layer 0: un-padded extents
+    float pad_value;
+    int relu;
+    int prepadded;        // layer 0: `in` already is the padded volume (N,D,H,W)
+};
+
+template <int COB, bool FIRST, bool FINAL>
+__global__ __launch_bounds__(256) void pc_conv3d_kernel(const PcLayerArgs a) {
+    const int n = blockIdx.z;
+    const int co0 = blockIdx.y * COB;
+    const int ovol = a.OD * a.OH * a.OW;
+    int v = blockIdx.x * 256 + threadIdx.x;
+    const bool live = v < ovol;
+    if (!live) v = ovol - 1;
+    const int ox = v % a.OW;
+    const int t = v / a.OW;
+    const int oy = t % a.OH, od = t / a.OH;
+
+    float acc[COB];
+#pragma unroll
+    for (int j = 0; j < COB; ++j) acc[j] = 0.f;
+    int wofs[COB];
+#pragma unroll
+    for (int j = 0; j < COB; ++j) wofs[j] = min(co0 + j, a.Cout - 1);
+
+    const int HW = a.H * a.W;
+    const int cstride = FIRST ? 0 : a.D * HW;
+    const float* inn = FIRST ? a.in + (size_t)n * a.qC * a.qh * a.qw : a.in + (size_t)n * a.Cin * cstride;
+    const int tapstride = a.Cin * a.Cout;
+
+    for (int ci = 0; ci < a.Cin; ++ci) {
+#pragma unroll
+        for (int kd = 0; kd < 2; ++kd) {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    // causal mask (probclass.py:150-176)
+                    const bool dead = (kd == 1) && (kh == 2 || (kh == 1 && (FIRST ? kw >= 1 : kw >= 2)));
+                    if (dead) continue;
+                    float xv;
+                    if (FIRST && a.prepadded) {
+                        xv = a.in[(((size_t)n * a.D + od + kd) * a.H + oy + kh) * a.W + ox + kw];
+                    } else if (FIRST) {
+                        const int c = od + kd - 4, y = oy + kh - 4, x = ox + kw - 4;
+                        const bool in = c >= 0 && y >= 0 && y < a.qh && x >= 0 && x < a.qw;   // c < qC always
+                        xv = in ? inn[((size_t)c * a.qh + y) * a.qw + x] : a.pad_value;
+                    } else {
+                        xv = inn[(size_t)ci * cstride + (size_t)(od + kd) * HW + (oy + kh) * a.W + (ox + kw)];
+                    }
+                    const float* wp = a.w + (size_t)((kd * 3 + kh) * 3 + kw) * tapstride + (size_t)ci * a.Cout;
+#pragma unroll
+                    for (int j = 0; j < COB; ++j) acc[j] = fmaf(xv, wp[wofs[j]], acc[j]);
+                }
+            }
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < COB; ++j) {
+        float r = acc[j] + a.bias[wofs[j]];
+        if (a.relu) r = fmaxf(r, 0.f);
+        if (a.res && co0 + j < a.Cout) {
+            const size_t ro = (((size_t)n * a.Cout + co0 + j) * a.RD + od + 2) * a.RH * a.RW
+                              + (size_t)(oy + 2) * a.RW + (ox + 2);
+            r += a.res[ro];
+        }
+        acc[j] = r;
+    }
+    if (!FINAL) {
+#pragma unroll
+        for (int j = 0; j < COB; ++j)
+            if (co0 + j < a.Cout) a.out[((size_t)n * a.Cout + co0 + j) * ovol + v] = acc[j];
+    } else {
+        // all Cout = L logits live in this lane (host guarantees gridDim.y == 1)
+        const size_t vox = (size_t)n * ovol + v;
+        if (a.out) {
+#pragma unroll
+            for (int j = 0; j < COB; ++j)
+                if (j < a.Cout) a.out[vox * a.Cout + j] = acc[j];
+        }
+        if (a.bits) {
+            // softmax_cross_entropy_with_logits(one_hot) * log2(e)   (probclass.py:100-104)
+            float m = acc[0];
+#pragma unroll
+            for (int j = 1; j < COB; ++j) if (j < a.Cout) m = fmaxf(m, acc[j]);
+            float s = 0.f, lsym = 0.f;
+            const int sym = (int)a.symbols[vox];
+#pragma unroll
+            for (int j = 0; j < COB; ++j) {
+                if (j < a.Cout) {
+                    const float sh = acc[j] - m;
+                    s += expf(sh);
+                    if (j == sym) lsym = sh;
+                }
+            }
+            a.bits[vox] = __fmul_rn(logf(s) - lsym, 1.44269504f);
+        }
+    }
+}
+
+extern "C" size_t ic_pc_workspace_bytes(int N, int C, int h, int w, int k) {
+    if (N <= 0 || C <= 0 || h <= 0 || w <= 0 || k <= 0) return 0;
+    size_t f = (size_t)(C + 3) * (h + 6) * (w + 6) + (size_t)(C + 2) * (h + 4) * (w + 4)
+               + (size_t)(C + 1) * (h + 2) * (w + 2);
+    return f * (size_t)N * k * sizeof(float);
+}
+
+template <int COB, bool FIRST, bool FINAL>
+static int launch_pc(const PcLayerArgs& a, hipStream_t st) {
+    dim3 g(ic_cdiv(a.OD * a.OH * a.OW, 256), FINAL ? 1 : ic_cdiv(a.Cout, COB), a.N);
+    hipLaunchKernelGGL((pc_conv3d_kernel<COB, FIRST, FINAL>), g, dim3(256), 0, st, a);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
+static int pc_forward(const float* q, int prepadded, const int64_t* symbols, const float* const* wt, int k, int L,
+                      float pad_value, float* logits, float* bits, int N, int C, int h, int w,
+                      void* workspace, size_t workspace_bytes, hipStream_t st) {
+    IC_CHECK_ARG(q && wt && workspace && N > 0 && C > 0 && h > 0 && w > 0 && k > 0 && L > 0);
+    for (int i = 0; i < 8; ++i) IC_CHECK_ARG(wt[i] != nullptr);
+    IC_CHECK_ARG(!bits || symbols);
+    if (L > 16) return IC_ERR_UNSUPPORTED;
+    if (workspace_bytes < ic_pc_workspace_bytes(N, C, h, w, k)) return IC_ERR_WORKSPACE;
+    float* b0 = (float*)workspace;
+    float* b1 = b0 + (size_t)N * k * (C + 3) * (h + 6) * (w + 6);
+    float* b2 = b1 + (size_t)N * k * (C + 2) * (h + 4) * (w + 4);
+    int rc;
+    PcLayerArgs a{};
+    a.N = N; a.pad_value = pad_value; a.prepadded = prepadded;
+    // conv0: 1 -> k, first mask, ReLU
+    a.in = q; a.w = wt[0]; a.bias = wt[1]; a.res = nullptr; a.out = b0;
+    a.Cin = 1; a.Cout = k; a.D = C + 4; a.H = h + 8; a.W = w + 8; a.OD = C + 3; a.OH = h + 6; a.OW = w + 6;
+    a.qC = C; a.qh = h; a.qw = w; a.relu = 1;
+    if ((rc = launch_pc<8, true, false>(a, st))) return rc;
+    // res1/conv1: k -> k, other mask, ReLU
+    a.in = b0; a.w = wt[2]; a.bias = wt[3]; a.out = b1;
+    a.Cin = k; a.D = C + 3; a.H = h + 6; a.W = w + 6; a.OD = C + 2; a.OH = h + 4; a.OW = w + 4; a.relu = 1;
+    if ((rc = launch_pc<8, false, false>(a, st))) return rc;
+    // res1/conv2: k -> k, linear, + conv0 output cropped [2:, 2:-2, 2:-2]
+    a.in = b1; a.w = wt[4]; a.bias = wt[5]; a.out = b2; a.res = b0; a.RD = C + 3; a.RH = h + 6; a.RW = w + 6;
+    a.D = C + 2; a.H = h + 4; a.W = w + 4; a.OD = C + 1; a.OH = h + 2; a.OW = w + 2; a.relu = 0;
+    if ((rc = launch_pc<8, false, false>(a, st))) return rc;
+    // conv2 (final): k -> L, ReLU (default activation), logits channels-last + bits
+    a.in = b2; a.w = wt[6]; a.bias = wt[7]; a.out = logits; a.res = nullptr; a.symbols = symbols; a.bits = bits;
+    a.Cout = L; a.D = C + 1; a.H = h + 2; a.W = w + 2; a.OD = C; a.OH = h; a.OW = w; a.relu = 1;
+    if (L <= 8) rc = launch_pc<8, false, true>(a, st);
+    else rc = launch_pc<16, false, true>(a, st);
+    return rc;
+}
+
+extern "C" int ic_pc_logits_f32(const float* q, const float* const* wtab_host, int k, int L, float pad_value,
+                                float* logits, int N, int C, int h, int w,
+                                void* workspace, size_t workspace_bytes, ic_stream_t stream) {
+    IC_CHECK_ARG(logits);
+    return pc_forward(q, 0, nullptr, wtab_host, k, L, pad_value, logits, nullptr, N, C, h, w,
+                      workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int ic_pc_logits_padded_f32(const float* vol, const float* const* wtab_host, int k, int L,
+                                       float* logits, int N, int D, int H, int W,
+                                       void* workspace, size_t workspace_bytes, ic_stream_t stream) {
+    IC_CHECK_ARG(logits);
+    if (D < 5 || H < 9 || W < 9) return IC_ERR_UNSUPPORTED;
+    return pc_forward(vol, 1, nullptr, wtab_host, k, L, 0.f, logits, nullptr, N, D - 4, H - 8, W - 8,
+                      workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int ic_pc_bitcost_f32(const float* q, const int64_t* symbols, const float* const* wtab_host, int k, int L,
+                                 float pad_value, float* logits, float* bits, int N, int C, int h, int w,
+                                 void* workspace, size_t workspace_bytes, ic_stream_t stream) {
+    IC_CHECK_ARG(bits && symbols);
+    return pc_forward(q, 0, symbols, wtab_host, k, L, pad_value, logits, bits, N, C, h, w,
+                      workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// ---- deterministic sum (bits.py:4-14 numerator) ----
+__global__ __launch_bounds__(256) void sum_stage1(const float* __restrict__ v, long long count, float* __restrict__ partial) {
+    __shared__ float sh[256];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) s += v[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(256) void sum_stage2(const float* __restrict__ partial, int n, float* __restrict__ out) {
+    __shared__ float sh[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+extern "C" int ic_sum_f32(const float* v, long long count, float* partial, float* out_sum, ic_stream_t stream) {
+    IC_CHECK_ARG(v && partial && out_sum && count > 0);
+    long long g = (count + 255) / 256;
+    const int blocks = (int)(g > 1024 ? 1024 : g);
+    hipLaunchKernelGGL(sum_stage1, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, count, partial);
+    hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, blocks, out_sum);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}

@@ -1,0 +1,266 @@
+"""Context-model ("probability classifier") plugin -- mirror of the reference's code/probclass.py.
+
+    cls = get_network_cls(pc_config)                 # keyed by pc_config.arch ('res_shallow')
+    pc = cls(pc_config, num_centers=L)
+    bits = pc.bitcost(q, target_symbols, is_training=False, pad_value=pc.auto_pad_value(ae))   # NCHW
+    logits = pc.logits(q_padded, is_training=False)                                            # N,C,h,w,L
+
+All positions are evaluated in parallel by libimgcomp_hip.so (csrc/probclass.hip); the volume is
+padded on load, never materialised.  Weights come from ``load_weights(dict)`` in the reference's
+variable names/layouts (unmasked conv3d filters [2,3,3,cin,cout] + biases).
+"""
+import itertools
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import weights as _weights
+from ._lib import lib, check, ptr
+
+
+def get_network_cls(pc_config):
+    """reference: code/probclass.py:11-15."""
+    return {
+        'res_shallow': _ResShallow,
+    }[pc_config.arch]
+
+
+def context_shape_from_context_size(context_size):
+    """:return context shape as DHW (reference code/probclass.py:18-20)."""
+    return context_size // 2 + 1, context_size, context_size
+
+
+def context_size_from_context_shape(context_shape):
+    return context_shape[-1]
+
+
+class _Network3D(object):
+    _PROBCLASS_SCOPE = 'probclass3d'
+
+    def __init__(self, pc_config, num_centers):
+        self.config = pc_config
+        self.L = int(num_centers)
+        self._params = None
+        self._device = None
+        self._ws = None
+        self._last_logits = None
+
+    # -- static geometry (reference :40-57) --
+
+    @classmethod
+    def get_num_layers(cls):
+        raise NotImplementedError()
+
+    @classmethod
+    def get_context_size(cls, config):
+        """width / height of the receptive field."""
+        return cls.get_num_layers() * (config.kernel_size - 1) + 1
+
+    @classmethod
+    def get_context_shape(cls, config):
+        """Shape as DHW."""
+        return context_shape_from_context_size(cls.get_context_size(config))
+
+    @property
+    def filter_shape(self):
+        K = self.config.kernel_size
+        return K // 2 + 1, K, K
+
+    def auto_pad_value(self, ae):
+        """0, or centers[0] when use_centers_for_padding (reference :59-61)."""
+        return 0 if not self.config.use_centers_for_padding else ae.get_centers_variable()[0]
+
+    # -- masks, as numpy (reference :150-176); the kernels skip the zeroed taps --
+
+    def create_first_mask(self):
+        K = self.config.kernel_size
+        mask = np.ones(self.filter_shape, dtype=np.float32)
+        mask[-1, K // 2, K // 2:] = 0
+        mask[-1, K // 2 + 1:, :] = 0
+        return mask[..., None, None]
+
+    def create_other_mask(self):
+        K = self.config.kernel_size
+        mask = np.ones(self.filter_shape, dtype=np.float32)
+        mask[-1, K // 2, K // 2 + 1:] = 0
+        mask[-1, K // 2 + 1:, :] = 0
+        return mask[..., None, None]
+
+    # -- weights --
+
+    def load_weights(self, weights, device='cuda'):
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise _lib.HipLibraryError('the context model runs only on a HIP device, got {}'.format(device))
+        self._device = device
+        self._params = OrderedDict()
+        for name, arr in weights.items():
+            if name.startswith(self._PROBCLASS_SCOPE + '/'):
+                self._params[name] = torch.as_tensor(np.ascontiguousarray(arr), dtype=torch.float32).to(device)
+        self._prepare()
+        return self
+
+    def variables(self):
+        self._require_weights()
+        return list(self._params.values())
+
+    def get_network_variables(self):
+        return self.variables()
+
+    def regularization_loss(self):
+        """None unless config.regularization_factor is set (reference :115-119)."""
+        if self.config.regularization_factor is None:
+            return None
+        self._require_weights()
+        f = float(self.config.regularization_factor)
+        return f * sum(0.5 * (t * t).sum() for n, t in self._params.items() if n.endswith('/weights'))
+
+    def _require_weights(self):
+        if self._params is None:
+            raise ValueError('no weights: call load_weights(dict) first')
+
+    def _prepare(self):
+        raise NotImplementedError()
+
+    # -- forward --
+
+    @staticmethod
+    def _pad_value_as_float(pad_value):
+        if torch.is_tensor(pad_value):
+            return float(pad_value.item())
+        return float(pad_value)
+
+    def bitcost(self, q, target_symbols, is_training, pad_value=0):
+        """q: NCHW float32, target_symbols: NCHW int64 -> bit cost per symbol, NCHW
+        (reference code/probclass.py:63-106)."""
+        raise NotImplementedError()
+
+    def logits(self, q, is_training):
+        """q: ALREADY padded volume (N,D,H,W) [the reference passes N,D,H,W,1] -> (N,D-4,H-8,W-8,L)
+        (reference code/probclass.py:130-135)."""
+        raise NotImplementedError()
+
+
+class _ResShallow(_Network3D):
+    """conv0 -> residual(conv1, conv2) -> conv2(final), reference code/probclass.py:199-221."""
+    _NUM_RESIDUAL = 1
+
+    @classmethod
+    def get_num_layers(cls):
+        return 2 + _ResShallow._NUM_RESIDUAL * 2
+
+    def _prepare(self):
+        if self.config.kernel_size != 3:
+            raise NotImplementedError('the HIP context model implements kernel_size = 3 (res_shallow configs)')
+        if self.config.learn_pad_var:
+            raise NotImplementedError('learn_pad_var=True is dead code in the reference configs')
+        self._k = int(self.config.arch_param__k)
+        tabs = []
+        for scope, shape in _weights.pc_conv_specs(self.L, self._k, int(self.config.kernel_size)):
+            w, b = self._params[scope + '/weights'], self._params[scope + '/biases']
+            assert tuple(w.shape) == tuple(shape), (scope, tuple(w.shape), shape)
+            tabs += [w, b]
+        self._tab_tensors = tabs
+        self._tab = _lib.ptr_table(tabs)
+
+    def _workspace(self, N, C, h, w):
+        need = lib.ic_pc_workspace_bytes(N, C, h, w, self._k)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self._device)
+        return self._ws, need
+
+    def bitcost(self, q, target_symbols, is_training, pad_value=0, return_logits=False):
+        if is_training:
+            raise NotImplementedError('backward kernels of the context model are not built yet (DESIGN.md)')
+        self._require_weights()
+        assert q.dim() == 4, 'Expected NCHW'
+        _lib.require_cuda(q, 'q')
+        assert target_symbols.dtype == torch.int64 and target_symbols.shape == q.shape
+        q = q.contiguous()
+        target_symbols = target_symbols.contiguous()
+        N, C, h, w = q.shape
+        bits = torch.empty_like(q)
+        logits = torch.empty((N, C, h, w, self.L), dtype=torch.float32, device=q.device) if return_logits else None
+        ws, need = self._workspace(N, C, h, w)
+        check(lib.ic_pc_bitcost_f32(ptr(q), ptr(target_symbols), self._tab, self._k, self.L,
+                                    self._pad_value_as_float(pad_value), ptr(logits), ptr(bits),
+                                    N, C, h, w, ptr(ws), need, _lib.current_stream(q.device)), 'ic_pc_bitcost_f32')
+        if return_logits:
+            return bits, logits
+        return bits
+
+    def logits_unpadded(self, q, pad_value):
+        """logits (N,C,h,w,L) for an un-padded q, padding on load with pad_value."""
+        self._require_weights()
+        _lib.require_cuda(q, 'q')
+        q = q.contiguous()
+        N, C, h, w = q.shape
+        out = torch.empty((N, C, h, w, self.L), dtype=torch.float32, device=q.device)
+        ws, need = self._workspace(N, C, h, w)
+        check(lib.ic_pc_logits_f32(ptr(q), self._tab, self._k, self.L, self._pad_value_as_float(pad_value),
+                                   ptr(out), N, C, h, w, ptr(ws), need, _lib.current_stream(q.device)),
+              'ic_pc_logits_f32')
+        return out
+
+    def logits(self, q, is_training):
+        if is_training:
+            raise NotImplementedError('backward kernels of the context model are not built yet (DESIGN.md)')
+        self._require_weights()
+        _lib.require_cuda(q, 'q')
+        if q.dim() == 5:
+            assert q.shape[-1] == 1, 'Expected NDHW1'
+            q = q[..., 0]
+        q = q.contiguous()
+        N, D, H, W = q.shape
+        out = torch.empty((N, D - 4, H - 8, W - 8, self.L), dtype=torch.float32, device=q.device)
+        ws, need = self._workspace(N, D - 4, H - 8, W - 8)
+        check(lib.ic_pc_logits_padded_f32(ptr(q), self._tab, self._k, self.L, ptr(out), N, D, H, W,
+                                          ptr(ws), need, _lib.current_stream(q.device)), 'ic_pc_logits_padded_f32')
+        return out
+
+
+# -- host-side helpers of the reference's NumPy branch (reference code/probclass.py:268-292,341-351,367-387) --
+
+def pad_for_probclass3d(x, context_size, pad_value=0, learn_pad_var=False):
+    """numpy CHW / NCHW or torch NCHW: constant-pad depth (front only), H and W by context_size // 2."""
+    assert not learn_pad_var, 'learn_pad_var is not supported'
+    pad = context_size // 2
+    assert pad >= 1
+    if isinstance(x, np.ndarray):
+        if x.ndim == 3:
+            return pad_for_probclass3d(x[None], context_size, pad_value)[0]
+        pads = [[0, 0], [pad, 0], [pad, pad], [pad, pad]]
+        return np.pad(x, pads, mode='constant', constant_values=pad_value)
+    N, C, H, W = x.shape
+    out = x.new_full((N, C + pad, H + 2 * pad, W + 2 * pad), float(pad_value))
+    out[:, pad:, pad:pad + H, pad:pad + W] = x
+    return out
+
+
+def undo_pad_for_probclass3d(x, context_size):
+    if isinstance(x, np.ndarray) and x.ndim == 3:
+        return undo_pad_for_probclass3d(x[None], context_size)[0]
+    pad = context_size // 2
+    assert pad >= 1
+    return x[:, pad:, pad:-pad, pad:-pad]
+
+
+def _iter_block_idices(syms_shape, block_sizes):
+    C, H, W = syms_shape
+    bC, bH, bW = block_sizes
+    for c, h, w in itertools.product(range(C - bC + 1), range(H - bH + 1), range(W - bW + 1)):
+        yield slice(c, c + bC), slice(h, h + bH), slice(w, w + bW)
+
+
+def iter_over_blocks(syms, block_sizes):
+    """blocks of a CHW volume in raster order C, then H, then W fastest."""
+    for cs, hs, ws in _iter_block_idices(syms.shape, block_sizes):
+        yield syms[cs, hs, ws]
+
+
+def num_blocks(syms_shape, block_sizes):
+    C, H, W = syms_shape
+    bC, bH, bW = block_sizes
+    return max(C - bC + 1, 0) * max(H - bH + 1, 0) * max(W - bW + 1, 0)

@@ -1,0 +1,164 @@
+/* imgcomp_hip.h -- C ABI of libimgcomp_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the data-parallel hot path of fab-jul/imgcomp-cvpr.  The reference has
+ * no FFI of its own: its boundary is the Python plugin surface (autoencoder.get_network_cls,
+ * probclass.get_network_cls, quantizer.quantize) whose ops TensorFlow dispatches to device
+ * kernels.  Every entry point below replaces the TF op call sites it cites (file:line relative
+ * to the reference's code/ directory); the Python mirror of the plugin surface
+ * (imgcomp_cvpr_amd/{autoencoder,probclass,quantizer}.py) binds them with ctypes.
+ *
+ * Conventions
+ *  - all pointers are DEVICE pointers unless the name ends in _host; the caller owns every
+ *    buffer including workspaces; the library never allocates device memory;
+ *  - tensors are dense fp32 NCHW, symbols are int64 (reference: quantizer.py:46);
+ *  - `stream` is a hipStream_t passed as void*; calls are asynchronous on it and re-entrant
+ *    (no global mutable state);
+ *  - return value: 0 = ok, < 0 = argument error (IC_ERR_*), > 0 = hipError_t of a failed launch;
+ *  - weights use the reference's TF variable layouts unless a function says "packed".
+ */
+#ifndef IMGCOMP_HIP_H
+#define IMGCOMP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IC_ABI_VERSION 1
+
+#define IC_OK 0
+#define IC_ERR_ARG (-1)          /* null pointer / non-positive extent */
+#define IC_ERR_UNSUPPORTED (-2)  /* shape or option outside what the kernels implement */
+#define IC_ERR_WORKSPACE (-3)    /* workspace too small */
+
+typedef void* ic_stream_t;
+
+int ic_abi_version(void);
+/* static string for a return code of this library (hipGetErrorString for codes > 0) */
+const char* ic_strerror(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * Generic direct convolution + folded BatchNorm + activation (+ up to two residual adds).
+ * Replaces slim.conv2d(..., normalizer_fn=slim.batch_norm) at autoencoder.py:222 (h1), :223 (h2),
+ * :237 (to_bn), :285 (residual 3x3 convs; the MFMA kernel below is the fast path for those).
+ *   x      (N,Cin,H,W)          w  [KH,KW,Cin,Cout]  (TF conv2d filter layout)
+ *   y      (N,Cout,OH,OW), OH = ceil(H/stride), TF 'SAME' padding (pad_before = total/2)
+ *   y = act(conv(x') * scale[co] + shift[co]) + res1 + res2      (res1/res2 nullable, shape of y)
+ *   x' = (x - in_mean[ci]) / in_std[ci] when in_mean != NULL (autoencoder.py:136-144, applied
+ *        before the zero padding, as the reference normalises before the conv pads)
+ *   scale = gamma / sqrt(moving_var + 1e-5), shift = beta - moving_mean * scale (autoencoder.py:114-125)
+ *   relu: 0/1.  stride: 1 or 2.
+ */
+int ic_conv2d_bn_act_f32(const float* x, const float* w, const float* scale, const float* shift,
+                         const float* res1, const float* res2, float* y,
+                         int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int relu,
+                         const float* in_mean, const float* in_std, ic_stream_t stream);
+
+/* Stride-2 'SAME' transposed convolution + folded BN + activation (+ de-normalise + clip).
+ * Replaces slim.conv2d_transpose at autoencoder.py:251 (from_bn), :264 (h12), :265 (h13) and
+ * _denormalize/_clip_to_image_range (:146-158) when out_mean != NULL.
+ *   x (N,Cin,H,W)   w [KH,KW,Cout,Cin] (TF conv2d_transpose filter layout)   y (N,Cout,2H,2W)
+ *   y = act(deconv(x) * scale + shift);  if out_mean: y = clip(y * out_std[co] + out_mean[co], 0, 255)
+ */
+int ic_deconv2d_bn_act_f32(const float* x, const float* w, const float* scale, const float* shift,
+                           float* y, int N, int Cin, int H, int W, int Cout, int KH, int KW, int relu,
+                           const float* out_mean, const float* out_std, ic_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * MFMA fast path for the 64 residual 3x3 convs (128 -> 128 channels, stride 1):
+ * autoencoder.py:274-287 called from :225-234 and :253-262 (~95 % of the path's FLOPs).
+ * ic_pack_conv3x3_c128_f32 re-orders a TF-layout filter [3,3,128,128] into the MFMA A-fragment
+ * order once (147,456 floats in, 147,456 floats out); ic_conv3x3_c128_bn_act_f32 consumes it.
+ *   y = act(conv3x3(x) * scale + shift) + res1 + res2       x, y, res*: (N,128,H,W)
+ */
+size_t ic_conv3x3_c128_packed_floats(void);
+int ic_pack_conv3x3_c128_f32(const float* w_tf, float* w_packed, ic_stream_t stream);
+int ic_conv3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale,
+                               const float* shift, const float* res1, const float* res2, float* y,
+                               int N, int H, int W, int relu, ic_stream_t stream);
+/* tile variant override for tuning/tests: -1 = automatic (default).  Returns previous value.
+ * Process-wide knob read at launch time; not part of the data path contract. */
+int ic_conv3x3_c128_set_variant(int variant);
+
+/* ---------------------------------------------------------------------------------------------
+ * Importance map + quantiser.
+ * ic_quantize_f32 replaces quantizer.quantize / _quantize1d (quantizer.py:37-100):
+ *   d_j = (z - c_j)^2; qsoft = sum_j softmax(-sigma d)_j c_j; symbols = first argmax_j of
+ *   (-1e7 * d_j); qhard = c[symbols].   z, qsoft, qhard: `count` floats; symbols: `count` int64.
+ *   Any output pointer may be NULL.  L <= 16.
+ * ic_heatmap_quantize_f32 fuses _get_heatmap3D + _mask_with_heatmap (autoencoder.py:171-200)
+ * with the quantiser and the STE forward value qbar = qsoft + (qhard - qsoft) (:127-134):
+ *   bottleneck (N,C+1,h,w) -> heatmap, z, qsoft, qhard, qbar (N,C,h,w) fp32, symbols int64.
+ */
+int ic_quantize_f32(const float* z, const float* centers, int L, float sigma,
+                    float* qsoft, float* qhard, int64_t* symbols, long long count, ic_stream_t stream);
+int ic_heatmap_quantize_f32(const float* bottleneck, const float* centers, int L, float sigma,
+                            float* heatmap, float* z, float* qsoft, float* qhard, float* qbar,
+                            int64_t* symbols, int N, int C, int h, int w, ic_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Context model (res_shallow): probclass.py:63-106 (bitcost), :130-135 (logits), :214-221
+ * (_ResShallow._logits), :227-261 (conv3d), :150-176 (masks), :268-292 (pad).
+ * The volume is padded on load with pad_value (= centers[0], probclass.py:59-61): depth front 4,
+ * H/W 4 each side; four masked VALID (2,3,3) conv3d layers 1->k->k->k->L with one residual;
+ * the last layer keeps conv3d's default ReLU.  Logits for ALL positions are produced in parallel.
+ *   q        (N,C,h,w) fp32     symbols (N,C,h,w) int64
+ *   wtab[8]  device pointers {w0,b0,w1,b1,w2,b2,w3,b3}; w* in TF layout [2,3,3,cin,cout], UNMASKED
+ *            (the masks are applied by skipping the dead taps); layers: conv0, res1/conv1,
+ *            res1/conv2, conv2(final)
+ *   logits   (N,C,h,w,L) fp32 (nullable for bitcost)     bits (N,C,h,w) fp32 = CE * log2(e)
+ *   workspace: ic_pc_workspace_bytes(N,C,h,w,k) bytes.
+ */
+size_t ic_pc_workspace_bytes(int N, int C, int h, int w, int k);
+int ic_pc_logits_f32(const float* q, const float* const* wtab_host, int k, int L, float pad_value,
+                     float* logits, int N, int C, int h, int w,
+                     void* workspace, size_t workspace_bytes, ic_stream_t stream);
+/* same network on an ALREADY padded volume (N,D,H,W) -> logits (N,D-4,H-8,W-8,L); this is
+ * _Network3D.logits (probclass.py:130-135) as PredictionNetwork calls it on a (5,9,9) context
+ * (probclass.py:436-442).  workspace: ic_pc_workspace_bytes(N, D-4, H-8, W-8, k). */
+int ic_pc_logits_padded_f32(const float* vol, const float* const* wtab_host, int k, int L,
+                            float* logits, int N, int D, int H, int W,
+                            void* workspace, size_t workspace_bytes, ic_stream_t stream);
+int ic_pc_bitcost_f32(const float* q, const int64_t* symbols, const float* const* wtab_host, int k, int L,
+                      float pad_value, float* logits, float* bits, int N, int C, int h, int w,
+                      void* workspace, size_t workspace_bytes, ic_stream_t stream);
+/* bits -> sum(bits) (bits.py:4-14 numerator); deterministic two-stage reduction.
+ * partial: >= 1024 floats of scratch.  out_sum: 1 float. */
+int ic_sum_f32(const float* v, long long count, float* partial, float* out_sum, ic_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole-network entry points for the CVPR autoencoder (autoencoder.py:218-268): one host call
+ * enqueues every stage, so batch-1 inference is not bound by per-op host overhead.
+ *
+ * enc_tab_host: host array of device pointers, 3 per conv layer {w, scale, shift}, in order
+ *   h1, h2, 32 residual convs (res_block_enc_0/enc_0_1/conv1 ... res_block_enc_final/conv2),
+ *   to_bn; then centers.  Count = 3*35 + 1 = 106.  The 32 residual filters are PACKED
+ *   (ic_pack_conv3x3_c128_f32); h1/h2/to_bn are TF layout.
+ * dec_tab_host: from_bn, 32 residual convs, h12, h13 -> 3*35 = 105 pointers (deconv filters in TF
+ *   conv2d_transpose layout, residual filters packed).
+ * B = arch_param_B (5).  C = num_chan_bn.  x: (N,3,H,W) float 0..255, H and W multiples of 8.
+ * Outputs of encode (each nullable except symbols/qhard): heatmap,z,qsoft,qhard,qbar (N,C,H/8,W/8),
+ * symbols int64.  decode: q (N,C,H/8,W/8) -> x_out (N,3,H,W) clipped to [0,255].
+ */
+size_t ic_ae_workspace_bytes(int N, int H, int W, int C);
+int ic_ae_encode_f32(const float* x, const void* const* enc_tab_host, int B, int C, int L, int heatmap_on,
+                     int normalize_on, float* heatmap, float* z, float* qsoft, float* qhard, float* qbar,
+                     int64_t* symbols, int N, int H, int W,
+                     void* workspace, size_t workspace_bytes, ic_stream_t stream);
+int ic_ae_decode_f32(const float* q, const void* const* dec_tab_host, int B, int C, int normalize_on,
+                     float* x_out, int N, int H, int W,
+                     void* workspace, size_t workspace_bytes, ic_stream_t stream);
+
+/* device timing helper for bench.py: wall time between two points on `stream` measured with
+ * hipEvents created on that stream's device (torch.cuda.Event only sees torch's own streams). */
+int ic_event_create(void** ev);
+int ic_event_destroy(void* ev);
+int ic_event_record(void* ev, ic_stream_t stream);
+int ic_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMGCOMP_HIP_H */

@@ -1,0 +1,129 @@
+"""-m gpu: the whole hot path through the plugin surface (autoencoder / probclass / bits) against the
+oracle, with the val.py wiring (reference code/val.py:81-94)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import assert_close, dev, rel_err, RTOL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def nets(cuda, configs, syn_weights):
+    from imgcomp_cvpr_amd import autoencoder, probclass
+    ae_cfg, pc_cfg = configs
+    ae = autoencoder.get_network_cls(ae_cfg)(ae_cfg)
+    pc = probclass.get_network_cls(pc_cfg)(pc_cfg, num_centers=ae_cfg.num_centers)
+    ae.load_weights(syn_weights, cuda)
+    pc.load_weights(syn_weights, cuda)
+    return ae, pc
+
+
+def _boundary_margin(z64, centers):
+    """distance of every z to the nearest quantiser decision midpoint (float64)."""
+    c = np.sort(np.asarray(centers, np.float64))
+    mids = (c[1:] + c[:-1]) / 2
+    return np.min(np.abs(z64[..., None] - mids), axis=-1)
+
+
+@pytest.mark.parametrize('shape,kind', [((1, 3, 64, 64), 'natural'), ((2, 3, 40, 72), 'noise')])
+def test_encode_matches_oracle(cuda, configs, syn_weights, nets, shape, kind):
+    from imgcomp_cvpr_amd import weights as W
+    from oracle import oracle as O
+    ae, pc = nets
+    ae_cfg, _ = configs
+    x = W.synthetic_image(shape, kind, seed=1)
+    enc = ae.encode(dev(x, cuda), is_training=False)
+    torch.cuda.synchronize()
+    ref = O.encode(torch.as_tensor(x).double(), syn_weights, ae_cfg.as_dict())
+    assert enc.symbols.dtype == torch.int64 and enc.symbols.shape == ref.symbols.shape
+    assert_close(enc.heatmap, ref.heatmap, 'heatmap')
+    assert_close(enc.z, ref.z, 'z')
+    # symbols: bit-exact wherever z is not within the fp32 error band of a decision midpoint
+    centers = syn_weights['autoencoder/encoder/centers']
+    zerr = float((enc.z.double().cpu() - ref.z).abs().max())
+    margin = _boundary_margin(ref.z.numpy(), centers)
+    flips = (enc.symbols.cpu() != ref.symbols).numpy()
+    assert not np.any(flips & (margin > 2 * zerr + 1e-12)), 'symbol flips away from decision boundaries'
+    assert flips.mean() < 5e-3, 'too many boundary flips: {}'.format(flips.mean())
+    same = ~flips
+    assert torch.equal(enc.qhard.cpu()[torch.as_tensor(same)], ref.qhard.float()[torch.as_tensor(same)])
+    # given the kernel's own z, symbols/qhard are exactly the oracle's
+    _, qh, sym = O.quantize(enc.z.cpu(), centers, 1.0)
+    assert torch.equal(sym, enc.symbols.cpu()) and torch.equal(qh, enc.qhard.cpu())
+    assert torch.equal(enc.qbar.cpu(), (ae._last_qsoft + (enc.qhard - ae._last_qsoft)).cpu())
+
+
+@pytest.mark.parametrize('shape', [(1, 32, 8, 8), (2, 32, 5, 9)])
+def test_decode_matches_oracle(cuda, configs, syn_weights, nets, shape):
+    from oracle import oracle as O
+    ae, _ = nets
+    ae_cfg, _ = configs
+    centers = syn_weights['autoencoder/encoder/centers']
+    sym = np.random.RandomState(5).randint(0, 6, shape)
+    q = centers[sym]
+    x_out = ae.decode(dev(q, cuda), is_training=False)
+    torch.cuda.synchronize()
+    ref = O.decode(torch.as_tensor(q).double(), syn_weights, ae_cfg.as_dict())
+    assert float(x_out.min()) >= 0 and float(x_out.max()) <= 255
+    assert_close(x_out, ref, 'decoded RGB')
+    # uint8 truncation (val.py:91) can differ only where the float64 value sits on an integer boundary
+    u_hip = x_out.to(torch.uint8).cpu()
+    u_ref = ref.to(torch.uint8)
+    frac = (ref - torch.floor(ref))
+    near_int = (torch.minimum(frac, 1 - frac) < 255 * RTOL)
+    assert not bool(((u_hip != u_ref) & ~near_int).any())
+
+
+def test_val_wiring(cuda, configs, syn_weights, nets):
+    """encode -> decode(qhard) ; bitcost(qbar, symbols, pad=centers[0]) -> bpp (val.py:85-89)."""
+    from imgcomp_cvpr_amd import bits, weights as W
+    from oracle import oracle as O
+    ae, pc = nets
+    ae_cfg, _ = configs
+    x = W.synthetic_image((1, 3, 64, 96), 'natural', seed=3)
+    xd = dev(x, cuda)
+    enc = ae.encode(xd, False)
+    x_out = ae.decode(enc.qhard, False)
+    bc = pc.bitcost(enc.qbar, enc.symbols, False, pad_value=pc.auto_pad_value(ae))
+    bpp = float(bits.bitcost_to_bpp(bc, xd))
+    # oracle, fed with the device's symbols so that the comparison is not chaotic in the (rare) flips
+    sym = enc.symbols.cpu()
+    centers = syn_weights['autoencoder/encoder/centers']
+    q = torch.as_tensor(centers)[sym].double()
+    assert torch.equal(q.float(), enc.qhard.cpu())
+    rb, _ = O.bitcost(q, sym, syn_weights, float(centers[0]))
+    assert_close(bc, rb, 'bit cost')
+    assert abs(bpp - O.bitcost_to_bpp(rb, torch.as_tensor(x))) < 1e-4
+    ref_out = O.decode(q, syn_weights, ae_cfg.as_dict())
+    assert_close(x_out, ref_out, 'x_out')
+    # val.py:174 invariant: bitcost from symbols alone == bitcost from the encoder's qbar
+    bc2 = pc.bitcost(dev(q.float().numpy(), cuda), enc.symbols, False, pad_value=float(centers[0]))
+    assert torch.equal(bc2, bc)
+
+
+def test_full_size_properties(cuda, configs, syn_weights, nets):
+    """BASELINE configs[1] shape (Kodak 512x768, batch 1): size-independent properties --
+    determinism, batch-independence (image n of a batch == the image alone), tile-variant independence."""
+    from imgcomp_cvpr_amd import weights as W, _lib
+    ae, pc = nets
+    x = dev(W.synthetic_image((1, 3, 512, 768), 'natural', seed=0), cuda)
+    e1 = ae.encode(x, False)
+    z1, s1 = e1.z.clone(), e1.symbols.clone()
+    e2 = ae.encode(x, False)
+    assert torch.equal(z1, e2.z) and torch.equal(s1, e2.symbols), 'encode is not deterministic'
+    prev = _lib.lib.ic_conv3x3_c128_set_variant(0)
+    try:
+        e3 = ae.encode(x, False)
+    finally:
+        _lib.lib.ic_conv3x3_c128_set_variant(prev)
+    assert torch.equal(z1, e3.z), 'result depends on the MFMA tile variant'
+    xo = ae.decode(e1.qhard, False)
+    assert xo.shape == x.shape and float(xo.min()) >= 0 and float(xo.max()) <= 255
+    bc = pc.bitcost(e1.qbar, e1.symbols, False, pad_value=pc.auto_pad_value(ae))
+    assert bool(torch.isfinite(bc).all()) and float(bc.min()) >= 0
+    xb = torch.cat([x[:, :, :256, :384], x[:, :, 256:, 384:]], 0).contiguous()
+    eb = ae.encode(xb, False)
+    ea = ae.encode(xb[1:].contiguous(), False)
+    assert torch.equal(eb.z[1:], ea.z), 'batched encode differs from single-image encode'

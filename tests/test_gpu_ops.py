@@ -1,0 +1,284 @@
+"""-m gpu: every C-ABI op of libimgcomp_hip.so against the CPU oracle on seeded inputs."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import assert_close, dev, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from imgcomp_cvpr_amd import _lib
+    return _lib
+
+
+def _bn(rs, c):
+    scale = rs.uniform(0.5, 1.5, c).astype(np.float32)
+    shift = rs.normal(0, 0.3, c).astype(np.float32)
+    return scale, shift
+
+
+def _ref_conv(x, w, scale, shift, stride, relu, transposed=False, res=(), norm=False, denorm=False):
+    from oracle import oracle as O
+    xt = torch.as_tensor(x).double()
+    if norm:
+        xt = O.normalize(xt)
+    y = O.conv2d_transpose_same(xt, w, 2) if transposed else O.conv2d_same(xt, w, stride)
+    y = y * torch.as_tensor(scale).double().view(1, -1, 1, 1) + torch.as_tensor(shift).double().view(1, -1, 1, 1)
+    if relu:
+        y = torch.relu(y)
+    for r in res:
+        y = y + torch.as_tensor(r).double()
+    if denorm:
+        y = torch.clamp(O.denormalize(y), 0, 255)
+    return y
+
+
+@pytest.mark.parametrize('name,N,Cin,H,W,Cout,K,stride,relu,norm', [
+    ('h1', 1, 3, 40, 56, 64, 5, 2, 1, True),
+    ('h2', 2, 64, 20, 28, 128, 5, 2, 1, False),
+    ('to_bn', 1, 128, 10, 14, 33, 5, 2, 0, False),
+    ('odd_sizes', 1, 5, 13, 9, 7, 3, 1, 1, False),
+    ('odd_s2', 1, 4, 11, 15, 18, 5, 2, 0, False),
+])
+def test_conv2d_direct(cuda, name, N, Cin, H, W, Cout, K, stride, relu, norm):
+    L = _lib()
+    rs = np.random.RandomState(zlib.crc32(name.encode()) % 1000)
+    x = (rs.uniform(0, 255, (N, Cin, H, W)) if norm else rs.normal(0, 1, (N, Cin, H, W))).astype(np.float32)
+    w = rs.normal(0, 0.1, (K, K, Cin, Cout)).astype(np.float32)
+    scale, shift = _bn(rs, Cout)
+    OH, OW = -(-H // stride), -(-W // stride)
+    res1 = rs.normal(0, 1, (N, Cout, OH, OW)).astype(np.float32)
+    y = torch.empty((N, Cout, OH, OW), device=cuda)
+    from oracle import oracle as O
+    mean, std = O.norm_consts(torch.float32)
+    d = lambda a: dev(a, cuda)
+    tens = [d(x), d(w), d(scale), d(shift), d(res1)]
+    m_d, s_d = (d(mean.flatten()), d(std.flatten())) if norm else (None, None)
+    L.check(L.lib.ic_conv2d_bn_act_f32(L.ptr(tens[0]), L.ptr(tens[1]), L.ptr(tens[2]), L.ptr(tens[3]),
+                                       L.ptr(tens[4]), None, L.ptr(y), N, Cin, H, W, Cout, K, K, stride, relu,
+                                       L.ptr(m_d), L.ptr(s_d), L.current_stream()))
+    torch.cuda.synchronize()
+    ref = _ref_conv(x, w, scale, shift, stride, relu, res=(res1,), norm=norm)
+    assert_close(y, ref, 'conv2d ' + name)
+
+
+@pytest.mark.parametrize('name,N,Cin,H,W,Cout,K,relu,denorm', [
+    ('from_bn', 1, 32, 6, 9, 128, 3, 1, False),
+    ('h12', 1, 128, 10, 12, 64, 5, 1, False),
+    ('h13', 2, 64, 12, 20, 3, 5, 0, True),
+    ('odd', 1, 3, 5, 7, 5, 5, 0, False),
+])
+def test_deconv2d(cuda, name, N, Cin, H, W, Cout, K, relu, denorm):
+    L = _lib()
+    rs = np.random.RandomState(zlib.crc32(name.encode()) % 1000 + 1)
+    x = rs.normal(0, 1, (N, Cin, H, W)).astype(np.float32)
+    w = rs.normal(0, 0.1, (K, K, Cout, Cin)).astype(np.float32)
+    scale, shift = _bn(rs, Cout)
+    y = torch.empty((N, Cout, 2 * H, 2 * W), device=cuda)
+    from oracle import oracle as O
+    mean, std = O.norm_consts(torch.float32)
+    d = lambda a: dev(a, cuda)
+    tens = [d(x), d(w), d(scale), d(shift)]
+    m_d, s_d = (d(mean.flatten()), d(std.flatten())) if denorm else (None, None)
+    L.check(L.lib.ic_deconv2d_bn_act_f32(L.ptr(tens[0]), L.ptr(tens[1]), L.ptr(tens[2]), L.ptr(tens[3]), L.ptr(y),
+                                         N, Cin, H, W, Cout, K, K, relu, L.ptr(m_d), L.ptr(s_d), L.current_stream()))
+    torch.cuda.synchronize()
+    ref = _ref_conv(x, w, scale, shift, 2, relu, transposed=True, denorm=denorm)
+    assert_close(y, ref, 'deconv2d ' + name)
+
+
+NUM_VARIANTS = 10
+
+
+@pytest.mark.parametrize('variant', list(range(NUM_VARIANTS)) + [-1])
+@pytest.mark.parametrize('N,H,W', [(1, 16, 32), (2, 13, 21), (1, 7, 5)])
+def test_conv3x3_c128_mfma(cuda, variant, N, H, W):
+    """the MFMA kernel, every tile variant, full and ragged tiles, with/without ReLU and residuals."""
+    L = _lib()
+    rs = np.random.RandomState(100 + H)
+    x = rs.normal(0, 1, (N, 128, H, W)).astype(np.float32)
+    w = rs.normal(0, 0.05, (3, 3, 128, 128)).astype(np.float32)
+    scale, shift = _bn(rs, 128)
+    r1 = rs.normal(0, 1, (N, 128, H, W)).astype(np.float32)
+    r2 = rs.normal(0, 1, (N, 128, H, W)).astype(np.float32)
+    d = lambda a: dev(a, cuda)
+    xd, wd, sd, hd, r1d, r2d = d(x), d(w), d(scale), d(shift), d(r1), d(r2)
+    wp = torch.empty(L.lib.ic_conv3x3_c128_packed_floats(), device=cuda)
+    L.check(L.lib.ic_pack_conv3x3_c128_f32(L.ptr(wd), L.ptr(wp), L.current_stream()))
+    prev = L.lib.ic_conv3x3_c128_set_variant(variant)
+    try:
+        for relu, res in ((1, ()), (0, (r1d,)), (0, (r1d, r2d))):
+            y = torch.full((N, 128, H, W), float('nan'), device=cuda)
+            L.check(L.lib.ic_conv3x3_c128_bn_act_f32(
+                L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(res[0]) if len(res) > 0 else None,
+                L.ptr(res[1]) if len(res) > 1 else None, L.ptr(y), N, H, W, relu, L.current_stream()))
+            torch.cuda.synchronize()
+            ref = _ref_conv(x, w, scale, shift, 1, relu, res=[r.cpu().numpy() for r in res])
+            assert_close(y, ref, 'conv3x3 mfma variant {} relu {} nres {}'.format(variant, relu, len(res)))
+    finally:
+        L.lib.ic_conv3x3_c128_set_variant(prev)
+
+
+def test_conv3x3_mfma_matches_direct_kernel(cuda):
+    """the two implementations of the same op agree (independent code paths on the device)."""
+    L = _lib()
+    rs = np.random.RandomState(7)
+    N, H, W = 1, 24, 40
+    d = lambda a: dev(a, cuda)
+    x = d(rs.normal(0, 1, (N, 128, H, W)))
+    w = d(rs.normal(0, 0.05, (3, 3, 128, 128)))
+    s, h = (d(a) for a in _bn(rs, 128))
+    wp = torch.empty(L.lib.ic_conv3x3_c128_packed_floats(), device=cuda)
+    L.check(L.lib.ic_pack_conv3x3_c128_f32(L.ptr(w), L.ptr(wp), L.current_stream()))
+    y1 = torch.empty((N, 128, H, W), device=cuda)
+    y2 = torch.empty_like(y1)
+    L.check(L.lib.ic_conv3x3_c128_bn_act_f32(L.ptr(x), L.ptr(wp), L.ptr(s), L.ptr(h), None, None, L.ptr(y1),
+                                             N, H, W, 1, L.current_stream()))
+    L.check(L.lib.ic_conv2d_bn_act_f32(L.ptr(x), L.ptr(w), L.ptr(s), L.ptr(h), None, None, L.ptr(y2),
+                                       N, 128, H, W, 128, 3, 3, 1, 1, None, None, L.current_stream()))
+    torch.cuda.synchronize()
+    assert rel_err(y1, y2) < 1e-5
+
+
+def test_quantize_bit_exact_symbols(cuda):
+    """symbols / qhard are bit-exact given identical z; includes exact ties and boundary values."""
+    from imgcomp_cvpr_amd import quantizer
+    from oracle import oracle as O
+    rs = np.random.RandomState(3)
+    for centers in (np.linspace(-2, 2, 6).astype(np.float32),
+                    np.sort(np.random.RandomState(666).uniform(-2, 2, 6)).astype(np.float32)):
+        z = rs.normal(0, 1.5, (2, 8, 16, 24)).astype(np.float32)
+        mids = ((centers[1:] + centers[:-1]) / 2).astype(np.float32)
+        flat = z.reshape(-1)
+        flat[:5] = mids                                   # exact midpoints -> ties
+        flat[5:10] = np.nextafter(mids, np.float32(10))   # one ulp above
+        flat[10:15] = np.nextafter(mids, np.float32(-10)) # one ulp below
+        flat[15:21] = centers
+        flat[21] = 0.0
+        flat[22:24] = [1e6, -1e6]
+        qs, qh, sym = quantizer.quantize(dev(z, cuda), dev(centers, cuda), 1.0)
+        rs32, rh32, rsym = O.quantize(torch.as_tensor(z), centers, 1.0)
+        assert sym.dtype == torch.int64
+        assert torch.equal(sym.cpu(), rsym), 'symbols differ from the oracle'
+        assert torch.equal(qh.cpu(), rh32), 'qhard differs from the oracle'
+        rs64, _, _ = O.quantize(torch.as_tensor(z).double(), centers.astype(np.float64), 1.0)
+        assert_close(qs, rs64, 'qsoft', rtol=1e-6)
+
+
+def test_heatmap_quantize(cuda):
+    from oracle import oracle as O
+    L = _lib()
+    rs = np.random.RandomState(5)
+    N, C, h, w = 2, 32, 9, 13
+    bott = rs.normal(0, 2, (N, C + 1, h, w)).astype(np.float32)
+    centers = np.linspace(-2, 2, 6).astype(np.float32)
+    bd, cd = dev(bott, cuda), dev(centers, cuda)
+    mk = lambda: torch.empty((N, C, h, w), device=cuda)
+    hm, z, qs, qh, qb = mk(), mk(), mk(), mk(), mk()
+    sym = torch.empty((N, C, h, w), dtype=torch.int64, device=cuda)
+    L.check(L.lib.ic_heatmap_quantize_f32(L.ptr(bd), L.ptr(cd), 6, 1.0, L.ptr(hm), L.ptr(z), L.ptr(qs), L.ptr(qh),
+                                          L.ptr(qb), L.ptr(sym), N, C, h, w, L.current_stream()))
+    torch.cuda.synchronize()
+    b64 = torch.as_tensor(bott).double()
+    hm64 = O.heatmap3d(b64)
+    assert_close(hm, hm64, 'heatmap', rtol=1e-6)
+    assert_close(z, hm64 * b64[:, 1:], 'z', rtol=1e-6)
+    # quantiser outputs must be exactly the oracle's on the kernel's own z
+    _, rh, rsym = O.quantize(z.cpu(), centers, 1.0)
+    assert torch.equal(sym.cpu(), rsym) and torch.equal(qh.cpu(), rh)
+    assert torch.equal(qb.cpu(), (qs + (qh - qs)).cpu())
+
+
+def _pc_setup(cuda, configs, syn_weights, k_cfg='res_shallow'):
+    from imgcomp_cvpr_amd import probclass, config_parser as cp
+    ae_cfg, pc_cfg = configs
+    if k_cfg != 'res_shallow':
+        pc_cfg, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', k_cfg))
+    pc = probclass.get_network_cls(pc_cfg)(pc_cfg, num_centers=ae_cfg.num_centers)
+    return pc, pc_cfg
+
+
+@pytest.mark.parametrize('N,C,h,w', [(1, 32, 8, 8), (2, 5, 7, 11), (1, 1, 1, 1)])
+def test_pc_bitcost_and_logits(cuda, configs, syn_weights, N, C, h, w):
+    from oracle import oracle as O
+    pc, _ = _pc_setup(cuda, configs, syn_weights)
+    pc.load_weights(syn_weights, cuda)
+    centers = syn_weights['autoencoder/encoder/centers']
+    rs = np.random.RandomState(11)
+    sym = rs.randint(0, 6, (N, C, h, w)).astype(np.int64)
+    q = centers[sym]
+    bits, logits = pc.bitcost(dev(q, cuda), dev(sym, cuda, torch.int64), False, pad_value=float(centers[0]),
+                              return_logits=True)
+    torch.cuda.synchronize()
+    rb, rl = O.bitcost(torch.as_tensor(q).double(), torch.as_tensor(sym), syn_weights, float(centers[0]))
+    assert_close(logits, rl, 'pc logits')
+    assert_close(bits, rb, 'pc bits')
+    # logits() on a pre-padded volume gives the same numbers bit-for-bit
+    qp = O.pad_for_probclass3d(torch.as_tensor(q), 9, float(centers[0]))
+    l2 = pc.logits(dev(qp.numpy(), cuda), False)
+    assert torch.equal(l2, logits)
+
+
+def test_pc_k64(cuda, configs):
+    """res_shallow_64 (arch_param__k = 64) goes through the same kernels."""
+    from imgcomp_cvpr_amd import weights as W
+    from oracle import oracle as O
+    ae_cfg, _ = configs
+    pc, pc_cfg = _pc_setup(cuda, configs, None, 'res_shallow_64')
+    wts = W.synthetic_weights(ae_cfg, pc_cfg)
+    pc.load_weights(wts, cuda)
+    centers = wts['autoencoder/encoder/centers']
+    sym = np.random.RandomState(2).randint(0, 6, (1, 6, 5, 9)).astype(np.int64)
+    q = centers[sym]
+    bits = pc.bitcost(dev(q, cuda), dev(sym, cuda, torch.int64), False, pad_value=float(centers[0]))
+    rb, _ = O.bitcost(torch.as_tensor(q).double(), torch.as_tensor(sym), wts, float(centers[0]))
+    assert_close(bits, rb, 'pc bits k=64')
+
+
+def test_pc_causality(cuda, configs, syn_weights):
+    """perturbing symbol i leaves logits at raster indices <= i unchanged (masks, probclass.py:150-176)."""
+    pc, _ = _pc_setup(cuda, configs, syn_weights)
+    pc.load_weights(syn_weights, cuda)
+    centers = syn_weights['autoencoder/encoder/centers']
+    rs = np.random.RandomState(4)
+    C, h, w = 6, 7, 9
+    sym = rs.randint(0, 6, (1, C, h, w))
+    base = pc.logits_unpadded(dev(centers[sym], cuda), float(centers[0])).cpu().reshape(-1, 6)
+    for idx in (0, 17, C * h * w // 2, C * h * w - 2):
+        s2 = sym.copy().reshape(-1)
+        s2[idx] = (s2[idx] + 3) % 6
+        out = pc.logits_unpadded(dev(centers[s2.reshape(1, C, h, w)], cuda), float(centers[0])).cpu().reshape(-1, 6)
+        assert torch.equal(out[:idx + 1], base[:idx + 1]), 'logits before/at the perturbed symbol changed'
+        assert not torch.equal(out[idx + 1:], base[idx + 1:])
+
+
+def test_sum_and_bpp(cuda):
+    from imgcomp_cvpr_amd import bits
+    rs = np.random.RandomState(9)
+    bc = rs.uniform(0, 3, (2, 32, 16, 24)).astype(np.float32)
+    x = torch.zeros((2, 3, 128, 192), device=cuda)
+    bpp = bits.bitcost_to_bpp(dev(bc, cuda), x)
+    ref = bc.astype(np.float64).sum() / (2 * 128 * 192)
+    assert abs(float(bpp) - ref) / ref < 1e-6
+    # deterministic
+    assert float(bits.bitcost_to_bpp(dev(bc, cuda), x)) == float(bpp)
+
+
+def test_error_codes(cuda):
+    """argument errors come back as codes, never as aborts; the Python shim raises."""
+    L = _lib()
+    assert L.lib.ic_conv2d_bn_act_f32(None, None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 1, 0,
+                                      None, None, None) == -1
+    x = torch.zeros(8, device=cuda)
+    assert L.lib.ic_quantize_f32(L.ptr(x), L.ptr(x), 17, 1.0, None, None, None, 8, None) == -2
+    assert L.lib.ic_pc_logits_f32(L.ptr(x), L.ptr_table([x] * 8), 24, 6, 0.0, L.ptr(x), 1, 1, 1, 1,
+                                  L.ptr(x), 4, None) == -3
+    with pytest.raises(L.HipLibraryError):
+        L.check(-2, 'demo')
+    with pytest.raises(L.HipLibraryError):
+        from imgcomp_cvpr_amd import quantizer
+        quantizer.quantize(torch.zeros(1, 1, 2, 2), torch.zeros(6), 1.0)     # CPU tensors: no fallback

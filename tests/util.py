@@ -1,0 +1,25 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+import torch
+
+# Parity bar (BASELINE.json north_star: "within 1e-4 fp32"): the HIP result must agree with the float64
+# evaluation of the oracle to 1e-4 relative to the tensor's scale, max(1, max|ref|).
+RTOL = 1e-4
+
+
+def rel_err(got, ref64):
+    got = got.detach().double().cpu() if torch.is_tensor(got) else torch.as_tensor(got).double()
+    ref64 = ref64.detach().double().cpu() if torch.is_tensor(ref64) else torch.as_tensor(ref64).double()
+    assert got.shape == ref64.shape, (got.shape, ref64.shape)
+    scale = max(1.0, float(ref64.abs().max()))
+    return float((got - ref64).abs().max()) / scale
+
+
+def assert_close(got, ref64, what, rtol=RTOL):
+    e = rel_err(got, ref64)
+    assert e <= rtol, '{}: max error {:.3e} (relative to tensor scale) exceeds {:.1e}'.format(what, e, rtol)
+    return e
+
+
+def dev(a, device, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).to(device)
