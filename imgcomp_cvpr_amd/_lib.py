@@ -28,6 +28,7 @@ PROTOTYPES = {
     'ic_pack_conv3x3_c128_f32': (c_int, [c_void_p, c_void_p, c_void_p]),
     'ic_conv3x3_c128_bn_act_f32': (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_void_p]),
     'ic_conv3x3_c128_set_variant': (c_int, [c_int]),
+    'ic_conv3x3_c128_set_tuning': (c_int, [c_int, c_int]),
     'ic_quantize_f32': (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                 c_longlong, c_void_p]),
     'ic_heatmap_quantize_f32': (c_int, [c_void_p, c_void_p, c_int, c_float] + [c_void_p] * 6 +

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void conv3x3_c128_kernel(const C3Args a) {
     constexpr int CS = (TR + 2) * S;        // LDS channel stride
     constexpr int CHUNK = KC * CS;          // floats per staged chunk
     constexpr int NST = (CHUNK + 255) / 256;
-    __shared__ float lds[2][CHUNK];
+    __shared__ float lds[2][NST * 256];    // padded so that staging writes need no bounds branch
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int b = blockIdx.x;
@@ -102,11 +102,10 @@ __global__ __launch_bounds__(256) void conv3x3_c128_kernel(const C3Args a) {
     {
         float st[NST];
 #pragma unroll
-        for (int i = 0; i < NST; ++i) st[i] = ((inb >> i) & 1) ? xin[goff[i]] : 0.f;
+        for (int i = 0; i < NST; ++i) { const float v = xin[goff[i]]; st[i] = ((inb >> i) & 1) ? v : 0.f; }
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
-            const int e = tid + 256 * i;
-            if (e < CHUNK) lds[0][e] = st[i];
+            lds[0][tid + 256 * i] = st[i];
         }
     }
     __syncthreads();
@@ -122,7 +121,7 @@ __global__ __launch_bounds__(256) void conv3x3_c128_kernel(const C3Args a) {
             for (int t = 0; t < 9; ++t) wnext[t] = wn[t * 256];
             const float* xc = xin + (size_t)(c + 1) * KC * HW;
 #pragma unroll
-            for (int i = 0; i < NST; ++i) st[i] = ((inb >> i) & 1) ? xc[goff[i]] : 0.f;
+            for (int i = 0; i < NST; ++i) { const float v = xc[goff[i]]; st[i] = ((inb >> i) & 1) ? v : 0.f; }
         }
         const float* __restrict__ L = lds[buf];
 #pragma unroll
@@ -141,8 +140,7 @@ __global__ __launch_bounds__(256) void conv3x3_c128_kernel(const C3Args a) {
         if (more) {
 #pragma unroll
             for (int i = 0; i < NST; ++i) {
-                const int e = tid + 256 * i;
-                if (e < CHUNK) lds[buf ^ 1][e] = st[i];
+                lds[buf ^ 1][tid + 256 * i] = st[i];
             }
 #pragma unroll
             for (int t = 0; t < 9; ++t) wcur[t] = wnext[t];
@@ -173,6 +171,166 @@ __global__ __launch_bounds__(256) void conv3x3_c128_kernel(const C3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Software-pipelined variant of the same computation (identical K order -> identical results).
+//  * the B operands of tap t+1 are fetched from LDS while the MFMAs of tap t issue (register double
+//    buffer; one ds_read slotted behind every MFMA by sched_group_barrier) -> every LDS read has 4*PT
+//    MFMA issue slots (>= 256 cycles) to land, so a single wave per SIMD keeps the matrix pipe fed;
+//  * the LDS ring is 3 deep and the hand-over barrier sits in the MIDDLE of a chunk: chunk c+1 is
+//    written (and the barrier passed) by tap 4 of chunk c, so the last tap of chunk c can already
+//    prefetch tap 0 of chunk c+1 and the MFMA stream never drains at a chunk boundary.
+//    (WAR: buffer (c+1)%3 was last read in chunk c-2; every wave has since passed chunk c-1's barrier.)
+template <int PT, int TR, int TC>
+__global__ __launch_bounds__(256) void conv3x3_c128_pipe_kernel(const C3Args a) {
+    static_assert(TR * TC == 32 * PT, "tile must be PT MFMA pixel tiles");
+    constexpr int S = TC + 2;
+    constexpr int CS = (TR + 2) * S;
+    constexpr int CHUNK = KC * CS;
+    constexpr int NST = (CHUNK + 255) / 256;
+    __shared__ float lds[3][NST * 256];    // padded so that staging writes need no bounds branch
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int b = blockIdx.x;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y; const int n = b / a.tiles_y;
+    const int x0 = tx * TC, y0 = ty * TR;
+    const int HW = a.H * a.W;
+    const float* __restrict__ xin = a.x + (size_t)n * C128 * HW;
+
+    int goff[NST];
+    unsigned inb = 0;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int e = tid + 256 * i;
+        const int ci = e / CS, rem = e - ci * CS;
+        const int r = rem / S, c = rem - r * S;
+        const int gy = y0 + r - 1, gx = x0 + c - 1;
+        const bool ok = (e < CHUNK) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        goff[i] = ok ? ci * HW + gy * a.W + gx : 0;
+        inb |= (ok ? 1u : 0u) << i;
+    }
+    const int j = lane & 31, kh = lane >> 5;
+    int boff[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int q = 32 * p + j;
+        boff[p] = kh * CS + (q / TC) * S + (q % TC);
+    }
+    const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + wave * 64 + lane;
+
+    f32x16 acc[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+    f32x4 wcur[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wcur[t] = wp[t * 256];
+    {
+        float st[NST];
+#pragma unroll
+        for (int i = 0; i < NST; ++i) { const float v = xin[goff[i]]; st[i] = ((inb >> i) & 1) ? v : 0.f; }
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            lds[0][tid + 256 * i] = st[i];
+        }
+    }
+    __syncthreads();
+
+    float bq[2][4][PT];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int p = 0; p < PT; ++p) bq[0][ks][p] = lds[0][boff[p] + 2 * ks * CS];
+
+    int ring = 0;                                   // c % 3
+    for (int c2 = 0; c2 < NCHUNK; c2 += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {               // two chunks per trip: register parity stays static
+            const int c = c2 + h;
+            const bool more = c + 1 < NCHUNK;
+            const int ringn = ring == 2 ? 0 : ring + 1;
+            const float* __restrict__ L = lds[ring];
+            float* __restrict__ Ln = lds[ringn];
+            f32x4 wnext[9];
+            float st[NST];
+            if (more) {
+                const f32x4* wn = wp + (size_t)(c + 1) * 9 * 256;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) wnext[t] = wn[t * 256];
+                const float* xc = xin + (size_t)(c + 1) * KC * HW;
+#pragma unroll
+                for (int i = 0; i < NST; ++i) { const float v = xc[goff[i]]; st[i] = ((inb >> i) & 1) ? v : 0.f; }
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int cur = (h * 9 + t) & 1;
+                if (t == 4) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) {
+#pragma unroll
+                        for (int i = 0; i < NST; ++i) {
+                            Ln[tid + 256 * i] = st[i];
+                        }
+                    }
+                    __syncthreads();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (t < 8) {
+                    const int tapoff = ((t + 1) / 3) * S + ((t + 1) % 3);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int p = 0; p < PT; ++p) bq[cur ^ 1][ks][p] = L[boff[p] + 2 * ks * CS + tapoff];
+                } else if (more) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int p = 0; p < PT; ++p) bq[cur ^ 1][ks][p] = Ln[boff[p] + 2 * ks * CS];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const float av = wcur[t][ks];
+#pragma unroll
+                    for (int p = 0; p < PT; ++p)
+                        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[cur][ks][p], acc[p], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4 * PT; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) wcur[t] = wnext[t];
+            }
+            ring = ringn;
+        }
+    }
+
+    const size_t obase = (size_t)n * C128 * HW;
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int q = 32 * p + j;
+        const int oy = y0 + q / TC, ox = x0 + q % TC;
+        if (oy < a.H && ox < a.W) {
+            const size_t pix = obase + (size_t)oy * a.W + ox;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                float v = fmaf(acc[p][r], a.scale[co], a.shift[co]);
+                if (a.relu) v = fmaxf(v, 0.f);
+                const size_t o = pix + (size_t)co * HW;
+                if (a.res1) v += a.res1[o];
+                if (a.res2) v += a.res2[o];
+                a.y[o] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 struct C3Variant { int PT, TR, TC; };
@@ -181,10 +339,23 @@ static const C3Variant kVariants[] = {
 };
 static const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 static int g_variant_override = -1;
+static int g_lds_pad = 0;      // extra dynamic LDS per work-group (tuning: limits work-groups per CU)
+static int g_pipe = 0;         // 0: compiler-scheduled inner loop, 1: explicit register double buffer
 
 extern "C" int ic_conv3x3_c128_set_variant(int v) {
     int prev = g_variant_override;
     g_variant_override = (v >= 0 && v < kNumVariants) ? v : -1;
+    return prev;
+}
+
+extern "C" int ic_conv3x3_c128_set_tuning(int key, int value) {
+    int prev = -1;
+    switch (key) {
+        case 0: return ic_conv3x3_c128_set_variant(value);
+        case 1: prev = g_lds_pad; g_lds_pad = value < 0 ? 0 : value; break;
+        case 2: prev = g_pipe; g_pipe = value ? 1 : 0; break;
+        default: break;
+    }
     return prev;
 }
 
@@ -214,8 +385,12 @@ extern "C" int ic_pack_conv3x3_c128_f32(const float* w_tf, float* w_packed, ic_s
 #define C3_LAUNCH(PT_, TR_, TC_)                                                                        \
     do {                                                                                                \
         a.tiles_x = ic_cdiv(W, TC_); a.tiles_y = ic_cdiv(H, TR_);                                       \
-        hipLaunchKernelGGL((conv3x3_c128_kernel<PT_, TR_, TC_>), dim3(a.tiles_x * a.tiles_y * N),       \
-                           dim3(256), 0, (hipStream_t)stream, a);                                       \
+        if (g_pipe)                                                                                     \
+            hipLaunchKernelGGL((conv3x3_c128_pipe_kernel<PT_, TR_, TC_>), dim3(a.tiles_x * a.tiles_y * N), \
+                               dim3(256), g_lds_pad, (hipStream_t)stream, a);                           \
+        else                                                                                            \
+            hipLaunchKernelGGL((conv3x3_c128_kernel<PT_, TR_, TC_>), dim3(a.tiles_x * a.tiles_y * N), \
+                               dim3(256), g_lds_pad, (hipStream_t)stream, a);                           \
     } while (0)
 
 extern "C" int ic_conv3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale,

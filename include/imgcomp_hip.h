@@ -81,6 +81,9 @@ int ic_conv3x3_c128_bn_act_f32(const float* x, const float* w_packed, const floa
 /* tile variant override for tuning/tests: -1 = automatic (default).  Returns previous value.
  * Process-wide knob read at launch time; not part of the data path contract. */
 int ic_conv3x3_c128_set_variant(int variant);
+/* tuning knobs (not part of the data-path contract): key 0 = tile variant, 1 = extra dynamic LDS bytes
+ * per work-group, 2 = inner-loop schedule (0 compiler, 1 explicit register double buffer). Returns previous. */
+int ic_conv3x3_c128_set_tuning(int key, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * Importance map + quantiser.

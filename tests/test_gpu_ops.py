@@ -185,8 +185,8 @@ def test_heatmap_quantize(cuda):
     torch.cuda.synchronize()
     b64 = torch.as_tensor(bott).double()
     hm64 = O.heatmap3d(b64)
-    assert_close(hm, hm64, 'heatmap', rtol=1e-6)
-    assert_close(z, hm64 * b64[:, 1:], 'z', rtol=1e-6)
+    assert_close(hm, hm64, 'heatmap', rtol=1e-5)
+    assert_close(z, hm64 * b64[:, 1:], 'z', rtol=1e-5)
     # quantiser outputs must be exactly the oracle's on the kernel's own z
     _, rh, rsym = O.quantize(z.cpu(), centers, 1.0)
     assert torch.equal(sym.cpu(), rsym) and torch.equal(qh.cpu(), rh)
