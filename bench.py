@@ -150,7 +150,9 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import oracle as O
-        cores = os.cpu_count() or 1
+        # torch's CPU conv kernels oversubscribe badly beyond a few dozen threads on the 256-core host
+        # (tools/cpu_threads.py: 16 threads is the fastest setting measured on the MI355X box)
+        cores = min(os.cpu_count() or 1, 16)
         torch.set_num_threads(cores)
         sample = x_np[:1]
         t1 = time.perf_counter()

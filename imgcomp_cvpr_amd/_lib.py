@@ -29,6 +29,7 @@ PROTOTYPES = {
     'ic_conv3x3_c128_bn_act_f32': (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_void_p]),
     'ic_conv3x3_c128_set_variant': (c_int, [c_int]),
     'ic_conv3x3_c128_set_tuning': (c_int, [c_int, c_int]),
+    'ic_conv3x3_c128_set_debug_buffer': (None, [c_void_p]),
     'ic_quantize_f32': (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                 c_longlong, c_void_p]),
     'ic_heatmap_quantize_f32': (c_int, [c_void_p, c_void_p, c_int, c_float] + [c_void_p] * 6 +

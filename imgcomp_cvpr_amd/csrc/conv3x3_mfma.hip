@@ -13,12 +13,24 @@
 //      each wave streams only ITS 32 output channels straight from L2 into registers with
 //      global_load_dwordx4 (one load = the A operands of 4 MFMA k-steps); no LDS, no duplication.
 //   B (activations): a (TR+2)x(TC+2) halo tile of 8 input channels at a time is staged through LDS
-//      (double buffered, register-staged so the global loads of chunk c+1 fly under the MFMAs of
-//      chunk c); all 9 taps and all 4 waves re-read it from LDS with conflict-free ds_read_b32.
+//      (register-staged ring); all 9 taps and all 4 waves re-read it from LDS with ds_read_b32.
 // Work-group = 256 threads = 4 waves; wave w owns output channels [32w, 32w+32) for all TRxTC pixels
 // of the tile (PT = TR*TC/32 accumulator tiles of 32x32 = 16*PT accumulator registers).
 // K order per output: chunk (8 ci) -> tap (ky,kx) -> k-step (2 ci) ; fixed, independent of the tile
-// position, so results do not depend on the launch geometry.
+// position and of the tile variant, so results do not depend on the launch geometry.
+//
+// Two schedules of the same arithmetic (bit-identical results):
+//   conv3x3_c128_kernel       simple double-buffered loop, compiler-scheduled (kept as the plain version)
+//   conv3x3_c128_pipe_kernel  the production schedule, built from what the profiles showed:
+//     * B operands of tap t+1 are fetched from LDS while the MFMAs of tap t issue (register double
+//       buffer, one ds_read slotted behind every MFMA) -> one wave per SIMD keeps the matrix pipe fed;
+//     * the filter fragments of chunk c+2 are requested the moment tap t of chunk c has consumed its
+//       registers (two named register sets, two chunks = ~14k clocks of cover): with all 256 CUs
+//       streaming the same 36 KB of filter per chunk in lock-step, an L2 load takes ~5k clocks;
+//     * the LDS ring is 3 deep and its hand-over barrier sits in the MIDDLE of a chunk, so the last tap
+//       of chunk c already prefetches tap 0 of chunk c+1 and the MFMA stream never drains;
+//     * the epilogue first loads ALL its operands (BN scale/shift, residuals) through __restrict__
+//       pointers, then computes and stores (a load->store->load chain costs one L2 round trip each).
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -33,7 +45,17 @@ struct C3Args {
     const float* x; const float* wp; const float* scale; const float* shift;
     const float* res1; const float* res2; float* y;
     int N, H, W, tiles_x, tiles_y, relu;
+    int abl;                   // tuning only: ablation mask (results invalid when != 0)
+    unsigned long long* dbg;   // tuning only: 4 shader-clock stamps per work-group, or null
 };
+
+#define DBG_STAMP()                                                                               \
+    do {                                                                                          \
+        if (a.dbg && threadIdx.x == 0) {                                                          \
+            unsigned long long* d_ = a.dbg + 4 * (size_t)blockIdx.x;                              \
+            d_[0] = t_start; d_[1] = t_pro; d_[2] = t_main; d_[3] = __builtin_readcyclecounter(); \
+        }                                                                                         \
+    } while (0)
 
 // packed[(((c*9 + t)*4 + n)*64 + l)*4 + j] = w_tf[t][ci = 8c + 2j + (l>>5)][co = 32n + (l&31)]
 __global__ void pack_conv3x3_c128_kernel(const float* __restrict__ w, float* __restrict__ out) {
@@ -46,15 +68,93 @@ __global__ void pack_conv3x3_c128_kernel(const float* __restrict__ w, float* __r
     out[idx] = w[(t * C128 + ci) * C128 + co];
 }
 
+// ------------------------------------------------------------------------------------------------
+// shared pieces
+// ------------------------------------------------------------------------------------------------
+template <int TR, int TC>
+struct Geo {
+    static constexpr int S = TC + 2;               // LDS row stride (floats)
+    static constexpr int CS = (TR + 2) * S;        // LDS channel stride
+    static constexpr int CHUNK = KC * CS;          // floats per staged chunk
+    static constexpr int NST = (CHUNK + 255) / 256;
+    static constexpr int LDSF = NST * 256;         // padded: staging writes need no bounds branch
+};
+
+// staging plan: element e = tid + 256 i of the chunk [ci][row][col] -> global offset + in-bounds bit
+template <int TR, int TC>
+__device__ __forceinline__ void staging_plan(int tid, int y0, int x0, int H, int W, int (&goff)[Geo<TR, TC>::NST],
+                                             unsigned& inb) {
+    using G = Geo<TR, TC>;
+    inb = 0;
+#pragma unroll
+    for (int i = 0; i < G::NST; ++i) {
+        const int e = tid + 256 * i;
+        const int ci = e / G::CS, rem = e - ci * G::CS;
+        const int r = rem / G::S, c = rem - r * G::S;
+        const int gy = y0 + r - 1, gx = x0 + c - 1;
+        const bool ok = (e < G::CHUNK) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        goff[i] = ok ? ci * H * W + gy * W + gx : 0;
+        inb |= (ok ? 1u : 0u) << i;
+    }
+}
+
+// D[i][j]: i = (r&3) + 8*(r>>2) + 4*(lane>>5) is the output channel within the wave's 32, j = lane&31 the
+// pixel within accumulator tile p.  All operand loads are issued before the first store.
+template <int PT, int TC>
+__device__ __forceinline__ void epilogue(const f32x16 (&acc)[PT], const C3Args& a, int n, int y0, int x0,
+                                         int wave, int lane) {
+    const float* __restrict__ scale = a.scale;
+    const float* __restrict__ shift = a.shift;
+    const float* __restrict__ res1 = a.res1;
+    const float* __restrict__ res2 = a.res2;
+    float* __restrict__ y = a.y;
+    const int j = lane & 31, kh = lane >> 5;
+    const int HW = a.H * a.W;
+    float sc[16], sh[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        sc[r] = scale[co];
+        sh[r] = shift[co];
+    }
+    const size_t cbase = ((size_t)n * C128 + 32 * wave + 4 * kh) * HW;
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int q = 32 * p + j;
+        const int oy = y0 + q / TC, ox = x0 + q % TC;
+        const bool live = oy < a.H && ox < a.W;
+        const size_t pix = cbase + (size_t)(live ? oy * a.W + ox : 0);
+        float r1[16], r2[16];
+        if (res1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) r1[r] = res1[pix + (size_t)((r & 3) + 8 * (r >> 2)) * HW];
+        }
+        if (res2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) r2[r] = res2[pix + (size_t)((r & 3) + 8 * (r >> 2)) * HW];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = fmaf(acc[p][r], sc[r], sh[r]);
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (res1) v += r1[r];
+            if (res2) v += r2[r];
+            if (live) y[pix + (size_t)((r & 3) + 8 * (r >> 2)) * HW] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// plain schedule
+// ------------------------------------------------------------------------------------------------
 template <int PT, int TR, int TC>
 __global__ __launch_bounds__(256) void conv3x3_c128_kernel(const C3Args a) {
     static_assert(TR * TC == 32 * PT, "tile must be PT MFMA pixel tiles");
-    constexpr int S = TC + 2;               // LDS row stride (floats)
-    constexpr int CS = (TR + 2) * S;        // LDS channel stride
-    constexpr int CHUNK = KC * CS;          // floats per staged chunk
-    constexpr int NST = (CHUNK + 255) / 256;
-    __shared__ float lds[2][NST * 256];    // padded so that staging writes need no bounds branch
+    using G = Geo<TR, TC>;
+    constexpr int S = G::S, CS = G::CS, NST = G::NST;
+    __shared__ float lds[2][G::LDSF];
 
+    const unsigned long long t_start = a.dbg ? __builtin_readcyclecounter() : 0ull;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int b = blockIdx.x;
     const int tx = b % a.tiles_x; b /= a.tiles_x;
@@ -63,21 +163,10 @@ __global__ __launch_bounds__(256) void conv3x3_c128_kernel(const C3Args a) {
     const int HW = a.H * a.W;
     const float* __restrict__ xin = a.x + (size_t)n * C128 * HW;
 
-    // ---- staging plan: element e = tid + 256 i of the chunk [ci][row][col] ----
     int goff[NST];
-    unsigned inb = 0;
-#pragma unroll
-    for (int i = 0; i < NST; ++i) {
-        const int e = tid + 256 * i;
-        const int ci = e / CS, rem = e - ci * CS;
-        const int r = rem / S, c = rem - r * S;
-        const int gy = y0 + r - 1, gx = x0 + c - 1;
-        const bool ok = (e < CHUNK) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        goff[i] = ok ? ci * HW + gy * a.W + gx : 0;
-        inb |= (ok ? 1u : 0u) << i;
-    }
+    unsigned inb;
+    staging_plan<TR, TC>(tid, y0, x0, a.H, a.W, goff, inb);
 
-    // ---- B-operand (pixel) read offsets per accumulator tile ----
     const int j = lane & 31, kh = lane >> 5;
     int boff[PT];
 #pragma unroll
@@ -85,7 +174,6 @@ __global__ __launch_bounds__(256) void conv3x3_c128_kernel(const C3Args a) {
         const int q = 32 * p + j;
         boff[p] = kh * CS + (q / TC) * S + (q % TC);
     }
-
     const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + wave * 64 + lane;
     // wp[(c*9 + t)*256] = A fragments of chunk c, tap t for this wave's 32 output channels
 
@@ -95,20 +183,16 @@ __global__ __launch_bounds__(256) void conv3x3_c128_kernel(const C3Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
-    // ---- prologue: chunk 0 ----
     f32x4 wcur[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) wcur[t] = wp[t * 256];
-    {
-        float st[NST];
 #pragma unroll
-        for (int i = 0; i < NST; ++i) { const float v = xin[goff[i]]; st[i] = ((inb >> i) & 1) ? v : 0.f; }
-#pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            lds[0][tid + 256 * i] = st[i];
-        }
+    for (int i = 0; i < NST; ++i) {
+        const float v = xin[goff[i]];
+        lds[0][tid + 256 * i] = ((inb >> i) & 1) ? v : 0.f;
     }
     __syncthreads();
+    const unsigned long long t_pro = a.dbg ? __builtin_readcyclecounter() : 0ull;
 
     for (int c = 0; c < NCHUNK; ++c) {
         const int buf = c & 1;
@@ -139,55 +223,30 @@ __global__ __launch_bounds__(256) void conv3x3_c128_kernel(const C3Args a) {
         }
         if (more) {
 #pragma unroll
-            for (int i = 0; i < NST; ++i) {
-                lds[buf ^ 1][tid + 256 * i] = st[i];
-            }
+            for (int i = 0; i < NST; ++i) lds[buf ^ 1][tid + 256 * i] = st[i];
 #pragma unroll
             for (int t = 0; t < 9; ++t) wcur[t] = wnext[t];
         }
         __syncthreads();
     }
-
-    // ---- epilogue: D[i][j], i = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel), j = lane&31 (pixel) ----
-    const size_t obase = (size_t)n * C128 * HW;
-#pragma unroll
-    for (int p = 0; p < PT; ++p) {
-        const int q = 32 * p + j;
-        const int oy = y0 + q / TC, ox = x0 + q % TC;
-        if (oy < a.H && ox < a.W) {
-            const size_t pix = obase + (size_t)oy * a.W + ox;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                float v = fmaf(acc[p][r], a.scale[co], a.shift[co]);
-                if (a.relu) v = fmaxf(v, 0.f);
-                const size_t o = pix + (size_t)co * HW;
-                if (a.res1) v += a.res1[o];
-                if (a.res2) v += a.res2[o];
-                a.y[o] = v;
-            }
-        }
-    }
+    const unsigned long long t_main = a.dbg ? __builtin_readcyclecounter() : 0ull;
+    epilogue<PT, TC>(acc, a, n, y0, x0, wave, lane);
+    DBG_STAMP();
 }
 
 // ------------------------------------------------------------------------------------------------
-// Software-pipelined variant of the same computation (identical K order -> identical results).
-//  * the B operands of tap t+1 are fetched from LDS while the MFMAs of tap t issue (register double
-//    buffer; one ds_read slotted behind every MFMA by sched_group_barrier) -> every LDS read has 4*PT
-//    MFMA issue slots (>= 256 cycles) to land, so a single wave per SIMD keeps the matrix pipe fed;
-//  * the LDS ring is 3 deep and the hand-over barrier sits in the MIDDLE of a chunk: chunk c+1 is
-//    written (and the barrier passed) by tap 4 of chunk c, so the last tap of chunk c can already
-//    prefetch tap 0 of chunk c+1 and the MFMA stream never drains at a chunk boundary.
-//    (WAR: buffer (c+1)%3 was last read in chunk c-2; every wave has since passed chunk c-1's barrier.)
+// production schedule (see the header comment)
+//   LDS ring WAR: buffer (c+1)%3 is written at the middle of chunk c; it was last read in chunk c-2 (and by
+//   the tap-0 prefetch at the end of chunk c-3); every wave has since passed chunk c-1's barrier.
+// ------------------------------------------------------------------------------------------------
 template <int PT, int TR, int TC>
 __global__ __launch_bounds__(256) void conv3x3_c128_pipe_kernel(const C3Args a) {
     static_assert(TR * TC == 32 * PT, "tile must be PT MFMA pixel tiles");
-    constexpr int S = TC + 2;
-    constexpr int CS = (TR + 2) * S;
-    constexpr int CHUNK = KC * CS;
-    constexpr int NST = (CHUNK + 255) / 256;
-    __shared__ float lds[3][NST * 256];    // padded so that staging writes need no bounds branch
+    using G = Geo<TR, TC>;
+    constexpr int S = G::S, CS = G::CS, NST = G::NST;
+    __shared__ float lds[3][G::LDSF];
 
+    const unsigned long long t_start = a.dbg ? __builtin_readcyclecounter() : 0ull;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int b = blockIdx.x;
     const int tx = b % a.tiles_x; b /= a.tiles_x;
@@ -197,17 +256,9 @@ __global__ __launch_bounds__(256) void conv3x3_c128_pipe_kernel(const C3Args a) 
     const float* __restrict__ xin = a.x + (size_t)n * C128 * HW;
 
     int goff[NST];
-    unsigned inb = 0;
-#pragma unroll
-    for (int i = 0; i < NST; ++i) {
-        const int e = tid + 256 * i;
-        const int ci = e / CS, rem = e - ci * CS;
-        const int r = rem / S, c = rem - r * S;
-        const int gy = y0 + r - 1, gx = x0 + c - 1;
-        const bool ok = (e < CHUNK) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        goff[i] = ok ? ci * HW + gy * a.W + gx : 0;
-        inb |= (ok ? 1u : 0u) << i;
-    }
+    unsigned inb;
+    staging_plan<TR, TC>(tid, y0, x0, a.H, a.W, goff, inb);
+
     const int j = lane & 31, kh = lane >> 5;
     int boff[PT];
 #pragma unroll
@@ -223,19 +274,25 @@ __global__ __launch_bounds__(256) void conv3x3_c128_pipe_kernel(const C3Args a) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
-    f32x4 wcur[9];
+    // filter fragments: set 0 holds even chunks, set 1 odd chunks
+    f32x4 wq[2][9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wcur[t] = wp[t * 256];
-    {
-        float st[NST];
+    for (int t = 0; t < 9; ++t) wq[0][t] = wp[t * 256];
 #pragma unroll
-        for (int i = 0; i < NST; ++i) { const float v = xin[goff[i]]; st[i] = ((inb >> i) & 1) ? v : 0.f; }
+    for (int t = 0; t < 9; ++t) wq[1][t] = wp[(9 + t) * 256];
+    float st[NST];
 #pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            lds[0][tid + 256 * i] = st[i];
-        }
+    for (int i = 0; i < NST; ++i) {
+        const float v = xin[goff[i]];
+        lds[0][tid + 256 * i] = ((inb >> i) & 1) ? v : 0.f;
+    }
+    {   // staging registers now carry chunk 1
+        const float* xc = xin + (size_t)KC * HW;
+#pragma unroll
+        for (int i = 0; i < NST; ++i) { const float v = xc[goff[i]]; st[i] = ((inb >> i) & 1) ? v : 0.f; }
     }
     __syncthreads();
+    const unsigned long long t_pro = a.dbg ? __builtin_readcyclecounter() : 0ull;
 
     float bq[2][4][PT];
 #pragma unroll
@@ -246,34 +303,33 @@ __global__ __launch_bounds__(256) void conv3x3_c128_pipe_kernel(const C3Args a) 
     int ring = 0;                                   // c % 3
     for (int c2 = 0; c2 < NCHUNK; c2 += 2) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {               // two chunks per trip: register parity stays static
+        for (int h = 0; h < 2; ++h) {               // two chunks per trip: register sets stay statically named
             const int c = c2 + h;
             const bool more = c + 1 < NCHUNK;
+            const bool more2 = c + 2 < NCHUNK && !(a.abl & 1);
             const int ringn = ring == 2 ? 0 : ring + 1;
             const float* __restrict__ L = lds[ring];
             float* __restrict__ Ln = lds[ringn];
-            f32x4 wnext[9];
-            float st[NST];
-            if (more) {
-                const f32x4* wn = wp + (size_t)(c + 1) * 9 * 256;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) wnext[t] = wn[t * 256];
-                const float* xc = xin + (size_t)(c + 1) * KC * HW;
-#pragma unroll
-                for (int i = 0; i < NST; ++i) { const float v = xc[goff[i]]; st[i] = ((inb >> i) & 1) ? v : 0.f; }
-            }
+            const f32x4* wn2 = wp + (size_t)(c + 2) * 9 * 256;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int cur = (h * 9 + t) & 1;
                 if (t == 4) {
+                    // hand chunk c+1 over through LDS, then start fetching chunk c+2's halo tile
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) {
 #pragma unroll
-                        for (int i = 0; i < NST; ++i) {
-                            Ln[tid + 256 * i] = st[i];
-                        }
+                        for (int i = 0; i < NST; ++i) Ln[tid + 256 * i] = st[i];
                     }
                     __syncthreads();
+                    if (more2) {
+                        const float* xc = xin + (size_t)(c + 2) * KC * HW;
+#pragma unroll
+                        for (int i = 0; i < NST; ++i) {
+                            const float v = xc[goff[i]];
+                            st[i] = ((inb >> i) & 1) ? v : 0.f;
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (t < 8) {
@@ -290,7 +346,7 @@ __global__ __launch_bounds__(256) void conv3x3_c128_pipe_kernel(const C3Args a) 
                 }
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const float av = wcur[t][ks];
+                    const float av = wq[h][t][ks];
 #pragma unroll
                     for (int p = 0; p < PT; ++p)
                         acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[cur][ks][p], acc[p], 0, 0, 0);
@@ -300,34 +356,15 @@ __global__ __launch_bounds__(256) void conv3x3_c128_pipe_kernel(const C3Args a) 
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
                 }
-            }
-            if (more) {
-#pragma unroll
-                for (int t = 0; t < 9; ++t) wcur[t] = wnext[t];
+                // this tap's fragment registers are free: request the same tap of chunk c+2
+                if (more2) wq[h][t] = wn2[t * 256];
             }
             ring = ringn;
         }
     }
-
-    const size_t obase = (size_t)n * C128 * HW;
-#pragma unroll
-    for (int p = 0; p < PT; ++p) {
-        const int q = 32 * p + j;
-        const int oy = y0 + q / TC, ox = x0 + q % TC;
-        if (oy < a.H && ox < a.W) {
-            const size_t pix = obase + (size_t)oy * a.W + ox;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                float v = fmaf(acc[p][r], a.scale[co], a.shift[co]);
-                if (a.relu) v = fmaxf(v, 0.f);
-                const size_t o = pix + (size_t)co * HW;
-                if (a.res1) v += a.res1[o];
-                if (a.res2) v += a.res2[o];
-                a.y[o] = v;
-            }
-        }
-    }
+    const unsigned long long t_main = a.dbg ? __builtin_readcyclecounter() : 0ull;
+    epilogue<PT, TC>(acc, a, n, y0, x0, wave, lane);
+    DBG_STAMP();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -340,7 +377,9 @@ static const C3Variant kVariants[] = {
 static const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 static int g_variant_override = -1;
 static int g_lds_pad = 0;      // extra dynamic LDS per work-group (tuning: limits work-groups per CU)
-static int g_pipe = 0;         // 0: compiler-scheduled inner loop, 1: explicit register double buffer
+static unsigned long long* g_dbg = nullptr;
+static int g_pipe = 1;         // 1: production schedule, 0: plain schedule
+static int g_abl = 0;
 
 extern "C" int ic_conv3x3_c128_set_variant(int v) {
     int prev = g_variant_override;
@@ -348,12 +387,15 @@ extern "C" int ic_conv3x3_c128_set_variant(int v) {
     return prev;
 }
 
+extern "C" void ic_conv3x3_c128_set_debug_buffer(void* p) { g_dbg = (unsigned long long*)p; }
+
 extern "C" int ic_conv3x3_c128_set_tuning(int key, int value) {
     int prev = -1;
     switch (key) {
         case 0: return ic_conv3x3_c128_set_variant(value);
         case 1: prev = g_lds_pad; g_lds_pad = value < 0 ? 0 : value; break;
         case 2: prev = g_pipe; g_pipe = value ? 1 : 0; break;
+        case 3: prev = g_abl; g_abl = value; break;
         default: break;
     }
     return prev;
@@ -389,7 +431,7 @@ extern "C" int ic_pack_conv3x3_c128_f32(const float* w_tf, float* w_packed, ic_s
             hipLaunchKernelGGL((conv3x3_c128_pipe_kernel<PT_, TR_, TC_>), dim3(a.tiles_x * a.tiles_y * N), \
                                dim3(256), g_lds_pad, (hipStream_t)stream, a);                           \
         else                                                                                            \
-            hipLaunchKernelGGL((conv3x3_c128_kernel<PT_, TR_, TC_>), dim3(a.tiles_x * a.tiles_y * N), \
+            hipLaunchKernelGGL((conv3x3_c128_kernel<PT_, TR_, TC_>), dim3(a.tiles_x * a.tiles_y * N),   \
                                dim3(256), g_lds_pad, (hipStream_t)stream, a);                           \
     } while (0)
 
@@ -401,7 +443,7 @@ extern "C" int ic_conv3x3_c128_bn_act_f32(const float* x, const float* w_packed,
     if ((long long)C128 * H * W >= (1ll << 31)) return IC_ERR_UNSUPPORTED;
     C3Args a{};
     a.x = x; a.wp = w_packed; a.scale = scale; a.shift = shift; a.res1 = res1; a.res2 = res2; a.y = y;
-    a.N = N; a.H = H; a.W = W; a.relu = relu;
+    a.N = N; a.H = H; a.W = W; a.relu = relu; a.dbg = g_dbg; a.abl = g_abl;
     switch (pick_variant(N, H, W)) {
         case 0: C3_LAUNCH(4, 8, 16); break;
         case 1: C3_LAUNCH(4, 4, 32); break;

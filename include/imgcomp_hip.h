@@ -84,6 +84,9 @@ int ic_conv3x3_c128_set_variant(int variant);
 /* tuning knobs (not part of the data-path contract): key 0 = tile variant, 1 = extra dynamic LDS bytes
  * per work-group, 2 = inner-loop schedule (0 compiler, 1 explicit register double buffer). Returns previous. */
 int ic_conv3x3_c128_set_tuning(int key, int value);
+/* tuning only: device buffer of 4 x u64 per work-group receiving shader-clock stamps
+ * {start, prologue done, main loop done, end}; NULL disables (default). */
+void ic_conv3x3_c128_set_debug_buffer(void* dev_u64);
 
 /* ---------------------------------------------------------------------------------------------
  * Importance map + quantiser.

@@ -22,6 +22,8 @@ def main():
     p.add_argument('--reps', type=int, default=30)
     p.add_argument('--variants', default='all')
     p.add_argument('--pads', default='0,86016')
+    p.add_argument('--abl', default='0', help='ablation masks for the pipelined kernel (tuning)')
+    p.add_argument('--phases', action='store_true', help='print in-kernel phase timing (shader clocks)')
     a = p.parse_args()
     lib = _lib.lib
     dev = torch.device('cuda:0')
@@ -48,7 +50,8 @@ def main():
     for v in vs:
         pt, tr, tc = VARIANTS[v]
         nwg = a.n * -(-a.h // tr) * -(-a.w // tc)
-        for pipe in (0, 1):
+        for pipe, abl in [(0, 0)] + [(1, int(m)) for m in a.abl.split(',')]:
+            lib.ic_conv3x3_c128_set_tuning(3, abl)
             for pad in [int(s) for s in a.pads.split(',')]:
                 lib.ic_conv3x3_c128_set_tuning(0, v)
                 lib.ic_conv3x3_c128_set_tuning(1, pad)
@@ -63,11 +66,24 @@ def main():
                 ms = ctypes.c_float()
                 _lib.check(lib.ic_event_elapsed_ms(ev[0], ev[1], ctypes.byref(ms)))
                 us = ms.value / a.reps * 1e3
-                print('variant {:2d} PT={} {}x{:<2d} nwg={:5d} pipe={} ldspad={:6d}: {:8.2f} us  {:6.1f} TFLOP/s'.format(
-                    v, pt, tr, tc, nwg, pipe, pad, us, flop / us / 1e6))
+                print('variant {:2d} PT={} {}x{:<2d} nwg={:5d} pipe={} abl={} ldspad={:6d}: {:8.2f} us  {:6.1f} TFLOP/s'.format(
+                    v, pt, tr, tc, nwg, pipe, abl, pad, us, flop / us / 1e6))
+                if a.phases:
+                    dbg = torch.zeros(4 * nwg, dtype=torch.int64, device=dev)
+                    lib.ic_conv3x3_c128_set_debug_buffer(_lib.ptr(dbg))
+                    run()
+                    torch.cuda.synchronize()
+                    lib.ic_conv3x3_c128_set_debug_buffer(None)
+                    d = dbg.cpu().view(nwg, 4).double()
+                    pro, main, epi = d[:, 1] - d[:, 0], d[:, 2] - d[:, 1], d[:, 3] - d[:, 2]
+                    print('    phases [shader clocks] prologue mean {:.0f} max {:.0f} | main mean {:.0f} max {:.0f} | '
+                          'epilogue mean {:.0f} max {:.0f} | start spread {:.0f} | span {:.0f}'.format(
+                              pro.mean(), pro.max(), main.mean(), main.max(), epi.mean(), epi.max(),
+                              d[:, 0].max() - d[:, 0].min(), d[:, 3].max() - d[:, 0].min()))
     lib.ic_conv3x3_c128_set_tuning(0, -1)
     lib.ic_conv3x3_c128_set_tuning(1, 0)
     lib.ic_conv3x3_c128_set_tuning(2, 0)
+    lib.ic_conv3x3_c128_set_tuning(3, 0)
 
 
 if __name__ == '__main__':
