@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256) void conv3x3_c128_pipe_kernel(const C3Args a) 
     static_assert(TR * TC == 32 * PT, "tile must be PT MFMA pixel tiles");
     using G = Geo<TR, TC>;
     constexpr int S = G::S, CS = G::CS, NST = G::NST;
+    static_assert(NST <= 8, "halo-tile loads are spread over taps 5..8, two per tap");
     __shared__ float lds[3][G::LDSF];
 
     const unsigned long long t_start = a.dbg ? __builtin_readcyclecounter() : 0ull;
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void conv3x3_c128_pipe_kernel(const C3Args a) 
         const int q = 32 * p + j;
         boff[p] = kh * CS + (q / TC) * S + (q % TC);
     }
-    const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + wave * 64 + lane;
+    const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + ((a.abl & 4) ? 0 : wave * 64) + lane;
 
     f32x16 acc[PT];
 #pragma unroll
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(256) void conv3x3_c128_pipe_kernel(const C3Args a) 
     {   // staging registers now carry chunk 1
         const float* xc = xin + (size_t)KC * HW;
 #pragma unroll
-        for (int i = 0; i < NST; ++i) { const float v = xc[goff[i]]; st[i] = ((inb >> i) & 1) ? v : 0.f; }
+        for (int i = 0; i < NST; ++i) st[i] = xc[goff[i]];
     }
     __syncthreads();
     const unsigned long long t_pro = a.dbg ? __builtin_readcyclecounter() : 0ull;
@@ -306,7 +307,8 @@ __global__ __launch_bounds__(256) void conv3x3_c128_pipe_kernel(const C3Args a) 
         for (int h = 0; h < 2; ++h) {               // two chunks per trip: register sets stay statically named
             const int c = c2 + h;
             const bool more = c + 1 < NCHUNK;
-            const bool more2 = c + 2 < NCHUNK && !(a.abl & 1);
+            const bool more2 = c + 2 < NCHUNK && !(a.abl & 1);     // filter prefetch
+            const bool more2s = c + 2 < NCHUNK && !(a.abl & 2);    // halo-tile prefetch
             const int ringn = ring == 2 ? 0 : ring + 1;
             const float* __restrict__ L = lds[ring];
             float* __restrict__ Ln = lds[ringn];
@@ -319,18 +321,28 @@ __global__ __launch_bounds__(256) void conv3x3_c128_pipe_kernel(const C3Args a) 
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) {
 #pragma unroll
-                        for (int i = 0; i < NST; ++i) Ln[tid + 256 * i] = st[i];
+                        for (int i = 0; i < NST; ++i) Ln[tid + 256 * i] = ((inb >> i) & 1) ? st[i] : 0.f;
                     }
-                    __syncthreads();
-                    if (more2) {
-                        const float* xc = xin + (size_t)(c + 2) * KC * HW;
-#pragma unroll
-                        for (int i = 0; i < NST; ++i) {
-                            const float v = xc[goff[i]];
-                            st[i] = ((inb >> i) & 1) ? v : 0.f;
-                        }
-                    }
+                    // raw barrier: __syncthreads() would also wait vmcnt(0) and drain the filter prefetch
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
+                }
+                // Global loads are slotted one or two per tap into the MFMA stream (a VMEM issue that does not
+                // fit into one MFMA's 64-clock shadow idles the matrix pipe of a one-wave-per-SIMD kernel):
+                //  - halo tile of chunk c+2 into the staging registers freed by the hand-over above;
+                //  - filter fragments of chunk c+2 into the registers of the tap TWO back (a load into registers
+                //    that an MFMA issued < 64 clocks ago reads has to wait for that MFMA).
+                if (t >= 5 && more2s) {
+                    const float* xc = xin + (size_t)(c + 2) * KC * HW;
+#pragma unroll
+                    for (int i = 2 * (t - 5); i < 2 * (t - 5) + 2; ++i)
+                        if (i < NST) st[i] = xc[goff[i]];        // raw; the zero-padding select is applied at the LDS write
+                }
+                if (t >= 2) {
+                    if (more2) wq[h][t - 2] = wn2[(t - 2) * 256];
+                } else if (c >= 1 && more && !(a.abl & 1)) {
+                    wq[h ^ 1][7 + t] = wp[((size_t)(c + 1) * 9 + 7 + t) * 256];   // taps 7, 8 of chunk c-1 -> chunk c+1
                 }
                 if (t < 8) {
                     const int tapoff = ((t + 1) / 3) * S + ((t + 1) % 3);
@@ -355,9 +367,9 @@ __global__ __launch_bounds__(256) void conv3x3_c128_pipe_kernel(const C3Args a) 
                 for (int i = 0; i < 4 * PT; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                    if (i == PT || i == 2 * PT || i == 3 * PT)
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
                 }
-                // this tap's fragment registers are free: request the same tap of chunk c+2
-                if (more2) wq[h][t] = wn2[t * 256];
             }
             ring = ringn;
         }
@@ -372,13 +384,13 @@ __global__ __launch_bounds__(256) void conv3x3_c128_pipe_kernel(const C3Args a) 
 // ------------------------------------------------------------------------------------------------
 struct C3Variant { int PT, TR, TC; };
 static const C3Variant kVariants[] = {
-    {4, 8, 16}, {4, 4, 32}, {3, 8, 12}, {3, 6, 16}, {3, 3, 32}, {2, 4, 16}, {2, 2, 32}, {2, 8, 8}, {1, 4, 8}, {1, 2, 16},
+    {4, 8, 16}, {4, 4, 32}, {3, 8, 12}, {3, 6, 16}, {3, 3, 32}, {2, 4, 16}, {2, 2, 32}, {2, 8, 8}, {1, 2, 16}, {1, 4, 8},
 };
 static const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 static int g_variant_override = -1;
 static int g_lds_pad = 0;      // extra dynamic LDS per work-group (tuning: limits work-groups per CU)
 static unsigned long long* g_dbg = nullptr;
-static int g_pipe = 1;         // 1: production schedule, 0: plain schedule
+static int g_pipe = -1;        // -1: automatic (pipelined schedule for PT >= 2, plain for PT == 1), 0: plain, 1: pipelined
 static int g_abl = 0;
 
 extern "C" int ic_conv3x3_c128_set_variant(int v) {
@@ -394,21 +406,29 @@ extern "C" int ic_conv3x3_c128_set_tuning(int key, int value) {
     switch (key) {
         case 0: return ic_conv3x3_c128_set_variant(value);
         case 1: prev = g_lds_pad; g_lds_pad = value < 0 ? 0 : value; break;
-        case 2: prev = g_pipe; g_pipe = value ? 1 : 0; break;
+        case 2: prev = g_pipe; g_pipe = value < 0 ? -1 : (value ? 1 : 0); break;
         case 3: prev = g_abl; g_abl = value; break;
         default: break;
     }
     return prev;
 }
 
+// Variant choice from a small cost model calibrated on MI355X (tools/bench_conv3x3.py, profiles/):
+// every CU gets W = ceil(nwg / 256) work-groups; up to `occ` of them are resident together, and the
+// matrix-pipe efficiency of a CU grows with the number of resident waves per SIMD (1: 0.70 with the
+// pipelined schedule, 2: 0.85, >= 3: 0.95 -- prologue/epilogue of one group hide under the others).
+static int variant_occupancy(int PT) { return PT == 1 ? 3 : (PT <= 3 ? 2 : 1); }
+
 static int pick_variant(int N, int H, int W) {
     if (g_variant_override >= 0) return g_variant_override;
+    static const double eff[4] = {0.0, 0.70, 0.85, 0.95};
     int best = 0; double bestc = 1e30;
     for (int v = 0; v < kNumVariants; ++v) {
         const C3Variant& k = kVariants[v];
         const long nwg = (long)N * ic_cdiv(H, k.TR) * ic_cdiv(W, k.TC);
-        // one work-group per CU per round; fixed per-group cost (prologue, epilogue) ~ 0.3 tile units
-        const double cost = (double)((nwg + 255) / 256) * (k.PT + 0.3);
+        const long per_cu = (nwg + 255) / 256;
+        const int conc = (int)(per_cu < variant_occupancy(k.PT) ? per_cu : variant_occupancy(k.PT));
+        const double cost = (double)per_cu * (k.PT + 0.3) / eff[conc];
         if (cost < bestc - 1e-9) { bestc = cost; best = v; }
     }
     return best;
@@ -427,7 +447,7 @@ extern "C" int ic_pack_conv3x3_c128_f32(const float* w_tf, float* w_packed, ic_s
 #define C3_LAUNCH(PT_, TR_, TC_)                                                                        \
     do {                                                                                                \
         a.tiles_x = ic_cdiv(W, TC_); a.tiles_y = ic_cdiv(H, TR_);                                       \
-        if (g_pipe)                                                                                     \
+        if (g_pipe < 0 ? (PT_ >= 2) : g_pipe)                                                           \
             hipLaunchKernelGGL((conv3x3_c128_pipe_kernel<PT_, TR_, TC_>), dim3(a.tiles_x * a.tiles_y * N), \
                                dim3(256), g_lds_pad, (hipStream_t)stream, a);                           \
         else                                                                                            \
@@ -453,8 +473,8 @@ extern "C" int ic_conv3x3_c128_bn_act_f32(const float* x, const float* w_packed,
         case 5: C3_LAUNCH(2, 4, 16); break;
         case 6: C3_LAUNCH(2, 2, 32); break;
         case 7: C3_LAUNCH(2, 8, 8); break;
-        case 8: C3_LAUNCH(1, 4, 8); break;
-        default: C3_LAUNCH(1, 2, 16); break;
+        case 8: C3_LAUNCH(1, 2, 16); break;
+        default: C3_LAUNCH(1, 4, 8); break;
     }
     IC_LAUNCH_CHECK();
     return IC_OK;
