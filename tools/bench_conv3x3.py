@@ -11,7 +11,7 @@ import torch
 from imgcomp_cvpr_amd import _lib
 
 VARIANTS = [(4, 8, 16), (4, 4, 32), (3, 8, 12), (3, 6, 16), (3, 3, 32), (2, 4, 16), (2, 2, 32), (2, 8, 8),
-            (1, 4, 8), (1, 2, 16)]
+            (1, 2, 16), (1, 4, 8)]
 
 
 def main():
@@ -82,7 +82,7 @@ def main():
                               d[:, 0].max() - d[:, 0].min(), d[:, 3].max() - d[:, 0].min()))
     lib.ic_conv3x3_c128_set_tuning(0, -1)
     lib.ic_conv3x3_c128_set_tuning(1, 0)
-    lib.ic_conv3x3_c128_set_tuning(2, 0)
+    lib.ic_conv3x3_c128_set_tuning(2, -1)
     lib.ic_conv3x3_c128_set_tuning(3, 0)
 
 
