@@ -170,9 +170,19 @@ class _CVPR(_Network):
                                              ('gamma', 'beta', 'moving_mean', 'moving_variance')))
             scale_d = torch.from_numpy(scale).to(dev)
             shift_d = torch.from_numpy(shift).to(dev)
+            kh, kw, a_, b_ = shape
+            cin, cout = (a_, b_) if kind == 'conv' else (b_, a_)
+            stride = 1 if (kh, kw) == (3, 3) and kind == 'conv' else 2
+            n_mfma = lib.ic_conv2d_mfma_packed_floats(kh, kw, cin, cout, stride, int(kind == 'deconv'))
             if kind == 'conv' and tuple(shape) == (3, 3, arch_param_n, arch_param_n):
                 wp = torch.empty(packed_n, dtype=torch.float32, device=dev)
                 check(lib.ic_pack_conv3x3_c128_f32(ptr(w), ptr(wp), st), 'ic_pack_conv3x3_c128_f32')
+                w_use = wp
+            elif n_mfma and not scope.endswith('/h1'):
+                # h2, to_bn, h12: matrix-core path, filter in MFMA fragment order
+                wp = torch.empty(n_mfma, dtype=torch.float32, device=dev)
+                check(lib.ic_pack_conv2d_mfma_f32(ptr(w), ptr(wp), kh, kw, cin, cout, stride, int(kind == 'deconv'), st),
+                      'ic_pack_conv2d_mfma_f32')
                 w_use = wp
             else:
                 w_use = w

@@ -81,20 +81,16 @@ extern "C" int ic_ae_encode_f32(const float* x, const void* const* tab, int B, i
     a.N = N; a.Cin = 3; a.H = H; a.W = W; a.Cout = 64; a.KH = 5; a.KW = 5; a.stride = 2; a.relu = 1;
     a.builtin_norm = normalize_on ? 1 : 0;
     if ((rc = icx_conv2d(a, false, st))) return rc;
-    // h2: 64 -> 128, 5x5 / 2, BN, ReLU
-    a = ConvArgs{};
-    a.x = half; a.w = t[3]; a.scale = t[4]; a.shift = t[5]; a.y = bufs[0];
-    a.N = N; a.Cin = 64; a.H = H / 2; a.W = W / 2; a.Cout = 128; a.KH = 5; a.KW = 5; a.stride = 2; a.relu = 1;
-    if ((rc = icx_conv2d(a, false, st))) return rc;
+    // h2: 64 -> 128, 5x5 / 2, BN, ReLU (matrix cores, packed filter)
+    if ((rc = ic_conv2d_mfma_bn_act_f32(half, t[3], t[4], t[5], bufs[0], N, 64, H / 2, W / 2, 128, 5, 5, 2, 0, 1, st)))
+        return rc;
     int o;
     if ((rc = res_stack(tab + 6, B, bufs, N, H / 4, W / 4, st, &o))) return rc;
     // to_bn: 128 -> C(+1), 5x5 / 2, BN, linear
     const float* const* tb = t + 6 + 3 * nconv;
     const int Cb = C + (heatmap_on ? 1 : 0);
-    a = ConvArgs{};
-    a.x = bufs[o]; a.w = tb[0]; a.scale = tb[1]; a.shift = tb[2]; a.y = bott;
-    a.N = N; a.Cin = 128; a.H = H / 4; a.W = W / 4; a.Cout = Cb; a.KH = 5; a.KW = 5; a.stride = 2; a.relu = 0;
-    if ((rc = icx_conv2d(a, false, st))) return rc;
+    if ((rc = ic_conv2d_mfma_bn_act_f32(bufs[o], tb[0], tb[1], tb[2], bott, N, 128, H / 4, W / 4, Cb, 5, 5, 2, 0, 0, st)))
+        return rc;
     const float* centers = tb[3];
     if (heatmap_on)
         return ic_heatmap_quantize_f32(bott, centers, L, 1.0f, heatmap, z, qsoft, qhard, qbar, symbols,
@@ -131,10 +127,8 @@ extern "C" int ic_ae_decode_f32(const float* q, const void* const* tab, int B, i
     if ((rc = res_stack(tab + 3, B, bufs, N, H / 4, W / 4, st, &o))) return rc;
     const float* const* th = t + 3 + 3 * nconv;
     // h12: 128 -> 64, 5x5 transposed / 2, BN, ReLU
-    a = ConvArgs{};
-    a.x = bufs[o]; a.w = th[0]; a.scale = th[1]; a.shift = th[2]; a.y = half;
-    a.N = N; a.Cin = 128; a.H = H / 4; a.W = W / 4; a.Cout = 64; a.KH = 5; a.KW = 5; a.relu = 1;
-    if ((rc = icx_conv2d(a, true, st))) return rc;
+    if ((rc = ic_conv2d_mfma_bn_act_f32(bufs[o], th[0], th[1], th[2], half, N, 128, H / 4, W / 4, 64, 5, 5, 2, 1, 1, st)))
+        return rc;
     // h13: 64 -> 3, 5x5 transposed / 2, BN, linear, de-normalise, clip to [0, 255]
     a = ConvArgs{};
     a.x = half; a.w = th[3]; a.scale = th[4]; a.shift = th[5]; a.y = x_out;

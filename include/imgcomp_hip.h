@@ -89,6 +89,21 @@ int ic_conv3x3_c128_set_tuning(int key, int value);
 void ic_conv3x3_c128_set_debug_buffer(void* dev_u64);
 
 /* ---------------------------------------------------------------------------------------------
+ * MFMA path for the strided 5x5 layers around the residual stacks: h2 (autoencoder.py:223, conv 64->128),
+ * to_bn (:237, conv 128->C+1) and h12 (:264, transposed conv 128->64).  Filters are re-ordered once by
+ * ic_pack_conv2d_mfma_f32 (TF layout in: conv [5,5,cin,cout], transposed [5,5,cout,cin]); a transposed
+ * conv is stored and executed as its four output phases.  Unsupported shapes return IC_ERR_UNSUPPORTED
+ * (ic_conv2d_mfma_packed_floats returns 0) -- use ic_conv2d_bn_act_f32 / ic_deconv2d_bn_act_f32 then.
+ *   y = act(conv(x) * scale + shift);  x (N,Cin,H,W) -> y (N,Cout,H/2,W/2) or, transposed, (N,Cout,2H,2W)
+ */
+size_t ic_conv2d_mfma_packed_floats(int KH, int KW, int Cin, int Cout, int stride, int transposed);
+int ic_pack_conv2d_mfma_f32(const float* w_tf, float* w_packed, int KH, int KW, int Cin, int Cout,
+                            int stride, int transposed, ic_stream_t stream);
+int ic_conv2d_mfma_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
+                              float* y, int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride,
+                              int transposed, int relu, ic_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Importance map + quantiser.
  * ic_quantize_f32 replaces quantizer.quantize / _quantize1d (quantizer.py:37-100):
  *   d_j = (z - c_j)^2; qsoft = sum_j softmax(-sigma d)_j c_j; symbols = first argmax_j of
@@ -140,10 +155,10 @@ int ic_sum_f32(const float* v, long long count, float* partial, float* out_sum, 
  *
  * enc_tab_host: host array of device pointers, 3 per conv layer {w, scale, shift}, in order
  *   h1, h2, 32 residual convs (res_block_enc_0/enc_0_1/conv1 ... res_block_enc_final/conv2),
- *   to_bn; then centers.  Count = 3*35 + 1 = 106.  The 32 residual filters are PACKED
- *   (ic_pack_conv3x3_c128_f32); h1/h2/to_bn are TF layout.
- * dec_tab_host: from_bn, 32 residual convs, h12, h13 -> 3*35 = 105 pointers (deconv filters in TF
- *   conv2d_transpose layout, residual filters packed).
+ *   to_bn; then centers.  Count = 3*35 + 1 = 106.  The 32 residual filters are PACKED with
+ *   ic_pack_conv3x3_c128_f32, h2 and to_bn with ic_pack_conv2d_mfma_f32; h1 is TF layout.
+ * dec_tab_host: from_bn, 32 residual convs, h12, h13 -> 3*35 = 105 pointers (from_bn and h13 filters in TF
+ *   conv2d_transpose layout, residual filters packed, h12 packed with ic_pack_conv2d_mfma_f32).
  * B = arch_param_B (5).  C = num_chan_bn.  x: (N,3,H,W) float 0..255, H and W multiples of 8.
  * Outputs of encode (each nullable except symbols/qhard): heatmap,z,qsoft,qhard,qbar (N,C,H/8,W/8),
  * symbols int64.  decode: q (N,C,H/8,W/8) -> x_out (N,3,H,W) clipped to [0,255].

@@ -91,6 +91,41 @@ def test_deconv2d(cuda, name, N, Cin, H, W, Cout, K, relu, denorm):
     assert_close(y, ref, 'deconv2d ' + name)
 
 
+@pytest.mark.parametrize('name,N,Cin,H,W,Cout,transposed,relu', [
+    ('h2', 1, 64, 24, 40, 128, 0, 1),
+    ('h2_ragged', 2, 64, 14, 22, 128, 0, 1),
+    ('to_bn', 1, 128, 12, 20, 33, 0, 0),
+    ('to_bn_hi', 1, 128, 10, 18, 65, 0, 0),
+    ('h12', 1, 128, 9, 13, 64, 1, 1),
+    ('h12_b', 2, 128, 8, 32, 64, 1, 1),
+])
+def test_conv2d_mfma_strided(cuda, name, N, Cin, H, W, Cout, transposed, relu):
+    """matrix-core path of h2 / to_bn / h12 (packed filters, transposed conv as four phases)."""
+    L = _lib()
+    rs = np.random.RandomState(zlib.crc32(name.encode()) % 1000 + 7)
+    x = rs.normal(0, 1, (N, Cin, H, W)).astype(np.float32)
+    wshape = (5, 5, Cout, Cin) if transposed else (5, 5, Cin, Cout)
+    w = rs.normal(0, 0.05, wshape).astype(np.float32)
+    scale, shift = _bn(rs, Cout)
+    n = L.lib.ic_conv2d_mfma_packed_floats(5, 5, Cin, Cout, 2, transposed)
+    assert n > 0
+    d = lambda a: dev(a, cuda)
+    xd, wd, sd, hd = d(x), d(w), d(scale), d(shift)
+    wp = torch.empty(n, device=cuda)
+    L.check(L.lib.ic_pack_conv2d_mfma_f32(L.ptr(wd), L.ptr(wp), 5, 5, Cin, Cout, 2, transposed, L.current_stream()))
+    oshape = (N, Cout, 2 * H, 2 * W) if transposed else (N, Cout, -(-H // 2), -(-W // 2))
+    y = torch.full(oshape, float('nan'), device=cuda)
+    L.check(L.lib.ic_conv2d_mfma_bn_act_f32(L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(y), N, Cin, H, W, Cout,
+                                            5, 5, 2, transposed, relu, L.current_stream()))
+    torch.cuda.synchronize()
+    ref = _ref_conv(x, w, scale, shift, 2, relu, transposed=bool(transposed))
+    assert_close(y, ref, 'conv2d mfma ' + name)
+    # unsupported shapes say so instead of computing something else
+    assert L.lib.ic_conv2d_mfma_packed_floats(3, 3, 32, 128, 2, 1) == 0
+    assert L.lib.ic_conv2d_mfma_bn_act_f32(L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(y), N, 32, H, W, 128,
+                                           3, 3, 2, 1, relu, L.current_stream()) == -2
+
+
 NUM_VARIANTS = 10
 
 
