@@ -32,7 +32,7 @@ PROTOTYPES = {
     'ic_conv3x3_c128_set_debug_buffer': (None, [c_void_p]),
     'ic_conv2d_mfma_packed_floats': (c_size_t, [c_int] * 6),
     'ic_pack_conv2d_mfma_f32': (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
-    'ic_conv2d_mfma_bn_act_f32': (c_int, [c_void_p] * 5 + [c_int] * 11 + [c_void_p]),
+    'ic_conv2d_mfma_bn_act_f32': (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p]),
     'ic_quantize_f32': (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                 c_longlong, c_void_p]),
     'ic_heatmap_quantize_f32': (c_int, [c_void_p, c_void_p, c_int, c_float] + [c_void_p] * 6 +
