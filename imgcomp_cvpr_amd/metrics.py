@@ -1,0 +1,100 @@
+"""Host-side validation metrics, restated from the definitions the reference uses in val.py:
+
+  * MS-SSIM in float64 (reference code/ms_ssim_np.py:51-200, called through tf.py_func at val.py:93):
+    5 scales, weights (0.0448, 0.2856, 0.3001, 0.2363, 0.1333), 11-tap Gaussian (sigma 1.5) 'valid' blur
+    shrunk for small images, 2x2 box down-sampling with 'reflect' at the far edge.
+  * PSNR on uint8 images, 10 log10(255^2 / MSE) (reference code/val.py:227-232).
+
+Pure numpy; these run on the host exactly as in the reference (they are not part of the GPU hot path).
+Pinned against outputs of the reference's own implementation: tests/golden/msssim.npz.
+"""
+import numpy as np
+
+_MSSSIM_WEIGHTS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)
+
+
+def _gauss1d(size, sigma):
+    """normalised 1-D Gaussian whose outer product is the fspecial('gaussian') window."""
+    r = size // 2
+    if size % 2 == 0:
+        x = np.arange(-r, r, dtype=np.float64) + 0.5
+    else:
+        x = np.arange(-r, r + 1, dtype=np.float64)
+    g = np.exp(-(x * x) / (2.0 * sigma * sigma))
+    return g / g.sum()
+
+
+def _blur_valid(img, g):
+    """separable 'valid' correlation of an (N,H,W,C) float64 array with the symmetric window g x g."""
+    k = g.size
+    H, W = img.shape[1], img.shape[2]
+    tmp = np.zeros((img.shape[0], H - k + 1, W, img.shape[3]), np.float64)
+    for i in range(k):
+        tmp += g[i] * img[:, i:i + H - k + 1, :, :]
+    out = np.zeros((img.shape[0], H - k + 1, W - k + 1, img.shape[3]), np.float64)
+    for i in range(k):
+        out += g[i] * tmp[:, :, i:i + W - k + 1, :]
+    return out
+
+
+def _ssim_and_cs(img1, img2, max_val=255.0, filter_size=11, filter_sigma=1.5, k1=0.01, k2=0.03):
+    img1 = img1.astype(np.float64)
+    img2 = img2.astype(np.float64)
+    _, h, w, _ = img1.shape
+    size = min(filter_size, h, w)
+    sigma = size * filter_sigma / filter_size
+    g = _gauss1d(size, sigma)
+    mu1, mu2 = _blur_valid(img1, g), _blur_valid(img2, g)
+    s11 = _blur_valid(img1 * img1, g) - mu1 * mu1
+    s22 = _blur_valid(img2 * img2, g) - mu2 * mu2
+    s12 = _blur_valid(img1 * img2, g) - mu1 * mu2
+    c1, c2 = (k1 * max_val) ** 2, (k2 * max_val) ** 2
+    v1 = 2.0 * s12 + c2
+    v2 = s11 + s22 + c2
+    ssim = np.mean(((2.0 * mu1 * mu2 + c1) * v1) / ((mu1 * mu1 + mu2 * mu2 + c1) * v2))
+    cs = np.mean(v1 / v2)
+    return ssim, cs
+
+
+def _downsample2(img):
+    """average of (i, i+1) x (j, j+1) with the far edge reflected, then every second sample."""
+    p = np.pad(img, ((0, 0), (0, 1), (0, 1), (0, 0)), mode='symmetric')
+    box = 0.25 * (p[:, :-1, :-1] + p[:, 1:, :-1] + p[:, :-1, 1:] + p[:, 1:, 1:])
+    return box[:, ::2, ::2, :]
+
+
+def multiscale_ssim(img1, img2, max_val=255.0):
+    """img1, img2: (N,H,W,C) arrays (uint8 or float).  -> float64 MS-SSIM."""
+    if img1.shape != img2.shape:
+        raise RuntimeError('Input images must have the same shape ({} vs. {}).'.format(img1.shape, img2.shape))
+    if img1.ndim != 4:
+        raise RuntimeError('Input images must have four dimensions, not {}'.format(img1.ndim))
+    w = np.array(_MSSSIM_WEIGHTS)
+    im1, im2 = img1.astype(np.float64), img2.astype(np.float64)
+    mssim, mcs = [], []
+    for _ in range(w.size):
+        s, c = _ssim_and_cs(im1, im2, max_val=max_val)
+        mssim.append(s)
+        mcs.append(c)
+        im1, im2 = _downsample2(im1), _downsample2(im2)
+    mcs, mssim = np.array(mcs), np.array(mssim)
+    return float(np.prod(mcs[:-1] ** w[:-1]) * (mssim[-1] ** w[-1]))
+
+
+def msssim_nchw_uint8(x, y):
+    """val.py's metric: uint8 NCHW batches -> float32 MS-SSIM (tf_msssim_np, data_format='NCHW')."""
+    x = np.transpose(np.asarray(x), (0, 2, 3, 1))
+    y = np.transpose(np.asarray(y), (0, 2, 3, 1))
+    assert x.dtype == np.uint8 and y.dtype == np.uint8, 'Expected uint8 input'
+    return np.float32(multiscale_ssim(x, y, max_val=255.0))
+
+
+def psnr_uint8(a, b):
+    """10 log10(255^2 / mean((a-b)^2)) on uint8 images (skimage compare_psnr with data_range 255)."""
+    a = np.asarray(a)
+    b = np.asarray(b)
+    assert a.dtype == np.uint8 and b.dtype == np.uint8, 'Expected uint8 input'
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    if mse == 0:
+        return np.float32(np.inf)
+    return np.float32(10.0 * np.log10(255.0 ** 2 / mse))

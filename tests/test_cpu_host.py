@@ -1,0 +1,207 @@
+"""-m "not gpu": host-side pieces -- config DSL, metrics vs the reference's outputs, NumPy helpers of the
+plugin modules vs the reference's outputs, the C ABI surface, weights inventory, sharding over gloo."""
+import os
+import re
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+# ---- config DSL -----------------------------------------------------------------------------------
+
+def test_config_inheritance_and_values(configs):
+    ae, pc = configs
+    assert ae.arch == 'CVPR' and ae.num_chan_bn == 32 and ae.arch_param_B == 5
+    assert ae.H_target == pytest.approx(0.4) and ae.beta == 500 and ae.num_centers == 6
+    assert ae.normalization == 'FIXED' and ae.heatmap is True and ae.crop_size == (160, 160)
+    assert ae.lr_initial == pytest.approx(8e-5) and ae.batch_size == 30          # batch_size from ../base
+    assert pc.arch == 'res_shallow' and pc.kernel_size == 3 and pc.arch_param__k == 24
+    assert pc.use_centers_for_padding is True and pc.regularization_factor is None
+    with pytest.raises(AttributeError):
+        ae.no_such_parameter
+
+
+def test_config_variants_and_rel_path():
+    from imgcomp_cvpr_amd import config_parser as cp
+    hi, rel = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'hi'))
+    assert hi.num_chan_bn == 64 and hi.H_target == 1.0 and rel == 'ae_configs/cvpr/hi'
+    med, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'med'))
+    assert med.H_target == pytest.approx(1.2)
+    k64, rel = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow_64'))
+    assert k64.arch_param__k == 64 and rel == 'pc_configs/cvpr/res_shallow_64'
+
+
+def test_config_constraints_and_errors(tmp_path):
+    from imgcomp_cvpr_amd import config_parser as cp
+    (tmp_path / 'base').write_text('constrain mode :: A, B\nmode = A\nx = 2*3\n')
+    (tmp_path / 'child').write_text('use base\nmode = B\ny = x + 1  # comment\n')
+    c, _ = cp.parse(str(tmp_path / 'child'))
+    assert c.mode == 'B' and c.y == 7
+    (tmp_path / 'bad').write_text('use base\nmode = C\n')
+    with pytest.raises(ValueError):
+        cp.parse(str(tmp_path / 'bad'))
+    (tmp_path / 'loop').write_text('use loop\n')
+    with pytest.raises(ValueError):
+        cp.parse(str(tmp_path / 'loop'))
+    with pytest.raises(FileNotFoundError):
+        cp.parse(str(tmp_path / 'missing'))
+
+
+# ---- metrics vs the reference's own numbers ------------------------------------------------------------
+
+def test_msssim_matches_reference_outputs():
+    from imgcomp_cvpr_amd import metrics
+    from tests.util import msssim_case, MSSSIM_CASES
+    g = np.load(os.path.join(GOLD, 'msssim.npz'))
+    for name in MSSSIM_CASES:
+        img1, img2 = msssim_case(name)
+        assert zlib.crc32(img1.tobytes() + img2.tobytes()) == int(g['crc_' + name]), 'fixture inputs drifted'
+        ssim, cs = metrics._ssim_and_cs(img1, img2)
+        assert ssim == pytest.approx(float(g['ssim_' + name]), abs=1e-10)
+        assert cs == pytest.approx(float(g['cs_' + name]), abs=1e-10)
+        assert metrics.multiscale_ssim(img1, img2) == pytest.approx(float(g['msssim_' + name]), abs=1e-10)
+    a, b = msssim_case('a')
+    assert metrics.multiscale_ssim(a, a) == pytest.approx(1.0)
+    assert float(metrics.msssim_nchw_uint8(a.transpose(0, 3, 1, 2), b.transpose(0, 3, 1, 2))) == pytest.approx(
+        float(g['msssim_a']), abs=1e-6)
+
+
+def test_psnr():
+    from imgcomp_cvpr_amd import metrics
+    a = np.full((1, 3, 8, 8), 100, np.uint8)
+    b = a.copy(); b[0, 0, 0, 0] = 110
+    mse = 100.0 / a.size
+    assert float(metrics.psnr_uint8(a, b)) == pytest.approx(10 * np.log10(255 ** 2 / mse), rel=1e-6)
+
+
+# ---- NumPy helpers of the plugin module vs the reference's outputs --------------------------------------
+
+def test_probclass_numpy_helpers_match_reference():
+    from imgcomp_cvpr_amd import probclass, config_parser as cp
+    g = np.load(os.path.join(GOLD, 'probclass_np.npz'))
+    pc_cfg, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
+    cls = probclass.get_network_cls(pc_cfg)
+    assert cls.get_context_size(pc_cfg) == int(g['context_size'])
+    assert tuple(cls.get_context_shape(pc_cfg)) == tuple(g['context_shape'])
+    net = cls(pc_cfg, num_centers=6)
+    np.testing.assert_array_equal(net.create_first_mask(), g['first_mask'])
+    np.testing.assert_array_equal(net.create_other_mask(), g['other_mask'])
+    np.testing.assert_array_equal(probclass.pad_for_probclass3d(g['vol'], 9), g['vol_padded'])
+    np.testing.assert_array_equal(probclass.undo_pad_for_probclass3d(g['vol_padded'], 9), g['vol'])
+    blocks = np.stack(list(probclass.iter_over_blocks(g['vol_padded'], (5, 9, 9))))
+    np.testing.assert_array_equal(blocks, g['blocks'])
+    assert probclass.num_blocks(g['vol_padded'].shape, (5, 9, 9)) == int(g['num_blocks'])
+    with pytest.raises(KeyError):
+        probclass.get_network_cls(type('C', (), {'arch': 'nope'}))
+
+
+# ---- C ABI ----------------------------------------------------------------------------------------------------
+
+def _header_prototypes():
+    text = open(os.path.join(ROOT, 'include', 'imgcomp_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return set(re.findall(r'\b(ic_[a-z0-9_]+)\s*\(', text))
+
+
+def test_abi_header_bindings_and_exports_agree():
+    """every ic_* prototype of include/imgcomp_hip.h is bound in _lib.PROTOTYPES and exported by the .so
+    (no compute calls here: there is no GPU)."""
+    from imgcomp_cvpr_amd import _lib
+    names = _header_prototypes()
+    assert names, 'no prototypes parsed'
+    assert names == set(_lib.PROTOTYPES), (names ^ set(_lib.PROTOTYPES))
+    out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r' T (ic_[a-z0-9_]+)', out))
+    assert names <= exported, names - exported
+    assert _lib.lib.ic_abi_version() == 1
+    assert _lib.lib.ic_strerror(-3) == b'workspace too small'
+    assert _lib.lib.ic_conv3x3_c128_packed_floats() == 9 * 128 * 128
+    # size queries are pure host arithmetic
+    assert _lib.lib.ic_pc_workspace_bytes(1, 32, 32, 32, 24) == 4 * 24 * (35 * 38 * 38 + 34 * 36 * 36 + 33 * 34 * 34)
+    assert _lib.lib.ic_ae_workspace_bytes(1, 512, 768, 32) > 0 and _lib.lib.ic_ae_workspace_bytes(0, 1, 1, 1) == 0
+
+
+def test_no_cpu_fallback():
+    """CPU tensors are refused loudly by the plugin surface."""
+    import torch
+    from imgcomp_cvpr_amd import _lib, quantizer, bits
+    with pytest.raises(_lib.HipLibraryError):
+        quantizer.quantize(torch.zeros(1, 1, 2, 2), torch.zeros(6), 1.0)
+    with pytest.raises(_lib.HipLibraryError):
+        bits.bitcost_to_bpp(torch.zeros(1, 1, 2, 2), torch.zeros(1, 3, 16, 16))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'imgcomp_cvpr_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+
+
+# ---- weights inventory ------------------------------------------------------------------------------------------
+
+def test_weight_inventory_matches_reference_counts(configs, syn_weights):
+    from imgcomp_cvpr_amd import weights as W
+    ae, pc = configs
+    assert W.num_parameters(syn_weights) == 10039916
+    enc = sum(a.size for n, a in syn_weights.items() if n.startswith(W.ENC) and 'moving' not in n)
+    dec = sum(a.size for n, a in syn_weights.items() if n.startswith(W.DEC) and 'moving' not in n)
+    pcn = sum(a.size for n, a in syn_weights.items() if n.startswith('probclass3d'))
+    assert (enc, dec, pcn) == (5042440, 4973638, 23838)
+    assert syn_weights[W.DEC + '/from_bn/weights'].shape == (3, 3, 128, 32)   # kh,kw,out,in
+    assert syn_weights[W.ENC + '/to_bn/weights'].shape == (5, 5, 128, 33)
+    assert syn_weights[W.PC + '/conv3d_conv2_mask/weights'].shape == (2, 3, 3, 24, 6)
+    again = W.synthetic_weights(ae, pc)
+    assert all(np.array_equal(again[k], syn_weights[k]) for k in syn_weights)
+
+
+# ---- multi-process sharding (gloo, world_size 2) ----------------------------------------------------------------
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+from imgcomp_cvpr_amd import sharding
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:{port}', rank=int(sys.argv[1]), world_size=2)
+rank, world = sharding.rank_and_world()
+items = ['img%02d' % i for i in range(7)]
+mine = sharding.shard_indices(len(items), rank, world)
+local = [(i, (items[i], i * i)) for i in mine]
+allr = sharding.gather_in_order(local, len(items))
+assert allr == [(items[i], i * i) for i in range(7)], allr
+assert sharding.shard(items) == [items[i] for i in mine]
+dist.barrier()
+dist.destroy_process_group()
+print('rank', rank, 'ok', mine)
+'''
+
+
+def test_image_sharding_over_gloo_world2(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER.format(root=ROOT, port=29000 + os.getpid() % 2000))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert 'rank {} ok'.format(r) in o
+
+
+def test_sharding_single_process():
+    from imgcomp_cvpr_amd import sharding
+    assert sharding.shard_indices(5, 1, 2) == [1, 3]
+    assert sorted(sharding.shard_indices(9, 0, 4) + sharding.shard_indices(9, 1, 4) +
+                  sharding.shard_indices(9, 2, 4) + sharding.shard_indices(9, 3, 4)) == list(range(9))
+    assert sharding.gather_in_order([(1, 'b'), (0, 'a')], 2) == ['a', 'b']
+    with pytest.raises(RuntimeError):
+        sharding.gather_in_order([(0, 'a')], 2)
+    with pytest.raises(ValueError):
+        sharding.shard_indices(3, 2, 2)

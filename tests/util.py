@@ -23,3 +23,18 @@ def assert_close(got, ref64, what, rtol=RTOL):
 
 def dev(a, device, dtype=torch.float32):
     return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).to(device)
+
+
+MSSSIM_CASES = {'a': (176, 208, 0), 'b': (256, 256, 1), 'c': (192, 320, 2)}
+
+
+def msssim_case(name):
+    """seeded NHWC uint8 image pair shared by tests/golden/make_golden.py and the metric tests."""
+    h, w, k = MSSSIM_CASES[name]
+    rs = np.random.RandomState(100 + k)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([128 + 60 * np.sin(xx / (7.0 + c) + yy / 11.0) + 30 * np.cos(yy / (5.0 + c))
+                     for c in range(3)], -1)
+    img1 = np.clip(base + rs.normal(0, 6, base.shape), 0, 255).astype(np.uint8)[None]
+    img2 = np.clip(img1.astype(np.float64) + rs.normal(0, 3 + 4 * k, img1.shape), 0, 255).astype(np.uint8)
+    return img1, img2
