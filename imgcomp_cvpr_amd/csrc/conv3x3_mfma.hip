@@ -78,6 +78,7 @@ struct Geo {
     static constexpr int CHUNK = KC * CS;          // floats per staged chunk
     static constexpr int NST = (CHUNK + 255) / 256;
     static constexpr int LDSF = NST * 256;         // padded: staging writes need no bounds branch
+    static_assert(NST <= 32, "in-bounds mask is 32 bits");
 };
 
 // staging plan: element e = tid + 256 i of the chunk [ci][row][col] -> global offset + in-bounds bit

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const GArgs a) {
     static_assert(WM * WN == 4, "4 waves per work-group");
     static_assert(TR * TC == 32 * PT * WN, "tile = PT accumulator tiles per wave x WN pixel groups");
     static_assert(NT % RD == 0 && RD >= 3, "ring depth must divide the tap count");
+    static_assert(NST <= 32, "in-bounds mask is 32 bits");
     static_assert(CIN % GKC == 0, "Cin multiple of 8");
     __shared__ float lds[2][NST * 256];
 

@@ -128,17 +128,206 @@ __global__ __launch_bounds__(256) void pc_conv3d_kernel(const PcLayerArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Matrix-core version of the k -> k and k -> L layers ("other" mask, 14 live taps).
+// Same implicit-GEMM shape as the autoencoder convs: D[co][voxel] += A[co][kk] * B[kk][voxel] with
+// kk = (8-channel chunk, tap, 2-channel k-step); fp32 MFMA = an fmaf chain in exactly that order, so the
+// logits are still a fixed, position-independent fp32 expression (what an incremental decoder must match).
+//   B: the (2, TR+2, TC+2) x KC-channel halo brick of the work-group's TR x TC voxels of ONE depth slice,
+//      staged through LDS once per KC channels;
+//   A: filter fragments packed per call into the workspace by pc_pack_kernel (filters are tiny: 14 KB per
+//      8-channel chunk), streamed through a 7-slot register ring.
+// Output channels are padded to 32 per tile (24 -> 32, L = 6 -> 32): the padding costs matrix-pipe time
+// (25 % / 81 %) but the layers are small; the VALU kernel above stays as the any-shape fallback.
+// ------------------------------------------------------------------------------------------------
+typedef float pc_f32x16 __attribute__((ext_vector_type(16)));
+typedef float pc_f32x4 __attribute__((ext_vector_type(4)));
+
+#define PC_NT 14          // live taps of the "other" mask, order (kd,kh,kw)
+__device__ __forceinline__ constexpr int pc_tap_kd(int t) { return t < 9 ? 0 : 1; }
+__device__ __forceinline__ constexpr int pc_tap_kh(int t) { return t < 9 ? t / 3 : (t < 12 ? 0 : 1); }
+__device__ __forceinline__ constexpr int pc_tap_kw(int t) { return t < 9 ? t % 3 : (t < 12 ? t - 9 : t - 12); }
+
+// packed[((c8*14 + t)*NCOT + n)*256 + l*4 + j] = w[kd][kh][kw][ci = 8 c8 + 2j + (l>>5)][co = 32n + (l&31)] (0 if co >= Cout)
+__global__ void pc_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout, int NCOT, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int j = idx & 3, l = (idx >> 2) & 63;
+    int r = idx >> 8;
+    const int n = r % NCOT; r /= NCOT;
+    const int t = r % PC_NT, c8 = r / PC_NT;
+    const int tap = (pc_tap_kd(t) * 3 + pc_tap_kh(t)) * 3 + pc_tap_kw(t);
+    const int ci = 8 * c8 + 2 * j + (l >> 5), co = 32 * n + (l & 31);
+    out[idx] = co < Cout ? w[((size_t)tap * Cin + ci) * Cout + co] : 0.f;
+}
+
+template <int CIN, int KC, int WM, int WN, int TR, int TC, bool FINAL>
+__global__ __launch_bounds__(256) void pc_mfma_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
+    constexpr int S = TC + 2, DS = (TR + 2) * S, CS = 2 * DS, CHUNK = KC * CS;
+    constexpr int NST = (CHUNK + 255) / 256;
+    constexpr int NCH = CIN / KC, C8 = KC / 8, RD = 7;
+    static_assert(WM * WN == 4 && TR * TC == 32 * WN, "one 32-voxel accumulator tile per wave");
+    static_assert(CIN % KC == 0 && KC % 8 == 0, "channel chunking");
+    __shared__ float lds[NST * 256];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int tiles_x = (a.OW + TC - 1) / TC, tiles_y = (a.OH + TR - 1) / TR;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y; const int od = b / tiles_y;
+    const int n = blockIdx.z;
+    const int x0 = tx * TC, y0 = ty * TR;
+    const int HW = a.H * a.W;
+    const size_t cstride = (size_t)a.D * HW;
+    const float* __restrict__ xin = a.in + (size_t)n * CIN * cstride + (size_t)od * HW;
+
+    // staging plan: e -> (ci, kd, row, col) of the brick [KC][2][TR+2][TC+2]; VALID conv: clip to the volume
+    int goff[NST];
+    static_assert(NST <= 64, "in-bounds mask is 64 bits");
+    unsigned long long inb = 0;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int e = tid + 256 * i;
+        const int ci = e / CS, r1 = e - ci * CS;
+        const int kd = r1 / DS, r2 = r1 - kd * DS;
+        const int rr = r2 / S, cc = r2 - rr * S;
+        const int iy = y0 + rr, ix = x0 + cc;
+        const bool ok = (e < CHUNK) && iy < a.H && ix < a.W;            // od + kd < D always
+        goff[i] = ok ? (int)(ci * cstride) + kd * HW + iy * a.W + ix : 0;
+        inb |= (ok ? 1ull : 0ull) << i;
+    }
+    const int j = lane & 31, kh = lane >> 5;
+    const int q = 32 * wn + j;
+    const int boff = kh * CS + (q / TC) * S + (q % TC);
+    const int cot = blockIdx.y * WM + wm, ncot = gridDim.y * WM;
+    const pc_f32x4* __restrict__ wp = reinterpret_cast<const pc_f32x4*>(wpk) + (size_t)cot * 64 + lane;
+    const int wstep = ncot * 64;
+
+    pc_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    pc_f32x4 ring[RD];
+#pragma unroll
+    for (int t = 0; t < RD - 2; ++t) ring[t] = wp[(size_t)t * wstep];
+
+    for (int c = 0; c < NCH; ++c) {
+        if (c > 0) __syncthreads();                       // everyone done reading the previous brick
+        const float* xc = xin + (size_t)c * KC * cstride;
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const float v = xc[goff[i]];
+            lds[tid + 256 * i] = ((inb >> i) & 1) ? v : 0.f;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int c8 = 0; c8 < C8; ++c8) {
+            const pc_f32x4* wc = wp + (size_t)((c * C8 + c8) * PC_NT) * wstep;
+            const bool more = (c * C8 + c8 + 1) * 8 < CIN;
+#pragma unroll
+            for (int t = 0; t < PC_NT; ++t) {
+                const int tn = t + RD - 2;
+                if (tn < PC_NT || more) ring[tn % RD] = wc[(size_t)tn * wstep];
+                const int tapoff = pc_tap_kd(t) * DS + pc_tap_kh(t) * S + pc_tap_kw(t);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const float bv = lds[boff + (8 * c8 + 2 * ks) * CS + tapoff];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[t % RD][ks], bv, acc, 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // epilogue: D[i][j], i = (r&3) + 8*(r>>2) + 4*kh output channel of tile `cot`, j = voxel
+    const int oy = y0 + q / TC, ox = x0 + q % TC;
+    const bool live = oy < a.OH && ox < a.OW;
+    const int ovol = a.OD * a.OH * a.OW;
+    const int v = (od * a.OH + (live ? oy : 0)) * a.OW + (live ? ox : 0);
+    float val[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = 32 * cot + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const bool cok = co < a.Cout;
+        float x = acc[r] + (cok ? a.bias[co] : 0.f);
+        if (a.relu) x = fmaxf(x, 0.f);
+        if (a.res && cok) x += a.res[(((size_t)n * a.Cout + co) * a.RD + od + 2) * a.RH * a.RW
+                                     + (size_t)((live ? oy : 0) + 2) * a.RW + (live ? ox : 0) + 2];
+        val[r] = x;
+        if (!FINAL && cok && live) a.out[((size_t)n * a.Cout + co) * ovol + v] = x;
+    }
+    if (FINAL) {
+        // logits of one voxel are split over the two half-waves (kh = 0: channels 0-3, 8-11, ...; kh = 1: 4-7, ...)
+        float lg[16];                                  // channels 0..15 of this voxel (L <= 16)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float mine = val[4 * g + i];                     // channel 8g + 4kh + i
+                const float other = __shfl_xor(mine, 32);              // channel 8g + 4(1-kh) + i
+                lg[8 * g + i] = kh == 0 ? mine : other;
+                lg[8 * g + 4 + i] = kh == 0 ? other : mine;
+            }
+        if (kh == 0 && live) {
+            const size_t vox = (size_t)n * ovol + v;
+            if (a.out) {
+#pragma unroll
+                for (int c2 = 0; c2 < 16; ++c2) if (c2 < a.Cout) a.out[vox * a.Cout + c2] = lg[c2];
+            }
+            if (a.bits) {
+                float m = lg[0];
+#pragma unroll
+                for (int c2 = 1; c2 < 16; ++c2) if (c2 < a.Cout) m = fmaxf(m, lg[c2]);
+                float ssum = 0.f, lsym = 0.f;
+                const int sym = (int)a.symbols[vox];
+#pragma unroll
+                for (int c2 = 0; c2 < 16; ++c2) {
+                    if (c2 < a.Cout) {
+                        const float shv = lg[c2] - m;
+                        ssum += expf(shv);
+                        if (c2 == sym) lsym = shv;
+                    }
+                }
+                a.bits[vox] = __fmul_rn(logf(ssum) - lsym, 1.44269504f);
+            }
+        }
+    }
+}
+
+static size_t pc_packed_floats(int k, int cout) { return (size_t)(k / 8) * PC_NT * ic_cdiv(cout, 32) * 256; }
+static bool pc_mfma_supported(int k, int L) { return (k == 24 || k == 64) && L <= 16; }
+
 extern "C" size_t ic_pc_workspace_bytes(int N, int C, int h, int w, int k) {
     if (N <= 0 || C <= 0 || h <= 0 || w <= 0 || k <= 0) return 0;
     size_t f = (size_t)(C + 3) * (h + 6) * (w + 6) + (size_t)(C + 2) * (h + 4) * (w + 4)
                + (size_t)(C + 1) * (h + 2) * (w + 2);
-    return f * (size_t)N * k * sizeof(float);
+    size_t bytes = f * (size_t)N * k * sizeof(float);
+    if (pc_mfma_supported(k, 16)) bytes += (2 * pc_packed_floats(k, k) + pc_packed_floats(k, 32)) * sizeof(float);
+    return bytes;
 }
 
 template <int COB, bool FIRST, bool FINAL>
 static int launch_pc(const PcLayerArgs& a, hipStream_t st) {
     dim3 g(ic_cdiv(a.OD * a.OH * a.OW, 256), FINAL ? 1 : ic_cdiv(a.Cout, COB), a.N);
     hipLaunchKernelGGL((pc_conv3d_kernel<COB, FIRST, FINAL>), g, dim3(256), 0, st, a);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
+static int launch_pc_mfma(const PcLayerArgs& a, const float* wpk, int k, bool final, hipStream_t st) {
+    if (k == 24) {
+        dim3 g(a.OD * ic_cdiv(a.OH, 8) * ic_cdiv(a.OW, 16), 1, a.N);
+        if (final) hipLaunchKernelGGL((pc_mfma_kernel<24, 24, 1, 4, 8, 16, true>), g, dim3(256), 0, st, a, wpk);
+        else hipLaunchKernelGGL((pc_mfma_kernel<24, 24, 1, 4, 8, 16, false>), g, dim3(256), 0, st, a, wpk);
+    } else {   // k == 64
+        if (final) {
+            dim3 g(a.OD * ic_cdiv(a.OH, 8) * ic_cdiv(a.OW, 16), 1, a.N);
+            hipLaunchKernelGGL((pc_mfma_kernel<64, 16, 1, 4, 8, 16, true>), g, dim3(256), 0, st, a, wpk);
+        } else {
+            dim3 g(a.OD * ic_cdiv(a.OH, 4) * ic_cdiv(a.OW, 16), 1, a.N);
+            hipLaunchKernelGGL((pc_mfma_kernel<64, 16, 2, 2, 4, 16, false>), g, dim3(256), 0, st, a, wpk);
+        }
+    }
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
@@ -162,18 +351,30 @@ static int pc_forward(const float* q, int prepadded, const int64_t* symbols, con
     a.Cin = 1; a.Cout = k; a.D = C + 4; a.H = h + 8; a.W = w + 8; a.OD = C + 3; a.OH = h + 6; a.OW = w + 6;
     a.qC = C; a.qh = h; a.qw = w; a.relu = 1;
     if ((rc = launch_pc<8, true, false>(a, st))) return rc;
+    const bool use_mfma = pc_mfma_supported(k, L);
+    float* pk1 = b2 + (size_t)N * k * (C + 1) * (h + 2) * (w + 2);
+    float* pk2 = pk1 + pc_packed_floats(k, k);
+    float* pk3 = pk2 + pc_packed_floats(k, k);
+    if (use_mfma) {
+        const int t1 = (int)pc_packed_floats(k, k), t3 = (int)pc_packed_floats(k, L);
+        hipLaunchKernelGGL(pc_pack_kernel, dim3(ic_cdiv(t1, 256)), dim3(256), 0, st, wt[2], pk1, k, k, ic_cdiv(k, 32), t1);
+        hipLaunchKernelGGL(pc_pack_kernel, dim3(ic_cdiv(t1, 256)), dim3(256), 0, st, wt[4], pk2, k, k, ic_cdiv(k, 32), t1);
+        hipLaunchKernelGGL(pc_pack_kernel, dim3(ic_cdiv(t3, 256)), dim3(256), 0, st, wt[6], pk3, k, L, 1, t3);
+        IC_LAUNCH_CHECK();
+    }
     // res1/conv1: k -> k, other mask, ReLU
     a.in = b0; a.w = wt[2]; a.bias = wt[3]; a.out = b1;
     a.Cin = k; a.D = C + 3; a.H = h + 6; a.W = w + 6; a.OD = C + 2; a.OH = h + 4; a.OW = w + 4; a.relu = 1;
-    if ((rc = launch_pc<8, false, false>(a, st))) return rc;
+    if ((rc = use_mfma ? launch_pc_mfma(a, pk1, k, false, st) : launch_pc<8, false, false>(a, st))) return rc;
     // res1/conv2: k -> k, linear, + conv0 output cropped [2:, 2:-2, 2:-2]
     a.in = b1; a.w = wt[4]; a.bias = wt[5]; a.out = b2; a.res = b0; a.RD = C + 3; a.RH = h + 6; a.RW = w + 6;
     a.D = C + 2; a.H = h + 4; a.W = w + 4; a.OD = C + 1; a.OH = h + 2; a.OW = w + 2; a.relu = 0;
-    if ((rc = launch_pc<8, false, false>(a, st))) return rc;
+    if ((rc = use_mfma ? launch_pc_mfma(a, pk2, k, false, st) : launch_pc<8, false, false>(a, st))) return rc;
     // conv2 (final): k -> L, ReLU (default activation), logits channels-last + bits
     a.in = b2; a.w = wt[6]; a.bias = wt[7]; a.out = logits; a.res = nullptr; a.symbols = symbols; a.bits = bits;
     a.Cout = L; a.D = C + 1; a.H = h + 2; a.W = w + 2; a.OD = C; a.OH = h; a.OW = w; a.relu = 1;
-    if (L <= 8) rc = launch_pc<8, false, true>(a, st);
+    if (use_mfma) rc = launch_pc_mfma(a, pk3, k, true, st);
+    else if (L <= 8) rc = launch_pc<8, false, true>(a, st);
     else rc = launch_pc<16, false, true>(a, st);
     return rc;
 }
