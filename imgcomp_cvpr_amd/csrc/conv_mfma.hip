@@ -25,11 +25,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GKC 8
 
 struct GArgs {
-    const float* x; const float* wp; const float* scale; const float* shift; float* y;
+    const float* x; const float* scale; const float* shift; float* y;
     int N, IH, IW;          // input extent
     int GH, GW;             // output grid extent (per phase for transposed)
-    int OH, OW, OS, py, px; // output tensor extent, grid->output stride and phase offset
-    int oy0, ox0;           // input offset of tap (0,0) relative to grid position * PS
+    int OH, OW, OS;         // output tensor extent, grid -> output stride (2 for transposed phases)
     int Cout, relu;
     int tiles_x, tiles_y;
 };
@@ -56,22 +55,36 @@ __global__ void pack_conv_mfma_kernel(const float* __restrict__ w, float* __rest
     out[idx] = v;
 }
 
-template <int NTY, int NTX, int PS, int CIN, int WM, int WN, int PT, int TR, int TC, int RD>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const GArgs a) {
+struct GPhase { const float* wp; int oy0, ox0, py, px; };
+
+template <int NTY, int NTX, int PS, int WK, int TR, int TC>
+struct GGeo {
+    static constexpr int ROWS = (TR - 1) * PS + NTY, COLS = (TC - 1) * PS + NTX;
+    static constexpr int S = COLS, CS = ROWS * COLS, CHUNK = GKC * WK * CS;
+    static constexpr int NST = (CHUNK + 255) / 256;
+    static constexpr int LDSF = 2 * NST * 256;
+    static_assert(NST <= 32, "in-bounds mask is 32 bits");
+};
+
+// WM x WN x WK = 4 waves: WM output-channel tiles x WN pixel groups x WK slices of the K (input channel)
+// axis.  With WK > 1 each stage holds 8*WK channels in LDS, wave wk multiplies channels [8 wk, 8 wk + 8) of
+// every stage, and the WK partial accumulators are summed through LDS in the fixed order wk = 0..WK-1
+// (deterministic, position independent).  Split-K is for layers whose output is too small to fill the chip
+// with whole-K tiles (to_bn: 6144 pixels x 33 channels, K = 3200).
+template <int NTY, int NTX, int PS, int CIN, int WM, int WN, int WK, int PT, int TR, int TC, int RD>
+__device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph, float* __restrict__ lds) {
+    using G = GGeo<NTY, NTX, PS, WK, TR, TC>;
     constexpr int NT = NTY * NTX;
-    constexpr int NCH = CIN / GKC;
-    constexpr int ROWS = (TR - 1) * PS + NTY, COLS = (TC - 1) * PS + NTX;
-    constexpr int S = COLS, CS = ROWS * COLS, CHUNK = GKC * CS;
-    constexpr int NST = (CHUNK + 255) / 256;
-    static_assert(WM * WN == 4, "4 waves per work-group");
+    constexpr int NCH = CIN / (GKC * WK);
+    constexpr int S = G::S, CS = G::CS, CHUNK = G::CHUNK, NST = G::NST;
+    static_assert(WM * WN * WK == 4, "4 waves per work-group");
     static_assert(TR * TC == 32 * PT * WN, "tile = PT accumulator tiles per wave x WN pixel groups");
     static_assert(NT % RD == 0 && RD >= 3, "ring depth must divide the tap count");
-    static_assert(NST <= 32, "in-bounds mask is 32 bits");
-    static_assert(CIN % GKC == 0, "Cin multiple of 8");
-    __shared__ float lds[2][NST * 256];
+    static_assert(CIN % (GKC * WK) == 0, "Cin multiple of 8 * WK");
+    static_assert(WK == 1 || (16 % WK == 0 && WM * WN * WK * PT * 16 * 64 <= G::LDSF), "reduction scratch fits in the staging buffers");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave % WM, wn = wave / WM;
+    const int wm = wave % WM, wn = (wave / WM) % WN, wk = wave / (WM * WN);
     int b = blockIdx.x;
     const int tx_ = b % a.tiles_x; b /= a.tiles_x;
     const int ty_ = b % a.tiles_y; const int n = b / a.tiles_y;
@@ -84,7 +97,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const GArgs a) {
     // staging plan
     int goff[NST];
     unsigned inb = 0;
-    const int iy0 = gy0 * PS + a.oy0, ix0 = gx0 * PS + a.ox0;
+    const int iy0 = gy0 * PS + ph.oy0, ix0 = gx0 * PS + ph.ox0;
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
         const int e = tid + 256 * i;
@@ -100,11 +113,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const GArgs a) {
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
         const int q = 32 * (PT * wn + p) + j;
-        boff[p] = kh * CS + (q / TC) * PS * S + (q % TC) * PS;
+        boff[p] = (GKC * wk + kh) * CS + (q / TC) * PS * S + (q % TC) * PS;
     }
-    // wp[(c*NT + t)*ncot*64] = A fragments of chunk c, tap t for this wave's output channels
-    const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + (size_t)cot * 64 + lane;
+    // wp[(c8*NT + t)*ncot*64] = A fragments of 8-channel chunk c8, tap t for this wave's output channels
+    const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(ph.wp) + (size_t)cot * 64 + lane;
     const int wstep = ncot * 64;
+    const size_t cstep = (size_t)NT * wstep;              // one 8-channel chunk of fragments
 
     f32x16 acc[PT];
 #pragma unroll
@@ -113,33 +127,36 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const GArgs a) {
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
     f32x4 ring[RD];
+    {
+        const f32x4* w0 = wp + (size_t)wk * cstep;
 #pragma unroll
-    for (int t = 0; t < RD - 2; ++t) ring[t] = wp[(size_t)t * wstep];
+        for (int t = 0; t < RD - 2; ++t) ring[t] = w0[(size_t)t * wstep];
+    }
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
         const float v = xin[goff[i]];
-        lds[0][tid + 256 * i] = ((inb >> i) & 1) ? v : 0.f;
+        lds[tid + 256 * i] = ((inb >> i) & 1) ? v : 0.f;
     }
     __syncthreads();
 
     for (int c = 0; c < NCH; ++c) {
-        const int buf = c & 1;
         const bool more = c + 1 < NCH;
         float st[NST];
         if (more) {
-            const float* xc = xin + (size_t)(c + 1) * GKC * IHW;
+            const float* xc = xin + (size_t)(c + 1) * GKC * WK * IHW;
 #pragma unroll
             for (int i = 0; i < NST; ++i) st[i] = xc[goff[i]];
         }
-        const float* __restrict__ L = lds[buf];
-        const f32x4* wc = wp + (size_t)c * NT * wstep;
+        const float* __restrict__ L = lds + (c & 1) * (NST * 256);
+        const f32x4* wc = wp + (size_t)(c * WK + wk) * cstep;
+        const f32x4* wnx = wp + (size_t)((c + 1) * WK + wk) * cstep;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             // ring: request tap g + RD - 2 into the slot whose last reader was tap g - 2
             {
                 const int tn = t + RD - 2;
                 if (tn < NT) ring[tn % RD] = wc[(size_t)tn * wstep];
-                else if (more) ring[tn % RD] = wc[(size_t)tn * wstep];     // runs on into chunk c+1 (contiguous)
+                else if (more) ring[tn % RD] = wnx[(size_t)(tn - NT) * wstep];
             }
             const int tapoff = (t / NTX) * S + (t % NTX);
 #pragma unroll
@@ -153,8 +170,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const GArgs a) {
             }
         }
         if (more) {
+            float* __restrict__ Ln = lds + ((c & 1) ^ 1) * (NST * 256);
 #pragma unroll
-            for (int i = 0; i < NST; ++i) lds[buf ^ 1][tid + 256 * i] = ((inb >> i) & 1) ? st[i] : 0.f;
+            for (int i = 0; i < NST; ++i) Ln[tid + 256 * i] = ((inb >> i) & 1) ? st[i] : 0.f;
         }
         // raw barrier: own LDS traffic done, filter prefetch stays in flight (no vmcnt(0) drain)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -165,30 +183,66 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const GArgs a) {
     const float* __restrict__ scale = a.scale;
     const float* __restrict__ shift = a.shift;
     float* __restrict__ y = a.y;
-    float sc[16], sh[16];
-    bool cok[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = 32 * cot + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        cok[r] = co < a.Cout;
-        sc[r] = cok[r] ? scale[co] : 0.f;
-        sh[r] = cok[r] ? shift[co] : 0.f;
-    }
     const size_t OHW = (size_t)a.OH * a.OW;
     const size_t cbase = ((size_t)n * a.Cout + 32 * cot + 4 * kh) * OHW;
+    constexpr int RPW = 16 / WK;                           // accumulator registers finished by each K-slice wave
+    if (WK > 1) {
+        // all waves passed the loop's last barrier: the staging buffers are free
+        float* red = lds + (size_t)((wm * WN + wn) * WK) * (PT * 16 * 64);
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(size_t)((wk * PT + p) * 16 + r) * 64 + lane] = acc[p][r];
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int r = wk * RPW + rr;
+                float sum = 0.f;
+#pragma unroll
+                for (int k2 = 0; k2 < WK; ++k2) sum += red[(size_t)((k2 * PT + p) * 16 + r) * 64 + lane];
+                acc[p][rr] = sum;                          // compacted: slot rr now holds register wk*RPW + rr
+            }
+    }
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
         const int q = 32 * (PT * wn + p) + j;
         const int gy = gy0 + q / TC, gx = gx0 + q % TC;
         if (gy < a.GH && gx < a.GW) {
-            const size_t pix = cbase + (size_t)(gy * a.OS + a.py) * a.OW + (gx * a.OS + a.px);
+            const size_t pix = cbase + (size_t)(gy * a.OS + ph.py) * a.OW + (gx * a.OS + ph.px);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = fmaf(acc[p][r], sc[r], sh[r]);
-                if (a.relu) v = fmaxf(v, 0.f);
-                if (cok[r]) y[pix + (size_t)((r & 3) + 8 * (r >> 2)) * OHW] = v;
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int r = (WK > 1 ? wk * RPW : 0) + rr;
+                const int crow = (r & 3) + 8 * (r >> 2);
+                const int co = 32 * cot + crow + 4 * kh;
+                if (co < a.Cout) {
+                    float v = fmaf(acc[p][rr], scale[co], shift[co]);
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    y[pix + (size_t)crow * OHW] = v;
+                }
             }
         }
+    }
+}
+
+template <int NTY, int NTX, int PS, int CIN, int WM, int WN, int WK, int PT, int TR, int TC, int RD>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const GArgs a, const GPhase ph) {
+    __shared__ float lds[GGeo<NTY, NTX, PS, WK, TR, TC>::LDSF];
+    conv_mfma_body<NTY, NTX, PS, CIN, WM, WN, WK, PT, TR, TC, RD>(a, ph, lds);
+}
+
+// all four output phases of a 5x5 / stride-2 transposed convolution in ONE launch (blockIdx.z = phase): 1.5 k
+// work-groups of unequal length that the dispatcher packs onto the CUs as slots free up.
+struct GPhases4 { GPhase p[4]; };
+template <int CIN, int WM, int WN, int PT, int TR, int TC>
+__global__ __launch_bounds__(256) void deconv5_mfma_kernel(const GArgs a, const GPhases4 ph) {
+    __shared__ float lds[GGeo<3, 3, 1, 1, TR, TC>::LDSF];
+    switch (blockIdx.z) {        // phase order (py,px) = (0,0),(0,1),(1,0),(1,1): taps 2x2, 2x3, 3x2, 3x3
+        case 0: conv_mfma_body<2, 2, 1, CIN, WM, WN, 1, PT, TR, TC, 4>(a, ph.p[0], lds); break;
+        case 1: conv_mfma_body<2, 3, 1, CIN, WM, WN, 1, PT, TR, TC, 3>(a, ph.p[1], lds); break;
+        case 2: conv_mfma_body<3, 2, 1, CIN, WM, WN, 1, PT, TR, TC, 3>(a, ph.p[2], lds); break;
+        default: conv_mfma_body<3, 3, 1, CIN, WM, WN, 1, PT, TR, TC, 3>(a, ph.p[3], lds); break;
     }
 }
 
@@ -248,13 +302,6 @@ extern "C" int ic_pack_conv2d_mfma_f32(const float* w_tf, float* w_packed, int K
     return IC_OK;
 }
 
-#define G_LAUNCH(NTY_, NTX_, PS_, CIN_, WM_, WN_, PT_, TR_, TC_, RD_)                                         \
-    do {                                                                                                       \
-        a.tiles_x = ic_cdiv(a.GW, TC_); a.tiles_y = ic_cdiv(a.GH, TR_);                                        \
-        hipLaunchKernelGGL((conv_mfma_kernel<NTY_, NTX_, PS_, CIN_, WM_, WN_, PT_, TR_, TC_, RD_>),            \
-                           dim3(a.tiles_x * a.tiles_y * a.N, ncot / WM_), dim3(256), 0, st, a);                \
-    } while (0)
-
 extern "C" int ic_conv2d_mfma_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
                                          float* y, int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride,
                                          int transposed, int relu, ic_stream_t stream) {
@@ -267,28 +314,36 @@ extern "C" int ic_conv2d_mfma_bn_act_f32(const float* x, const float* w_packed, 
     a.x = x; a.scale = scale; a.shift = shift; a.y = y;
     a.N = N; a.IH = H; a.IW = W; a.Cout = Cout; a.relu = relu;
     if (!transposed) {
-        a.wp = w_packed;
-        a.GH = ic_cdiv(H, 2); a.GW = ic_cdiv(W, 2); a.OH = a.GH; a.OW = a.GW; a.OS = 1; a.py = 0; a.px = 0;
-        a.oy0 = -ic_same_pad_before(H, KH, 2); a.ox0 = -ic_same_pad_before(W, KW, 2);
-        if (Cin == 64) G_LAUNCH(5, 5, 2, 64, 4, 1, 1, 2, 16, 5);          // h2: 4 co tiles x 32 px
-        else G_LAUNCH(5, 5, 2, 128, 2, 2, 1, 4, 16, 5);                   // to_bn: 2 co tiles x 64 px
-    } else {
+        GPhase ph{};
+        ph.wp = w_packed; ph.py = 0; ph.px = 0;
+        ph.oy0 = -ic_same_pad_before(H, KH, 2); ph.ox0 = -ic_same_pad_before(W, KW, 2);
+        a.GH = ic_cdiv(H, 2); a.GW = ic_cdiv(W, 2); a.OH = a.GH; a.OW = a.GW; a.OS = 1;
+        if (Cin == 64) {            // h2: 4 channel tiles x 32 pixels per work-group
+            a.tiles_x = ic_cdiv(a.GW, 16); a.tiles_y = ic_cdiv(a.GH, 2);
+            hipLaunchKernelGGL((conv_mfma_kernel<5, 5, 2, 64, 4, 1, 1, 1, 2, 16, 5>),
+                               dim3(a.tiles_x * a.tiles_y * N, ncot / 4), dim3(256), 0, st, a, ph);
+        } else {                    // to_bn: 1 channel tile x 32 pixels x 4 K-slices per work-group
+            a.tiles_x = ic_cdiv(a.GW, 16); a.tiles_y = ic_cdiv(a.GH, 2);
+            hipLaunchKernelGGL((conv_mfma_kernel<5, 5, 2, 128, 1, 1, 4, 1, 2, 16, 5>),
+                               dim3(a.tiles_x * a.tiles_y * N, ncot), dim3(256), 0, st, a, ph);
+        }
+    } else {                        // h12: four phases, 2 channel tiles x 2 pixel groups of 32 per work-group
         a.GH = H; a.GW = W; a.OH = 2 * H; a.OW = 2 * W; a.OS = 2;
         const int pad = 1, nch = Cin / GKC;
+        GPhases4 ph{};
         size_t off = 0;
         for (int py = 0; py < 2; ++py)
             for (int px = 0; px < 2; ++px) {
                 int nty, ntx, kyb, kxb;
-                phase_taps(KH, pad, py, &nty, &a.oy0, &kyb);
-                phase_taps(KW, pad, px, &ntx, &a.ox0, &kxb);
-                a.wp = w_packed + off; a.py = py; a.px = px;
-                // h12: 2 co tiles x 2 pixel groups of 32 px
-                if (nty == 3 && ntx == 3) G_LAUNCH(3, 3, 1, 128, 2, 2, 1, 4, 16, 3);
-                else if (nty == 3 && ntx == 2) G_LAUNCH(3, 2, 1, 128, 2, 2, 1, 4, 16, 3);
-                else if (nty == 2 && ntx == 3) G_LAUNCH(2, 3, 1, 128, 2, 2, 1, 4, 16, 3);
-                else G_LAUNCH(2, 2, 1, 128, 2, 2, 1, 4, 16, 4);
+                GPhase& g = ph.p[py * 2 + px];
+                phase_taps(KH, pad, py, &nty, &g.oy0, &kyb);
+                phase_taps(KW, pad, px, &ntx, &g.ox0, &kxb);
+                g.wp = w_packed + off; g.py = py; g.px = px;
                 off += (size_t)nch * nty * ntx * ncot * 256;
             }
+        a.tiles_x = ic_cdiv(a.GW, 16); a.tiles_y = ic_cdiv(a.GH, 4);
+        hipLaunchKernelGGL((deconv5_mfma_kernel<128, 2, 2, 1, 4, 16>),
+                           dim3(a.tiles_x * a.tiles_y * N, ncot / 2, 4), dim3(256), 0, st, a, ph);
     }
     IC_LAUNCH_CHECK();
     return IC_OK;
