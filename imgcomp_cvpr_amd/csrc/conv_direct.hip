@@ -8,7 +8,7 @@
 #include "internal.h"
 
 
-template <int COB, bool TRANSPOSED>
+template <int COB, bool TRANSPOSED, bool CONTIG = false>
 __global__ __launch_bounds__(256) void conv2d_direct_kernel(const ConvArgs a) {
     const int n = blockIdx.z;
     int cob, py = 0, px = 0;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void conv2d_direct_kernel(const ConvArgs a) {
                 }
                 const float* wp = a.w + (size_t)(ky * a.KW + kx) * tapstride + (size_t)ci * a.w_sci;
 #pragma unroll
-                for (int j = 0; j < COB; ++j) acc[j] = fmaf(xv, wp[wofs[j]], acc[j]);
+                for (int j = 0; j < COB; ++j) acc[j] = fmaf(xv, CONTIG ? wp[co0 + j] : wp[wofs[j]], acc[j]);
             }
         }
     }
@@ -84,7 +84,11 @@ static int launch_direct(const ConvArgs& a, hipStream_t st) {
     const int GH = TRANSPOSED ? a.H : a.OH, GW = TRANSPOSED ? a.W : a.OW;
     const int pb = ic_cdiv(GH * GW, 256);
     // small Cout (h13: 3) keeps registers low; otherwise 16 accumulators per lane
-    if (a.Cout <= 4) {
+    if (!TRANSPOSED && a.Cin <= 4 && a.Cout % 32 == 0 && a.w_sco == 1) {
+        // h1: few input channels, many outputs: 32 accumulators per lane, filter taps as runs of 32 scalars
+        dim3 g(pb, a.Cout / 32, a.N);
+        hipLaunchKernelGGL((conv2d_direct_kernel<32, false, true>), g, dim3(256), 0, st, a);
+    } else if (a.Cout <= 4) {
         dim3 g(pb, (TRANSPOSED ? 4 : 1) * ic_cdiv(a.Cout, 4), a.N);
         hipLaunchKernelGGL((conv2d_direct_kernel<4, TRANSPOSED>), g, dim3(256), 0, st, a);
     } else if (a.Cout % 16 != 0 && a.Cout % 11 == 0) {   // to_bn: 33 = 3 x 11
@@ -109,6 +113,10 @@ int icx_conv2d(ConvArgs a, bool transposed, hipStream_t st) {
     // pads of the SAME forward conv (2H -> H) whose adjoint this is (k=3: 0, k=5: 1)
     a.pt = ic_same_pad_before(2 * a.H, a.KH, 2); a.pl = ic_same_pad_before(2 * a.W, a.KW, 2);
     a.w_sci = 1; a.w_sco = a.Cin;                      // TF conv2d_transpose filter [kh,kw,cout,cin]
+    if (a.Cout <= 4 && a.KH == 5 && a.KW == 5) {
+        const int rc = icx_deconv5_small_cout(a, st);
+        if (rc != IC_ERR_UNSUPPORTED) return rc;
+    }
     return launch_direct<true>(a, st);
 }
 

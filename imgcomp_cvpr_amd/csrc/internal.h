@@ -14,3 +14,7 @@ struct ConvArgs {
 
 // fills OH/OW/pads/filter strides for a TF-SAME conv (transposed = stride-2 conv2d_transpose) and launches
 int icx_conv2d(ConvArgs a, bool transposed, hipStream_t st);
+
+// 5x5 / stride-2 transposed conv with <= 4 output channels (h13); `a` already completed by icx_conv2d's
+// transposed branch.  IC_ERR_UNSUPPORTED when the shape does not fit.
+int icx_deconv5_small_cout(const ConvArgs& a, hipStream_t st);
