@@ -10,7 +10,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_longlong, c_size_t, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libimgcomp_hip.so')
+# IMGCOMP_HIP_LIB: tuning aid (A/B two builds of the library on one GPU box); default = the in-tree build
+LIB_PATH = os.environ.get('IMGCOMP_HIP_LIB') or os.path.join(_HERE, 'libimgcomp_hip.so')
 
 
 class HipLibraryError(RuntimeError):

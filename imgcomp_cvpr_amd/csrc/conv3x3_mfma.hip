@@ -53,7 +53,11 @@ struct C3Args {
     do {                                                                                          \
         if (a.dbg && threadIdx.x == 0) {                                                          \
             unsigned long long* d_ = a.dbg + 4 * (size_t)blockIdx.x;                              \
-            d_[0] = t_start; d_[1] = t_pro; d_[2] = t_main; d_[3] = __builtin_readcyclecounter(); \
+            /* stamps: start, prologue length | (XCC_ID:HW_ID << 24), main-loop end, end */      \
+            const unsigned long long hw_ = ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32) | \
+                                           (unsigned)__builtin_amdgcn_s_getreg(0xF804);            \
+            d_[0] = t_start; d_[1] = (t_pro - t_start) | (hw_ << 24); d_[2] = t_main;             \
+            d_[3] = __builtin_readcyclecounter();                                                 \
         }                                                                                         \
     } while (0)
 

@@ -50,7 +50,7 @@ def main():
     for v in vs:
         pt, tr, tc = VARIANTS[v]
         nwg = a.n * -(-a.h // tr) * -(-a.w // tc)
-        for pipe, abl in [(0, 0)] + [(1, int(m)) for m in a.abl.split(',')]:
+        for pipe, abl in [(pp, int(m)) for pp in (0, 1) for m in a.abl.split(',')]:
             lib.ic_conv3x3_c128_set_tuning(3, abl)
             for pad in [int(s) for s in a.pads.split(',')]:
                 lib.ic_conv3x3_c128_set_tuning(0, v)
@@ -75,11 +75,13 @@ def main():
                     torch.cuda.synchronize()
                     lib.ic_conv3x3_c128_set_debug_buffer(None)
                     d = dbg.cpu().view(nwg, 4).double()
-                    pro, main, epi = d[:, 1] - d[:, 0], d[:, 2] - d[:, 1], d[:, 3] - d[:, 2]
+                    import numpy as np
+                    raw = dbg.cpu().numpy().reshape(nwg, 4).astype(np.uint64)
+                    pro = torch.as_tensor((raw[:, 1] & np.uint64(0xFFFFFF)).astype(np.float64))
+                    main, epi = d[:, 2] - d[:, 0] - pro, d[:, 3] - d[:, 2]
                     print('    phases [shader clocks] prologue mean {:.0f} max {:.0f} | main mean {:.0f} max {:.0f} | '
-                          'epilogue mean {:.0f} max {:.0f} | start spread {:.0f} | span {:.0f}'.format(
-                              pro.mean(), pro.max(), main.mean(), main.max(), epi.mean(), epi.max(),
-                              d[:, 0].max() - d[:, 0].min(), d[:, 3].max() - d[:, 0].min()))
+                          'epilogue mean {:.0f} max {:.0f}'.format(
+                              pro.mean(), pro.max(), main.mean(), main.max(), epi.mean(), epi.max()))
     lib.ic_conv3x3_c128_set_tuning(0, -1)
     lib.ic_conv3x3_c128_set_tuning(1, 0)
     lib.ic_conv3x3_c128_set_tuning(2, -1)
