@@ -404,6 +404,39 @@ extern "C" int ic_pc_bitcost_f32(const float* q, const int64_t* symbols, const f
                       workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+// ---- logits -> integer frequency tables for the arithmetic coder (probclass.py:443-444, :474) ----
+// pr = softmax(logits); freqs = max(int64(pr * resolution), 1).  One lane per context; a fixed per-row fp32
+// expression (max, exp, sequential sum, divide, multiply, truncate), so the encoder (all contexts at once) and
+// the decoder (one context at a time) derive IDENTICAL tables from identical logits.
+__global__ __launch_bounds__(256) void logits_to_freqs_kernel(const float* __restrict__ logits, long long count, int L,
+                                                              float resolution, long long* __restrict__ freqs,
+                                                              float* __restrict__ pr) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const float* l = logits + i * L;
+    float m = l[0];
+    for (int j = 1; j < L; ++j) m = fmaxf(m, l[j]);
+    float e[16];
+    float s = 0.f;
+    for (int j = 0; j < L; ++j) { e[j] = expf(l[j] - m); s += e[j]; }
+    for (int j = 0; j < L; ++j) {
+        const float p = e[j] / s;
+        if (pr) pr[i * L + j] = p;
+        long long f = (long long)__fmul_rn(p, resolution);
+        freqs[i * L + j] = f < 1 ? 1 : f;
+    }
+}
+
+extern "C" int ic_pc_logits_to_freqs_f32(const float* logits, long long count, int L, float resolution,
+                                         int64_t* freqs, float* pr, ic_stream_t stream) {
+    IC_CHECK_ARG(logits && freqs && count > 0 && L > 0);
+    if (L > 16) return IC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(logits_to_freqs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       logits, count, L, resolution, (long long*)freqs, pr);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
 // ---- deterministic sum (bits.py:4-14 numerator) ----
 __global__ __launch_bounds__(256) void sum_stage1(const float* __restrict__ v, long long count, float* __restrict__ partial) {
     __shared__ float sh[256];

@@ -221,6 +221,87 @@ class _ResShallow(_Network3D):
         return out
 
 
+################################################################################
+# Helpers for arithmetic coding (val.py --real_bpp), reference code/probclass.py:393-482
+################################################################################
+
+
+class ProbclassNetworkTesting(object):
+    """bit cost of a whole symbol volume, fully convolutionally (reference code/probclass.py:393-421)."""
+
+    def __init__(self, pc, ae, sess=None):
+        self.pc = pc
+        self.centers = ae.get_centers_variable()
+        self.pad_value = pc.auto_pad_value(ae)
+
+    def get_total_bit_cost(self, symbols):
+        """:param symbols: CHW or NCHW numpy / tensor of all symbols of an image -> total bits (float)."""
+        sym = symbols if torch.is_tensor(symbols) else torch.as_tensor(np.asarray(symbols))
+        if sym.dim() == 3:
+            sym = sym[None]
+        assert sym.dim() == 4
+        sym = sym.to(self.centers.device).long().contiguous()
+        q = self.centers[sym]                                    # tf.gather(centers, symbols)
+        bc = self.pc.bitcost(q, sym, is_training=False, pad_value=self.pad_value)
+        return float(bc.double().sum())
+
+
+class PredictionNetwork(object):
+    """Frequency tables for the arithmetic coder (reference code/probclass.py:425-482).
+
+    get_pr / get_freqs keep the reference's one-context-at-a-time interface (the decoder needs it: a symbol's
+    table depends on the symbols decoded before it).  get_all(...) is the parallel path the README asks for
+    (README.md:71): ONE pass of the context model yields the tables of every position, and because the kernels
+    evaluate a fixed, position-independent fp32 expression per logit, both paths give bit-identical tables."""
+
+    def __init__(self, pc, config, centers, sess=None, freqs_resolution=1e9):
+        self.pc = pc
+        self.pc_class = pc.__class__
+        self.config = config
+        self.centers = centers
+        self.input_ctx_shape = self.pc_class.get_context_shape(config)
+        self.freqs_resolution = float(freqs_resolution)
+
+    def pad_symbols_volume(self, symbols):
+        assert symbols.ndim == 3
+        return pad_for_probclass3d(symbols, self.pc_class.get_context_size(self.config))
+
+    def undo_pad_symbols_volume(self, symbols):
+        assert symbols.ndim == 3
+        return undo_pad_for_probclass3d(symbols, self.pc_class.get_context_size(self.config))
+
+    def _tables(self, vol_padded):
+        """vol_padded: (D,H,W) int symbols (already padded) -> (pr, freqs) for every context, raster C,H,W."""
+        dev = self.centers.device
+        sym = torch.as_tensor(np.ascontiguousarray(vol_padded)).to(dev).long()
+        q = self.centers[sym][None].contiguous()                       # gather -> (1,D,H,W) float
+        logits = self.pc.logits(q, is_training=False)                  # (1,D-4,H-8,W-8,L)
+        n = logits.numel() // self.pc.L
+        freqs = torch.empty((n, self.pc.L), dtype=torch.int64, device=dev)
+        pr = torch.empty((n, self.pc.L), dtype=torch.float32, device=dev)
+        check(lib.ic_pc_logits_to_freqs_f32(ptr(logits), n, self.pc.L, self.freqs_resolution, ptr(freqs), ptr(pr),
+                                            _lib.current_stream(dev)), 'ic_pc_logits_to_freqs_f32')
+        return pr.cpu().numpy(), freqs.cpu().numpy()
+
+    def get_all(self, symbols_padded):
+        """(pr, freqs), each (num_contexts, L), contexts in the order of iter_over_blocks."""
+        return self._tables(symbols_padded)
+
+    def get_pr(self, input_ctx):
+        """:param input_ctx: symbols of ONE context, CHW = input_ctx_shape -> (L,) float32."""
+        assert tuple(input_ctx.shape) == tuple(self.input_ctx_shape), '{} != {}'.format(
+            input_ctx.shape, self.input_ctx_shape)
+        return self._tables(input_ctx)[0][0]
+
+    def get_freqs(self, input_ctx):
+        """:param input_ctx: symbols of ONE context, CHW -> (L,) int64, all > 0."""
+        assert tuple(input_ctx.shape) == tuple(self.input_ctx_shape), '{} != {}'.format(
+            input_ctx.shape, self.input_ctx_shape)
+        f = self._tables(input_ctx)[1][0]
+        assert np.all(f > 0), 'We do not want zero frequencies!: {}'.format(f)
+        return f
+
+
 # -- host-side helpers of the reference's NumPy branch (reference code/probclass.py:268-292,341-351,367-387) --
 
 def pad_for_probclass3d(x, context_size, pad_value=0, learn_pad_var=False):

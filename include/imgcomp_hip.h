@@ -145,6 +145,11 @@ int ic_pc_logits_padded_f32(const float* vol, const float* const* wtab_host, int
 int ic_pc_bitcost_f32(const float* q, const int64_t* symbols, const float* const* wtab_host, int k, int L,
                       float pad_value, float* logits, float* bits, int N, int C, int h, int w,
                       void* workspace, size_t workspace_bytes, ic_stream_t stream);
+/* logits (count, L) -> freqs (count, L) int64 = max(int64(softmax(logits) * resolution), 1) and optionally the
+ * probabilities pr (count, L): PredictionNetwork.freqs / get_freqs (probclass.py:443-444, :465-476).  The row
+ * expression is fixed, so tables built from all-position logits equal tables built context by context. */
+int ic_pc_logits_to_freqs_f32(const float* logits, long long count, int L, float resolution,
+                              int64_t* freqs, float* pr, ic_stream_t stream);
 /* bits -> sum(bits) (bits.py:4-14 numerator); deterministic two-stage reduction.
  * partial: >= 1024 floats of scratch.  out_sum: 1 float. */
 int ic_sum_f32(const float* v, long long count, float* partial, float* out_sum, ic_stream_t stream);

@@ -80,6 +80,56 @@ def test_psnr():
     assert float(metrics.psnr_uint8(a, b)) == pytest.approx(10 * np.log10(255 ** 2 / mse), rel=1e-6)
 
 
+# ---- arithmetic coder vs a stream produced by the reference's coder ---------------------------------------------
+
+class _KeepOpen(__import__('io').BytesIO):
+    def close(self):
+        pass
+
+
+def test_arithmetic_coder_reproduces_reference_stream():
+    import io
+    from imgcomp_cvpr_amd import arithmetic_coding as ac
+    g = np.load(os.path.join(GOLD, 'arithcoding.npz'))
+    buf = _KeepOpen()
+    out = ac.CountingBitOutputStream(ac.BitOutputStream(buf))
+    enc = ac.ArithmeticEncoder(out)
+    for s, f in zip(g['symbols'], g['freqs']):
+        enc.write(ac.SimpleFrequencyTable(f), int(s))
+    enc.finish()
+    out.close()
+    assert buf.getvalue() == g['stream'].tobytes(), 'bit stream differs from the reference coder'
+    assert out.num_bits == 8 * len(g['stream'])
+    buf2 = _KeepOpen()
+    assert ac.encode_sequence(g['symbols'], g['freqs'], buf2) == 8 * len(g['stream'])
+    assert buf2.getvalue() == g['stream'].tobytes()
+    dec = ac.ArithmeticDecoder(ac.BitInputStream(io.BytesIO(g['stream'].tobytes())))
+    assert [dec.read(ac.SimpleFrequencyTable(f)) for f in g['freqs']] == g['symbols'].tolist()
+
+
+def test_arithmetic_coder_edge_cases():
+    import io
+    from imgcomp_cvpr_amd import arithmetic_coding as ac
+    rs = np.random.RandomState(3)
+    # skewed tables at the reference's resolution (int(p * 1e9), floor 1), incl. near-deterministic rows
+    p = rs.dirichlet([0.05] * 6, size=500)
+    freqs = np.maximum((p * 1e9).astype(np.int64), 1)
+    assert freqs.sum(1).max() <= ac.MAX_TOTAL                    # 1e9 + 6 <= 2^30 + 2 (probclass.py:474-475)
+    syms = np.array([rs.choice(6, p=r) for r in p])
+    buf = _KeepOpen()
+    ac.encode_sequence(syms, freqs, buf)
+    dec = ac.ArithmeticDecoder(ac.BitInputStream(io.BytesIO(buf.getvalue())))
+    assert [dec.read(ac.SimpleFrequencyTable(f)) for f in freqs] == syms.tolist()
+    with pytest.raises(ValueError):
+        ac.ArithmeticEncoder(ac.BitOutputStream(_KeepOpen())).write(ac.SimpleFrequencyTable([2 ** 30, 2 ** 30]), 0)
+    with pytest.raises(ValueError):
+        ac.ArithmeticEncoder(ac.BitOutputStream(_KeepOpen())).write(ac.SimpleFrequencyTable([0, 5]), 0)
+    with pytest.raises(ValueError):
+        ac.SimpleFrequencyTable([])
+    with pytest.raises(ValueError):
+        ac.BitOutputStream(_KeepOpen()).write(2)
+
+
 # ---- NumPy helpers of the plugin module vs the reference's outputs --------------------------------------
 
 def test_probclass_numpy_helpers_match_reference():
