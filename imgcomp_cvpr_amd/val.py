@@ -1,0 +1,298 @@
+"""Inference driver -- the val.py entry point of the reference (code/val.py) on the MI355X hot path.
+
+    python -m imgcomp_cvpr_amd.val LOG_DIR_ROOT JOB_IDS IMAGES [--save_ours] [--how_many N] [--real_bpp]
+                                   [--weights synthetic|FILE.npz] [--reset]
+
+Per image (batch 1, as val.py:157-158): encode -> decode(qhard) -> bitcost(qbar, symbols, pad=centers[0]) -> bpp;
+output truncated to uint8; MS-SSIM (float64 numpy, metrics.py) and PSNR on the host; `measures.csv`
+(`img_name,bpp,ms-ssim,psnr`) in `LOG_DIR_ROOT/{log_date} {dataset}` like val_files.py:62-77; with --real_bpp the
+arithmetic-coded size is measured too and |bpp_theory - bpp_loss| < 1e-3 is asserted (val.py:163-174).
+
+Job directories are named as the reference names them, `MMDD_HHMM ae_configs@cvpr@low pc_configs@cvpr@res_shallow`
+(logdir_helpers.py:34-56); the configs are recovered from the name (logdir_helpers.py:130-151) and resolved against
+$CONFIG_BASE_AE / $CONFIG_BASE_PC or this package's config trees.  Weights: `JOB_DIR/ckpts/weights.npz` (variable
+names and layouts of the TF checkpoint) or `--weights synthetic`.  Reading the TF-1 tensor
+bundle itself (`ckpt-*.index/.data`) is row N1 of the plan and not built yet.
+
+Under torch.distributed.run (one process per GPU) the image list is sharded round-robin over the ranks; rank 0
+writes the merged measures.
+"""
+import argparse
+import glob
+import os
+import re
+import sys
+from collections import defaultdict, namedtuple
+from datetime import datetime
+from os import path
+
+import numpy as np
+import torch
+
+from . import autoencoder, bits, bpp_helpers, config_parser, metrics, probclass, sharding
+from . import weights as _weights
+
+OutputFlags = namedtuple('OutputFlags', ['save_ours', 'ckpt_step', 'real_bpp'])
+_LOG_DATE_FORMAT = '%m%d_%H%M'
+_MEASURES_FILE_NAME = 'measures.csv'
+
+
+# ---- images (reference code/images_iterator.py, code/val_images.py) -------------------------------------------
+
+def add_padding(im, pad):
+    """HWC uint8 -> zero-padded (centred, extra pixel at the far side) to multiples of `pad`
+    (images_iterator.py:39-59).  Returns (padded, undo_fn)."""
+    h, w, chan = im.shape
+    if chan == 4:
+        return add_padding(im[:, :, :3], pad)
+    if h % pad == 0 and w % pad == 0:
+        return im, lambda x: x
+    hp, wp = (-h) % pad, (-w) % pad
+    t, l = hp // 2, wp // 2
+    padded = np.pad(im, [[t, hp - t], [l, wp - l], [0, 0]], mode='constant')
+    return padded, lambda x: x[t:t + h, l:l + w, :]
+
+
+def get_image_paths(images):
+    """directory with PNGs, or a glob -> (sorted paths, dataset name)  (val_images.py:12-46)."""
+    if '*' not in images:
+        images = path.join(images, '*.png')
+    paths = sorted(glob.glob(images))
+    if not paths:
+        raise ValueError('Not matching any files: {}'.format(images))
+    for comp in reversed(images.strip(path.sep).split(path.sep)):
+        if '*' not in comp:
+            return paths, comp
+    raise ValueError('No component without *: {}'.format(images))
+
+
+def load_image_chw(p, pad):
+    from PIL import Image
+    im = np.asarray(Image.open(p).convert('RGB'), dtype=np.uint8)
+    im, _ = add_padding(im, pad)
+    return np.ascontiguousarray(np.transpose(im, (2, 0, 1)))
+
+
+# ---- log-dir conventions (reference code/logdir_helpers.py) -----------------------------------------------------
+
+def is_log_date(s):
+    try:
+        datetime.strptime(s, _LOG_DATE_FORMAT)
+        return True
+    except ValueError:
+        return False
+
+
+def log_date_from_log_dir(log_dir):
+    d = path.basename(log_dir.rstrip(path.sep)).split(' ')[0]
+    if not is_log_date(d):
+        raise ValueError('Invalid log dir: {}'.format(log_dir))
+    return d
+
+
+def config_paths_from_log_dir(log_dir, base_dirs):
+    """`{date} {ae cfg with / -> @} {pc cfg}` -> real config paths; a `*` in a component is a one-character
+    wildcard (the reference replaces `-`), matched against files of the same length (logdir_helpers.py:130-151)."""
+    comps = path.basename(log_dir.rstrip(path.sep)).split(' ')
+    assert is_log_date(comps[0]), 'Invalid log_dir: {}'.format(log_dir)
+    comps = [c for c in comps[1:] if 'RESTORE@' not in c]
+    assert len(comps) <= len(base_dirs)
+    out = []
+    for base, c in zip(base_dirs, comps):
+        rel = c.replace('@', path.sep)
+        # the component may or may not repeat the name of the base dir (ae_configs/cvpr/low vs cvpr/low)
+        cands = [path.join(base, rel), path.join(path.dirname(base.rstrip(path.sep)), rel)]
+        hits = []
+        for cand in cands:
+            hits = [g for g in glob.glob(cand) if len(g) == len(cand) and path.isfile(g)]
+            if len(hits) == 1:
+                break
+        if len(hits) != 1:
+            raise ValueError('Cannot find config on disk: {} (matches: {})'.format(cands, hits))
+        out.append(hits[0])
+    return out
+
+
+def iter_job_dirs(log_dir_root, job_ids_str):
+    for job_id in job_ids_str.strip().replace(';', ',').split(','):
+        m = [d for d in glob.glob(path.join(log_dir_root, job_id + '*')) if path.isdir(d) and
+             len(path.basename(d).split(' ')) >= 3]
+        if len(m) != 1:
+            print('*** ERR: {} matches for job {}'.format(len(m), job_id))
+            continue
+        yield m[0]
+
+
+class MeasuresWriter(object):
+    def __init__(self, out_dir):
+        os.makedirs(out_dir, exist_ok=True)
+        self.fout = open(path.join(out_dir, _MEASURES_FILE_NAME), 'w')
+        self.fout.write('img_name,bpp,ms-ssim,psnr\n')
+
+    def append(self, img_name, otp):
+        self.fout.write('{},{},{},{}\n'.format(img_name, otp['bpp'], otp['ms-ssim'], otp['psnr']))
+
+    def close(self):
+        self.fout.close()
+
+
+class ValuesAggregator(object):
+    def __init__(self, *tags):
+        self._vals = defaultdict(list)
+        self.tags = tags
+
+    def update(self, d):
+        for t in self.tags:
+            assert not np.isnan(d[t]), 'nan encountered in {}'.format(d)
+            self._vals[t].append(d[t])
+
+    def averages(self):
+        return {t: float(np.mean(v)) for t, v in self._vals.items()}
+
+    def averages_str(self):
+        a = self.averages()
+        return ', '.join('{}: {:.3f}'.format(t, a[t]) for t in self.tags)
+
+
+# ---- the per-image fetch (val.py:81-94) -------------------------------------------------------------------------
+
+class Fetcher(object):
+    """builds the networks once, then maps one padded uint8 CHW image to its measures."""
+
+    def __init__(self, ae_config, pc_config, weights, device):
+        self.device = torch.device(device)
+        self.ae = autoencoder.get_network_cls(ae_config)(ae_config).load_weights(weights, self.device)
+        self.pc = probclass.get_network_cls(pc_config)(pc_config, num_centers=ae_config.num_centers).load_weights(
+            weights, self.device)
+        self.pc_config = pc_config
+        self._bpp_fetcher = None
+
+    def __call__(self, img_chw_uint8, want_symbols=False, want_image=False):
+        x_uint8 = torch.as_tensor(img_chw_uint8)[None]
+        x = x_uint8.to(self.device).float()
+        enc = self.ae.encode(x, is_training=False)
+        x_out = self.ae.decode(enc.qhard, is_training=False)
+        bc = self.pc.bitcost(enc.qbar, enc.symbols, is_training=False, pad_value=self.pc.auto_pad_value(self.ae))
+        bpp = bits.bitcost_to_bpp(bc, x)
+        x_out_uint8 = x_out.to(torch.uint8).cpu().numpy()          # tf.cast truncates (val.py:91)
+        otp = {'bpp': float(bpp),
+               'ms-ssim': float(metrics.msssim_nchw_uint8(x_uint8.numpy(), x_out_uint8)),
+               'psnr': float(metrics.psnr_uint8(x_uint8.numpy(), x_out_uint8))}
+        if want_symbols:
+            otp['sym'] = enc.symbols.cpu().numpy()
+        if want_image:
+            otp['img_out'] = x_out_uint8
+        return otp
+
+    def real_bpp(self, symbols, num_pixels):
+        if self._bpp_fetcher is None:
+            pred = probclass.PredictionNetwork(self.pc, self.pc_config, self.ae.get_centers_variable())
+            checker = probclass.ProbclassNetworkTesting(self.pc, self.ae)
+            self._bpp_fetcher = bpp_helpers.BppFetcher(pred, checker)
+        return self._bpp_fetcher.get_bpp(symbols, num_pixels)
+
+
+def validate(ae_config, pc_config, weights, image_paths, out_dir, flags, device='cuda', verbose=True):
+    """-> dict of averages; writes out_dir/measures.csv (rank 0)."""
+    rank, world = sharding.rank_and_world()
+    fetcher = Fetcher(ae_config, pc_config, weights, device)
+    pad = fetcher.ae.get_subsampling_factor()
+    local = []
+    for idx in sharding.shard_indices(len(image_paths), rank, world):
+        p = image_paths[idx]
+        img = load_image_chw(p, pad)
+        otp = fetcher(img, want_symbols=flags.real_bpp, want_image=flags.save_ours)
+        if flags.real_bpp:
+            bpp_real, bpp_theory = fetcher.real_bpp(otp.pop('sym'), bpp_helpers.num_pixels_in_image(img))
+            otp['bpp_real'], otp['bpp_theory'] = bpp_real, bpp_theory
+            if verbose:
+                print('BPP: Real         {:.5f}\n     Theoretical: {:.5f} [{:5.1f}% of real]\n'
+                      '     Loss:        {:.5f} [{:5.1f}% of real]'.format(
+                          bpp_real, bpp_theory, bpp_theory / bpp_real * 100, otp['bpp'], otp['bpp'] / bpp_theory * 100))
+            assert abs(bpp_theory - otp['bpp']) < 1e-3, 'Expected bpp_theory to match loss! Got {} and {}'.format(
+                bpp_theory, otp['bpp'])
+        if flags.save_ours:
+            save_img(path.basename(p), otp.pop('img_out'), out_dir)
+        local.append((idx, (path.basename(p), otp)))
+    merged = sharding.gather_in_order(local, len(image_paths))
+    agg = ValuesAggregator('bpp', 'ms-ssim', 'psnr')
+    if rank == 0:
+        w = MeasuresWriter(out_dir)
+        for i, (name, otp) in enumerate(merged):
+            w.append(name, otp)
+            agg.update(otp)
+            if verbose:
+                print('{: 10d} {} | Mean: {}'.format(i, name, agg.averages_str()))
+        w.close()
+    else:
+        for _, otp in merged:
+            agg.update(otp)
+    return agg.averages()
+
+
+def save_img(img_name, img_out, out_dir):
+    from PIL import Image
+    assert img_out.ndim == 4 and img_out.shape[1] == 3, 'Expected NCHW, got {}'.format(img_out.shape)
+    d = path.join(out_dir, 'imgs')
+    os.makedirs(d, exist_ok=True)
+    Image.fromarray(np.transpose(img_out[0], (1, 2, 0))).save(path.join(d, img_name))
+
+
+def load_weights_for_job(job_dir, weights_arg, ae_config, pc_config):
+    if weights_arg == 'synthetic':
+        return _weights.synthetic_weights(ae_config, pc_config)
+    p = weights_arg or path.join(job_dir, 'ckpts', 'weights.npz')
+    if not path.isfile(p):
+        raise FileNotFoundError(
+            '{} not found.  Checkpoints of the reference are TF-1 tensor bundles (ckpt-*.index/.data); convert them '
+            'to an .npz keyed by variable name, or pass --weights synthetic.'.format(p))
+    with np.load(p) as z:
+        return {k[:-2] if k.endswith(':0') else k: z[k] for k in z.files}
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument('log_dir_root', help='Path to dir containing log_dirs.')
+    p.add_argument('job_ids', help='Comma separated list of job_ids.')
+    p.add_argument('images')
+    p.add_argument('--save_ours', '-o', action='store_const', const=True)
+    p.add_argument('--how_many', type=int, help='Number of images to output')
+    p.add_argument('--reset', action='store_const', const=True, help='Remove previous output')
+    p.add_argument('--real_bpp', action='store_const', const=True,
+                   help='If given, calculate real bpp using arithmetic encoding.')
+    p.add_argument('--weights', help="'synthetic' or an .npz of checkpoint variables (default JOB_DIR/ckpts/weights.npz)")
+    p.add_argument('--device', default=None)
+    flags, unknown = p.parse_known_args(argv)
+    if unknown:
+        print('Unknown flags: {}'.format(unknown))
+
+    if 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        import torch.distributed as dist
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    device = flags.device or 'cuda:{}'.format(torch.cuda.current_device())
+
+    image_paths, dataset_name = get_image_paths(flags.images)
+    image_paths = image_paths[:flags.how_many]
+    here = path.dirname(path.abspath(__file__))
+    bases = [os.environ.get('CONFIG_BASE_AE', path.join(here, 'ae_configs')),
+             os.environ.get('CONFIG_BASE_PC', path.join(here, 'pc_configs'))]
+    for job_dir in iter_job_dirs(flags.log_dir_root, flags.job_ids):
+        ae_p, pc_p = config_paths_from_log_dir(job_dir, bases)
+        ae_config, _ = config_parser.parse(ae_p)
+        pc_config, _ = config_parser.parse(pc_p)
+        weights = load_weights_for_job(job_dir, flags.weights, ae_config, pc_config)
+        out_dir = path.join(flags.log_dir_root, '{} {}'.format(log_date_from_log_dir(job_dir), dataset_name))
+        if flags.reset and path.isdir(out_dir) and sharding.rank_and_world()[0] == 0:
+            import shutil
+            shutil.rmtree(out_dir)
+        avgs = validate(ae_config, pc_config, weights, image_paths, out_dir,
+                        OutputFlags(flags.save_ours, -1, flags.real_bpp), device)
+        if sharding.rank_and_world()[0] == 0:
+            print('Validation completed: {} | {}'.format(out_dir, avgs))
+    print('*** All given job_ids validated.')
+
+
+if __name__ == '__main__':
+    main()

@@ -257,3 +257,35 @@ def test_sharding_single_process():
         sharding.gather_in_order([(0, 'a')], 2)
     with pytest.raises(ValueError):
         sharding.shard_indices(3, 2, 2)
+
+
+# ---- val.py host logic -----------------------------------------------------------------------------------------
+
+def test_val_padding_and_paths(tmp_path):
+    from imgcomp_cvpr_amd import val
+    im = np.arange(5 * 13 * 3, dtype=np.uint8).reshape(5, 13, 3)
+    padded, undo = val.add_padding(im, 8)
+    assert padded.shape == (8, 16, 3)
+    # centred, the odd pixel goes to the far side (images_iterator.py:45-55): 3 rows -> 1 before / 2 after
+    assert np.array_equal(padded[1:6, 1:14], im) and padded[0].sum() == 0 and padded[6:].sum() == 0
+    assert np.array_equal(undo(padded), im)
+    same, _ = val.add_padding(np.zeros((16, 24, 3), np.uint8), 8)
+    assert same.shape == (16, 24, 3)
+    rgba, _ = val.add_padding(np.zeros((8, 8, 4), np.uint8), 8)
+    assert rgba.shape == (8, 8, 3)
+    # job dir name -> config files (logdir_helpers.py:130-151)
+    job = tmp_path / '0515_1103 ae_configs@cvpr@low pc_configs@cvpr@res_shallow'
+    job.mkdir()
+    here = os.path.join(ROOT, 'imgcomp_cvpr_amd')
+    ae_p, pc_p = val.config_paths_from_log_dir(str(job), [os.path.join(here, 'ae_configs'), os.path.join(here, 'pc_configs')])
+    assert ae_p.endswith('ae_configs/cvpr/low') and pc_p.endswith('pc_configs/cvpr/res_shallow')
+    assert val.log_date_from_log_dir(str(job)) == '0515_1103'
+    assert list(val.iter_job_dirs(str(tmp_path), '0515')) == [str(job)]
+    with pytest.raises(ValueError):
+        val.log_date_from_log_dir(str(tmp_path / 'nodate x y'))
+    with pytest.raises(ValueError):
+        val.get_image_paths(str(tmp_path / 'no_images'))
+    w = val.MeasuresWriter(str(tmp_path / 'out'))
+    w.append('a.png', {'bpp': 0.5, 'ms-ssim': 0.9, 'psnr': 30.0})
+    w.close()
+    assert (tmp_path / 'out' / 'measures.csv').read_text() == 'img_name,bpp,ms-ssim,psnr\na.png,0.5,0.9,30.0\n'

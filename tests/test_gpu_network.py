@@ -175,3 +175,25 @@ def test_blockwise_logits_bit_identical_to_full_volume(cuda, configs, syn_weight
         one = pc.logits(blk, False)
         assert one.shape == (1, 1, 1, 1, 6)
         assert torch.equal(one[0, 0, 0, 0], full[0, c, y, x])
+
+
+def test_val_entry_point(cuda, tmp_path):
+    """python -m imgcomp_cvpr_amd.val LOG_DIR_ROOT JOB_IDS IMAGES --real_bpp on synthetic PNGs of ragged size."""
+    from PIL import Image
+    from imgcomp_cvpr_amd import val, weights as W
+    imgs = tmp_path / 'kodakish'
+    imgs.mkdir()
+    for i, (h, w) in enumerate(((21, 30), (32, 24))):
+        im = W.synthetic_image((1, 3, h, w), 'natural', seed=i)[0].transpose(1, 2, 0)
+        Image.fromarray(im).save(str(imgs / 'img{:02d}.png'.format(i)))
+    root = tmp_path / 'logs'
+    (root / '0515_1103 ae_configs@cvpr@low pc_configs@cvpr@res_shallow').mkdir(parents=True)
+    val.main([str(root), '0515_1103', str(imgs), '--weights', 'synthetic', '--real_bpp', '--save_ours'])
+    out = root / '0515_1103 kodakish'
+    rows = (out / 'measures.csv').read_text().strip().split('\n')
+    assert rows[0] == 'img_name,bpp,ms-ssim,psnr' and len(rows) == 3
+    for r in rows[1:]:
+        name, bpp, msssim, psnr = r.split(',')
+        assert 0 < float(bpp) < 10 and 0 < float(msssim) <= 1 and float(psnr) > 0
+    saved = np.asarray(Image.open(str(out / 'imgs' / 'img00.png')))
+    assert saved.shape == (24, 32, 3)          # padded to the subsampling factor
