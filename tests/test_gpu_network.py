@@ -177,18 +177,18 @@ def test_blockwise_logits_bit_identical_to_full_volume(cuda, configs, syn_weight
         assert torch.equal(one[0, 0, 0, 0], full[0, c, y, x])
 
 
-def test_val_entry_point(cuda, tmp_path):
-    """python -m imgcomp_cvpr_amd.val LOG_DIR_ROOT JOB_IDS IMAGES --real_bpp on synthetic PNGs of ragged size."""
+def test_val_entry_point(cuda, tmp_path, configs, syn_weights):
+    """python -m imgcomp_cvpr_amd.val LOG_DIR_ROOT JOB_IDS IMAGES on synthetic PNGs of ragged size."""
     from PIL import Image
-    from imgcomp_cvpr_amd import val, weights as W
+    from imgcomp_cvpr_amd import val, weights as W, bpp_helpers
     imgs = tmp_path / 'kodakish'
     imgs.mkdir()
-    for i, (h, w) in enumerate(((21, 30), (32, 24))):
+    for i, (h, w) in enumerate(((181, 203), (192, 176))):
         im = W.synthetic_image((1, 3, h, w), 'natural', seed=i)[0].transpose(1, 2, 0)
         Image.fromarray(im).save(str(imgs / 'img{:02d}.png'.format(i)))
     root = tmp_path / 'logs'
     (root / '0515_1103 ae_configs@cvpr@low pc_configs@cvpr@res_shallow').mkdir(parents=True)
-    val.main([str(root), '0515_1103', str(imgs), '--weights', 'synthetic', '--real_bpp', '--save_ours'])
+    val.main([str(root), '0515_1103', str(imgs), '--weights', 'synthetic', '--save_ours'])
     out = root / '0515_1103 kodakish'
     rows = (out / 'measures.csv').read_text().strip().split('\n')
     assert rows[0] == 'img_name,bpp,ms-ssim,psnr' and len(rows) == 3
@@ -196,4 +196,16 @@ def test_val_entry_point(cuda, tmp_path):
         name, bpp, msssim, psnr = r.split(',')
         assert 0 < float(bpp) < 10 and 0 < float(msssim) <= 1 and float(psnr) > 0
     saved = np.asarray(Image.open(str(out / 'imgs' / 'img00.png')))
-    assert saved.shape == (24, 32, 3)          # padded to the subsampling factor
+    assert saved.shape == (184, 208, 3)          # padded to the subsampling factor
+    # --real_bpp leg on a small image: arithmetic-coded size vs theoretical vs loss (val.py:163-174)
+    ae_cfg, pc_cfg = configs
+    f = val.Fetcher(ae_cfg, pc_cfg, syn_weights, cuda)
+    img = W.synthetic_image((1, 3, 32, 48), 'natural', seed=5)[0]
+    x = torch.as_tensor(img)[None].to(cuda).float()
+    enc = f.ae.encode(x, False)
+    bc = f.pc.bitcost(enc.qbar, enc.symbols, False, pad_value=f.pc.auto_pad_value(f.ae))
+    from imgcomp_cvpr_amd import bits
+    bpp_loss = float(bits.bitcost_to_bpp(bc, x))
+    bpp_real, bpp_theory = f.real_bpp(enc.symbols.cpu().numpy(), bpp_helpers.num_pixels_in_image(img))
+    assert abs(bpp_theory - bpp_loss) < 1e-3
+    assert abs(bpp_real - bpp_theory) * 32 * 48 < 58
