@@ -52,6 +52,23 @@ PROTOTYPES = {
                          [c_int] * 3 + [c_void_p, c_size_t, c_void_p]),
     'ic_ae_decode_f32': (c_int, [c_void_p, POINTER(c_void_p)] + [c_int] * 3 + [c_void_p] +
                          [c_int] * 3 + [c_void_p, c_size_t, c_void_p]),
+    'ic_bn_workspace_bytes': (c_size_t, [c_int]),
+    'ic_bn_stats_f32': (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p, c_void_p]),
+    'ic_bn_apply_f32': (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
+    'ic_bn_backward_f32': (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p, c_void_p]),
+    'ic_conv2d_wgrad_workspace_bytes': (c_size_t, [c_int] * 7),
+    'ic_conv2d_wgrad_f32': (c_int, [c_void_p] * 3 + [c_int] * 8 + [c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
+    'ic_pack_conv3x3_c128_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'ic_heatmap_quantize_bwd_workspace_bytes': (c_size_t, [c_int]),
+    'ic_heatmap_quantize_bwd_f32': (c_int, [c_void_p, c_void_p, c_int, c_float] + [c_void_p] * 4 + [c_int] * 5 +
+                                    [c_void_p, c_void_p]),
+    'ic_pc_dlogits_f32': (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),
+    'ic_pc_bwd_data_f32': (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
+    'ic_pc_wgrad_workspace_bytes': (c_size_t, [c_int] * 6),
+    'ic_pc_wgrad_f32': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p] + [c_int] * 7 +
+                        [c_void_p, c_size_t, c_void_p]),
+    'ic_channel_sum_workspace_bytes': (c_size_t, [c_int]),
+    'ic_channel_sum_f32': (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p, c_void_p]),
     'ic_event_create': (c_int, [POINTER(c_void_p)]),
     'ic_event_destroy': (c_int, [c_void_p]),
     'ic_event_record': (c_int, [c_void_p, c_void_p]),

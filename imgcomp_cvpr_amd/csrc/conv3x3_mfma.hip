@@ -72,6 +72,19 @@ __global__ void pack_conv3x3_c128_kernel(const float* __restrict__ w, float* __r
     out[idx] = w[(t * C128 + ci) * C128 + co];
 }
 
+// backward-data filter: dx = conv3x3(dy, W') with W'[t'][co][ci] = W[8 - t'][ci][co] (taps mirrored, channels swapped)
+// packed[(((c*9 + t)*4 + n)*64 + l)*4 + j] = w_tf[8 - t][ci = 32n + (l&31)][co = 8c + 2j + (l>>5)]
+__global__ void pack_conv3x3_c128_bwd_kernel(const float* __restrict__ w, float* __restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= PACKED_FLOATS) return;
+    const int j = idx & 3, l = (idx >> 2) & 63, n = (idx >> 8) & 3;
+    const int ct = idx >> 10;
+    const int t = ct % 9, c = ct / 9;
+    const int k_in = KC * c + 2 * j + (l >> 5);      // reduction channel of the backward conv = forward OUTPUT channel
+    const int m_out = 32 * n + (l & 31);             // produced channel = forward INPUT channel
+    out[idx] = w[((8 - t) * C128 + m_out) * C128 + k_in];
+}
+
 // ------------------------------------------------------------------------------------------------
 // shared pieces
 // ------------------------------------------------------------------------------------------------
@@ -440,6 +453,14 @@ static int pick_variant(int N, int H, int W) {
 }
 
 extern "C" size_t ic_conv3x3_c128_packed_floats(void) { return PACKED_FLOATS; }
+
+extern "C" int ic_pack_conv3x3_c128_bwd_f32(const float* w_tf, float* w_packed, ic_stream_t stream) {
+    IC_CHECK_ARG(w_tf && w_packed);
+    hipLaunchKernelGGL(pack_conv3x3_c128_bwd_kernel, dim3(PACKED_FLOATS / 256), dim3(256), 0, (hipStream_t)stream,
+                       w_tf, w_packed);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
 
 extern "C" int ic_pack_conv3x3_c128_f32(const float* w_tf, float* w_packed, ic_stream_t stream) {
     IC_CHECK_ARG(w_tf && w_packed);

@@ -1,0 +1,260 @@
+// Training-mode BatchNorm around the autoencoder convs, and the backward of the importance map + quantiser.
+//   reference: code/autoencoder.py:106-125 (slim.batch_norm, is_training=True: batch statistics over (N,H,W), biased
+//   variance, eps 1e-5, decay 0.9), :127-134 (_quantize, qbar = qsoft + stop_gradient(qhard - qsoft)),
+//   :171-200 (heatmap), code/quantizer.py:43-100.
+// All of it is HBM streaming: every kernel reads/writes each activation once, per-channel sums are reduced in
+// float64 in a fixed two-stage order (deterministic, no atomics).
+//
+// forward :  raw = conv(x)                      (conv kernels with scale = 1, shift = 0)
+//            mean, var = ic_bn_stats_f32(raw)   -> host folds scale = gamma / sqrt(var + eps), shift = beta - mean * scale
+//            y = ic_bn_apply_f32(raw, scale, shift, relu, res1, res2)
+// backward:  g = dy * [raw * scale + shift > 0]  (ReLU mask recomputed, the residual adds pass dy through unchanged)
+//            ic_bn_bwd_reduce_f32 -> sum_g, sum_gxhat per channel  (= dbeta, dgamma)
+//            ic_bn_bwd_apply_f32  -> draw = gamma * invstd * (g - sum_g / M - xhat * sum_gxhat / M)
+#include "common.h"
+
+#define BN_CHUNKS 64      // stage-1 slices per channel
+
+struct BnArgs {
+    const float* x; const float* dy; const float* scale; const float* shift;
+    const float* mean; const float* invstd; const float* gamma;
+    const double* sums;       // [2][C] stage-2 results (sum_g, sum_gxhat)
+    double* partial;          // [C][BN_CHUNKS][2]
+    float* out0; float* out1; // stats: mean, var ; bwd_apply: dx
+    int N, C, HW, relu;
+};
+
+__device__ __forceinline__ void block_reduce2(double& a, double& b) {
+    __shared__ double sa[256], sb[256];
+    sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sa[threadIdx.x] += sa[threadIdx.x + o]; sb[threadIdx.x] += sb[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    a = sa[0]; b = sb[0];
+}
+
+// MODE 0: (sum x, sum x^2)   MODE 1: (sum g, sum g * xhat)
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_stage1(const BnArgs a) {
+    const int c = blockIdx.x, chunk = blockIdx.y;
+    const long long M = (long long)a.N * a.HW;
+    const long long per = (M + BN_CHUNKS - 1) / BN_CHUNKS;
+    const long long lo = per * chunk, hi = lo + per < M ? lo + per : M;
+    float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
+    if (MODE == 1) { sc = a.scale[c]; sh = a.shift[c]; mu = a.mean[c]; is = a.invstd[c]; }
+    double s0 = 0.0, s1 = 0.0;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        const long long n = i / a.HW, p = i - n * a.HW;
+        const size_t o = ((size_t)n * a.C + c) * a.HW + p;
+        const float xv = a.x[o];
+        if (MODE == 0) { s0 += xv; s1 += (double)xv * xv; }
+        else {
+            float g = a.dy[o];
+            if (a.relu && !(fmaf(xv, sc, sh) > 0.f)) g = 0.f;
+            s0 += g; s1 += (double)g * ((xv - mu) * is);
+        }
+    }
+    block_reduce2(s0, s1);
+    if (threadIdx.x == 0) { a.partial[((size_t)c * BN_CHUNKS + chunk) * 2] = s0; a.partial[((size_t)c * BN_CHUNKS + chunk) * 2 + 1] = s1; }
+}
+
+template <int MODE>
+__global__ void bn_reduce_stage2(const double* __restrict__ partial, int C, long long M, float* __restrict__ o0,
+                                 float* __restrict__ o1, double* __restrict__ sums) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < BN_CHUNKS; ++k) { s0 += partial[((size_t)c * BN_CHUNKS + k) * 2]; s1 += partial[((size_t)c * BN_CHUNKS + k) * 2 + 1]; }
+    if (MODE == 0) {
+        const double m = s0 / (double)M;
+        double v = s1 / (double)M - m * m;        // biased variance (what BN normalises with)
+        if (v < 0.0) v = 0.0;
+        o0[c] = (float)m; o1[c] = (float)v;
+    } else {
+        sums[c] = s0; sums[C + c] = s1;
+        if (o0) o0[c] = (float)s0;                 // dbeta
+        if (o1) o1[c] = (float)s1;                 // dgamma
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ res1,
+                                                       const float* __restrict__ res2, float* __restrict__ y,
+                                                       int C, int HW, long long total, int relu) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)((i / HW) % C);
+        float v = fmaf(x[i], scale[c], shift[c]);
+        if (relu) v = fmaxf(v, 0.f);
+        if (res1) v += res1[i];
+        if (res2) v += res2[i];
+        y[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs a, long long total) {
+    const double M = (double)a.N * a.HW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)((i / a.HW) % a.C);
+        const float xv = a.x[i];
+        float g = a.dy[i];
+        if (a.relu && !(fmaf(xv, a.scale[c], a.shift[c]) > 0.f)) g = 0.f;
+        const float xhat = (xv - a.mean[c]) * a.invstd[c];
+        const float mg = (float)(a.sums[c] / M), mgx = (float)(a.sums[a.C + c] / M);
+        a.out0[i] = a.gamma[c] * a.invstd[c] * (g - mg - xhat * mgx);
+    }
+}
+
+static int ew_grid(long long total) {
+    long long g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+extern "C" size_t ic_bn_workspace_bytes(int C) { return C > 0 ? ((size_t)C * BN_CHUNKS * 2 + 2 * (size_t)C) * sizeof(double) : 0; }
+
+extern "C" int ic_bn_stats_f32(const float* x, float* mean, float* var, int N, int C, int HW, void* workspace,
+                               ic_stream_t stream) {
+    IC_CHECK_ARG(x && mean && var && workspace && N > 0 && C > 0 && HW > 0);
+    BnArgs a{};
+    a.x = x; a.N = N; a.C = C; a.HW = HW; a.partial = (double*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_reduce_stage1<0>, dim3(C, BN_CHUNKS), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(bn_reduce_stage2<0>, dim3(ic_cdiv(C, 64)), dim3(64), 0, st, a.partial, C, (long long)N * HW, mean, var,
+                       (double*)nullptr);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
+extern "C" int ic_bn_apply_f32(const float* x, const float* scale, const float* shift, const float* res1,
+                               const float* res2, float* y, int N, int C, int HW, int relu, ic_stream_t stream) {
+    IC_CHECK_ARG(x && scale && shift && y && N > 0 && C > 0 && HW > 0);
+    const long long total = (long long)N * C * HW;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, res1, res2,
+                       y, C, HW, total, relu);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
+extern "C" int ic_bn_backward_f32(const float* dy, const float* x, const float* scale, const float* shift,
+                                  const float* mean, const float* invstd, const float* gamma, float* dx,
+                                  float* dgamma, float* dbeta, int N, int C, int HW, int relu, void* workspace,
+                                  ic_stream_t stream) {
+    IC_CHECK_ARG(dy && x && scale && shift && mean && invstd && gamma && dx && workspace && N > 0 && C > 0 && HW > 0);
+    BnArgs a{};
+    a.x = x; a.dy = dy; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.gamma = gamma;
+    a.N = N; a.C = C; a.HW = HW; a.relu = relu;
+    a.partial = (double*)workspace;
+    double* sums = a.partial + (size_t)C * BN_CHUNKS * 2;
+    a.sums = sums; a.out0 = dx;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_reduce_stage1<1>, dim3(C, BN_CHUNKS), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(bn_reduce_stage2<1>, dim3(ic_cdiv(C, 64)), dim3(64), 0, st, a.partial, C, (long long)N * HW, dbeta,
+                       dgamma, sums);
+    const long long total = (long long)N * C * HW;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, a, total);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// importance map + quantiser backward.  One lane = one pixel (n, p), looping over the C channels, so the
+// gradient of the shared heatmap channel z0 is a plain in-lane sum (no atomics).
+//   in : bottleneck (N,C+1,h,w), centers (L), d_qbar (N,C,h,w), d_heatmap (N,C,h,w) or null
+//   out: d_bottleneck (N,C+1,h,w), d_centers partial sums [gridDim.x][L] -> ic_... stage 2 sums them in order
+// ------------------------------------------------------------------------------------------------
+#define Q_MAX_L 16
+__global__ __launch_bounds__(256) void heatmap_quantize_bwd_kernel(
+        const float* __restrict__ bn, const float* __restrict__ centers, int L, float sigma,
+        const float* __restrict__ d_qbar, const float* __restrict__ d_heatmap, float* __restrict__ d_bn,
+        double* __restrict__ dc_partial, int N, int C, int hw, int heatmap_on) {
+    float c[Q_MAX_L];
+#pragma unroll
+    for (int j = 0; j < Q_MAX_L; ++j) c[j] = j < L ? centers[j] : 0.f;
+    double dc[Q_MAX_L];
+#pragma unroll
+    for (int j = 0; j < Q_MAX_L; ++j) dc[j] = 0.0;
+    const long long npix = (long long)N * hw;
+    const int CB = C + (heatmap_on ? 1 : 0);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+        const long long n = i / hw;
+        const int p = (int)(i - n * hw);
+        const float* b = bn + n * (long long)CB * hw;
+        float* db = d_bn + n * (long long)CB * hw;
+        float z0 = 0.f, sg = 1.f;
+        if (heatmap_on) { z0 = b[p]; sg = 1.0f / (1.0f + expf(-z0)); }
+        float dz0 = 0.f;
+        for (int ch = 0; ch < C; ++ch) {
+            const size_t e = ((size_t)n * C + ch) * hw + p;
+            const float zc = b[(size_t)(ch + (heatmap_on ? 1 : 0)) * hw + p];
+            float m = 1.f, u = 0.5f;
+            if (heatmap_on) { u = sg * (float)C - (float)ch; m = fmaxf(fminf(u, 1.0f), 0.0f); }
+            const float z = m * zc;
+            // phi = softmax(-sigma d), qsoft = sum phi c
+            float lmax = -INFINITY;
+            float d[Q_MAX_L];
+#pragma unroll
+            for (int j = 0; j < Q_MAX_L; ++j) if (j < L) { const float t = z - c[j]; d[j] = t * t; lmax = fmaxf(lmax, -sigma * d[j]); }
+            float den = 0.f, phi[Q_MAX_L];
+#pragma unroll
+            for (int j = 0; j < Q_MAX_L; ++j) if (j < L) { phi[j] = expf(-sigma * d[j] - lmax); den += phi[j]; }
+            float qs = 0.f, mz = 0.f;                 // qsoft, sum_k phi_k (z - c_k)
+#pragma unroll
+            for (int j = 0; j < Q_MAX_L; ++j) if (j < L) { phi[j] /= den; qs += phi[j] * c[j]; mz += phi[j] * (z - c[j]); }
+            const float gq = d_qbar[e];
+            float dq_dz = 0.f;
+#pragma unroll
+            for (int j = 0; j < Q_MAX_L; ++j) if (j < L) {
+                dq_dz += c[j] * phi[j] * (-2.f * sigma) * ((z - c[j]) - mz);
+                dc[j] += (double)gq * (phi[j] + 2.f * sigma * (z - c[j]) * phi[j] * (c[j] - qs));
+            }
+            const float dz = gq * dq_dz;
+            db[(size_t)(ch + (heatmap_on ? 1 : 0)) * hw + p] = dz * m;
+            if (heatmap_on) {
+                const float dm = dz * zc + (d_heatmap ? d_heatmap[e] : 0.f);
+                if (u >= 0.f && u <= 1.f) dz0 += dm;          // clip passes the gradient inside [0, 1]
+            }
+        }
+        if (heatmap_on) db[p] = dz0 * (float)C * sg * (1.f - sg);
+    }
+    // block reduction of the centre gradients
+    __shared__ double sh[256];
+    for (int j = 0; j < L; ++j) {
+        sh[threadIdx.x] = dc[j];
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) dc_partial[(size_t)blockIdx.x * L + j] = sh[0];
+        __syncthreads();
+    }
+}
+
+__global__ void dcenters_stage2(const double* __restrict__ partial, int nblocks, int L, float* __restrict__ out) {
+    const int j = threadIdx.x;
+    if (j >= L) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * L + j];
+    out[j] = (float)s;
+}
+
+#define QB_BLOCKS 512
+extern "C" size_t ic_heatmap_quantize_bwd_workspace_bytes(int L) { return (size_t)QB_BLOCKS * (L > 0 ? L : 0) * sizeof(double); }
+
+extern "C" int ic_heatmap_quantize_bwd_f32(const float* bottleneck, const float* centers, int L, float sigma,
+                                           const float* d_qbar, const float* d_heatmap, float* d_bottleneck,
+                                           float* d_centers, int N, int C, int h, int w, int heatmap_on,
+                                           void* workspace, ic_stream_t stream) {
+    IC_CHECK_ARG(bottleneck && centers && d_qbar && d_bottleneck && d_centers && workspace && N > 0 && C > 0 && h > 0 && w > 0);
+    if (L < 1 || L > Q_MAX_L) return IC_ERR_UNSUPPORTED;
+    const long long npix = (long long)N * h * w;
+    long long g = (npix + 255) / 256;
+    const int blocks = (int)(g > QB_BLOCKS ? QB_BLOCKS : g);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(heatmap_quantize_bwd_kernel, dim3(blocks), dim3(256), 0, st, bottleneck, centers, L, sigma, d_qbar,
+                       d_heatmap, d_bottleneck, (double*)workspace, N, C, h * w, heatmap_on);
+    hipLaunchKernelGGL(dcenters_stage2, dim3(1), dim3(64), 0, st, (const double*)workspace, blocks, L, d_centers);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}

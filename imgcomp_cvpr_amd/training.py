@@ -1,0 +1,503 @@
+"""One training step of the reference's graph on the MI355X kernels (forward in training mode + backward).
+
+Mirrors code/train.py:101-106 (wiring), :303-336 (get_loss), :339-349 (two Adam optimisers), :352-394
+(Distortions) and the is_training=True branches of code/autoencoder.py / code/probclass.py:
+
+    enc   = ae.encode(x, is_training=True)                 # BatchNorm on batch statistics
+    x_out = ae.decode(enc.qbar, is_training=True)          # decoder sees qbar (straight-through estimator)
+    bc    = pc.bitcost(stop_gradient(enc.qbar), enc.symbols, is_training=True, pad_value=centers[0])
+    loss  = K_ms_ssim * (1 - MS-SSIM(x, x_out)) + beta * max(0.5 * (mean(bc * heatmap) + mean(bc)) - H_target, 0)
+            + L2(encoder, decoder[, pc]) + 0.1 * l2_loss(centers)
+
+TensorFlow derives the backward graph automatically; here it is written out by hand on top of the HIP kernels
+(conv data gradients reuse the forward conv kernels, filter gradients use ic_conv2d_wgrad_f32, BatchNorm /
+quantiser / context-model gradients have their own kernels).  PyTorch supplies tensors, the MS-SSIM loss
+(ms_ssim.py, autograd) and elementwise glue.  Gradients are written straight into flat per-group buffers
+(context model | decoder | encoder) so that data-parallel training all-reduces three contiguous buckets over
+RCCL, each launched as soon as its group's backward is complete (pc first, then decoder, then encoder).
+
+BatchNorm under data parallelism uses LOCAL batch statistics (the reference has no multi-GPU mode; its single-GPU
+batch-30 statistics are reproduced exactly only at world size 1).
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib, ms_ssim
+from . import weights as _weights
+from ._lib import lib, check, ptr
+
+BN_EPS = 1e-5
+BN_DECAY = 0.9
+_IMG_MEAN = (121.85369873, 113.58860779, 100.63715363)
+_IMG_VAR = (4746.37695312, 4454.13964844, 4812.234375)
+
+
+class _Layer(object):
+    __slots__ = ('scope', 'kind', 'kh', 'kw', 'cin', 'cout', 'stride', 'group')
+
+
+class TrainGraph(object):
+    """Parameters, gradients and the hand-written forward/backward of the CVPR autoencoder + res_shallow context model."""
+
+    def __init__(self, ae_config, pc_config, weights, device='cuda', process_group=None):
+        self.ae_config, self.pc_config = ae_config, pc_config
+        self.dev = torch.device(device)
+        if self.dev.type != 'cuda':
+            raise _lib.HipLibraryError('training runs only on a HIP device, got {}'.format(self.dev))
+        self.pg = process_group
+        self.B = int(ae_config.arch_param_B)
+        self.C = int(ae_config.num_chan_bn)
+        self.L = int(ae_config.num_centers)
+        self.k = int(pc_config.arch_param__k)
+        self.heatmap = bool(ae_config.heatmap)
+        if pc_config.kernel_size != 3:
+            raise NotImplementedError('context model: kernel_size 3 only')
+        # ---- layer table ----
+        self.layers = OrderedDict()
+        for scope, kind, shape in _weights.ae_conv_specs(self.C, self.B, self.heatmap):
+            l = _Layer()
+            l.scope, l.kind = scope, kind
+            l.kh, l.kw = shape[0], shape[1]
+            l.cin, l.cout = (shape[2], shape[3]) if kind == 'conv' else (shape[3], shape[2])
+            l.stride = 1 if (kind == 'conv' and l.kh == 3) else 2
+            l.group = 'enc' if scope.startswith(_weights.ENC) else 'dec'
+            self.layers[scope] = l
+        self.pc_scopes = [s for s, _ in _weights.pc_conv_specs(self.L, self.k, 3)]
+        # ---- parameters (checkpoint names and TF layouts) and flat gradient buckets ----
+        self.params = OrderedDict()
+        for name, arr in weights.items():
+            self.params[name] = torch.as_tensor(np.ascontiguousarray(arr), dtype=torch.float32).to(self.dev)
+        self.trainable = OrderedDict((n, t) for n, t in self.params.items() if 'moving_' not in n)
+        groups = {'pc': [], 'dec': [], 'enc': []}
+        for n in self.trainable:
+            groups['pc' if n.startswith('probclass3d/') else ('dec' if n.startswith(_weights.DEC) else 'enc')].append(n)
+        self.group_names = groups
+        self.flat_grads, self.grads = {}, OrderedDict()
+        for g, names in groups.items():
+            total = sum(self.trainable[n].numel() for n in names)
+            flat = torch.zeros(total, dtype=torch.float32, device=self.dev)
+            self.flat_grads[g] = flat
+            off = 0
+            for n in names:
+                k = self.trainable[n].numel()
+                self.grads[n] = flat[off:off + k].view(self.trainable[n].shape)
+                off += k
+        # ---- constants and scratch ----
+        self.ones = torch.ones(256, device=self.dev)
+        self.zeros = torch.zeros(256, device=self.dev)
+        self.img_mean = torch.tensor(_IMG_MEAN, device=self.dev)
+        self.img_std = torch.sqrt(torch.tensor(_IMG_VAR, device=self.dev) + 1e-10)
+        self.bn_ws = torch.empty(lib.ic_bn_workspace_bytes(256), dtype=torch.uint8, device=self.dev)
+        self.packed3 = lib.ic_conv3x3_c128_packed_floats()
+        self._ws = {}
+        self._pending = []
+
+    # ------------------------------------------------------------------------------------------------
+    # small helpers
+    # ------------------------------------------------------------------------------------------------
+    def _st(self):
+        return _lib.current_stream(self.dev)
+
+    def _scratch(self, key, nbytes):
+        t = self._ws.get(key)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=self.dev)
+            self._ws[key] = t
+        return t
+
+    def _new(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.dev)
+
+    # ---- raw convolution (no BN, no activation): forward and data-gradient use ----
+    def _conv3x3(self, x, w_tf, backward=False):
+        N, _, H, W = x.shape
+        wp = self._new(self.packed3)
+        f = lib.ic_pack_conv3x3_c128_bwd_f32 if backward else lib.ic_pack_conv3x3_c128_f32
+        check(f(ptr(w_tf), ptr(wp), self._st()))
+        y = self._new(N, 128, H, W)
+        check(lib.ic_conv3x3_c128_bn_act_f32(ptr(x), ptr(wp), ptr(self.ones), ptr(self.zeros), None, None, ptr(y),
+                                             N, H, W, 0, self._st()), 'conv3x3')
+        return y
+
+    def _conv_s(self, x, w_tf, kh, kw, cin, cout, stride):
+        """TF-SAME conv with filter [kh,kw,cin,cout]; matrix-core path when the shape has one."""
+        N, _, H, W = x.shape
+        y = self._new(N, cout, -(-H // stride), -(-W // stride))
+        n = lib.ic_conv2d_mfma_packed_floats(kh, kw, cin, cout, stride, 0)
+        if n:
+            wp = self._new(n)
+            check(lib.ic_pack_conv2d_mfma_f32(ptr(w_tf), ptr(wp), kh, kw, cin, cout, stride, 0, self._st()))
+            check(lib.ic_conv2d_mfma_bn_act_f32(ptr(x), ptr(wp), ptr(self.ones), ptr(self.zeros), ptr(y), N, cin, H, W,
+                                                cout, kh, kw, stride, 0, 0, self._st()), 'conv mfma')
+        else:
+            check(lib.ic_conv2d_bn_act_f32(ptr(x), ptr(w_tf), ptr(self.ones), ptr(self.zeros), None, None, ptr(y),
+                                           N, cin, H, W, cout, kh, kw, stride, 0, None, None, self._st()), 'conv direct')
+        return y
+
+    def _deconv_s(self, x, w_tf, kh, kw, cin, cout):
+        """stride-2 TF-SAME transposed conv with filter [kh,kw,cout,cin]."""
+        N, _, H, W = x.shape
+        y = self._new(N, cout, 2 * H, 2 * W)
+        n = lib.ic_conv2d_mfma_packed_floats(kh, kw, cin, cout, 2, 1)
+        if n:
+            wp = self._new(n)
+            check(lib.ic_pack_conv2d_mfma_f32(ptr(w_tf), ptr(wp), kh, kw, cin, cout, 2, 1, self._st()))
+            check(lib.ic_conv2d_mfma_bn_act_f32(ptr(x), ptr(wp), ptr(self.ones), ptr(self.zeros), ptr(y), N, cin, H, W,
+                                                cout, kh, kw, 2, 1, 0, self._st()), 'deconv mfma')
+        else:
+            check(lib.ic_deconv2d_bn_act_f32(ptr(x), ptr(w_tf), ptr(self.ones), ptr(self.zeros), ptr(y), N, cin, H, W,
+                                             cout, kh, kw, 0, None, None, self._st()), 'deconv direct')
+        return y
+
+    def _raw_forward(self, l, x):
+        w = self.params[l.scope + '/weights']
+        if l.kind == 'conv' and l.kh == 3 and l.cin == 128 and l.cout == 128:
+            return self._conv3x3(x, w)
+        if l.kind == 'conv':
+            return self._conv_s(x, w, l.kh, l.kw, l.cin, l.cout, l.stride)
+        return self._deconv_s(x, w, l.kh, l.kw, l.cin, l.cout)
+
+    def _raw_backward_data(self, l, g):
+        """gradient wrt the layer input of the raw conv (g = gradient wrt its output)."""
+        w = self.params[l.scope + '/weights']
+        if l.kind == 'conv' and l.kh == 3 and l.cin == 128 and l.cout == 128:
+            return self._conv3x3(g, w, backward=True)
+        if l.kind == 'conv':      # adjoint of a strided conv = transposed conv with the SAME array read as [kh,kw,out=cin,in=cout]
+            return self._deconv_s(g, w, l.kh, l.kw, l.cout, l.cin)
+        # adjoint of a transposed conv = strided conv with the same array read as [kh,kw,cin=cout_l,cout=cin_l]
+        return self._conv_s(g, w, l.kh, l.kw, l.cout, l.cin, 2)
+
+    def _wgrad(self, l, x_in, g):
+        N = x_in.shape[0]
+        dw = self.grads[l.scope + '/weights']
+        wd = float(self.ae_config.regularization_factor)
+        w = self.params[l.scope + '/weights']
+        if l.kind == 'conv':
+            U, V, A, Bc, UH, UW = x_in, g, l.cin, l.cout, x_in.shape[2], x_in.shape[3]
+        else:
+            U, V, A, Bc, UH, UW = g, x_in, l.cout, l.cin, g.shape[2], g.shape[3]
+        VH, VW = -(-UH // l.stride), -(-UW // l.stride)
+        need = lib.ic_conv2d_wgrad_workspace_bytes(N, A, Bc, VH, VW, l.kh, l.kw)
+        ws = self._scratch('wgrad', need)
+        check(lib.ic_conv2d_wgrad_f32(ptr(U), ptr(V), ptr(dw), N, A, UH, UW, Bc, l.kh, l.kw, l.stride, ptr(w), wd,
+                                      ptr(ws), need, self._st()), 'wgrad ' + l.scope)
+
+    # ---- conv + BatchNorm(train) + activation (+ residual adds) ----
+    def _cba_fwd(self, scope, x, relu, res1=None, res2=None, tape=None):
+        l = self.layers[scope]
+        raw = self._raw_forward(l, x)
+        N, Cc, H, W = raw.shape
+        mean, var = self._new(Cc), self._new(Cc)
+        check(lib.ic_bn_stats_f32(ptr(raw), ptr(mean), ptr(var), N, Cc, H * W, ptr(self.bn_ws), self._st()))
+        gamma = self.params[scope + '/BatchNorm/gamma']
+        beta = self.params[scope + '/BatchNorm/beta']
+        invstd = torch.rsqrt(var + BN_EPS)
+        scale = gamma * invstd
+        shift = beta - mean * scale
+        y = self._new(N, Cc, H, W)
+        check(lib.ic_bn_apply_f32(ptr(raw), ptr(scale), ptr(shift), ptr(res1), ptr(res2), ptr(y), N, Cc, H * W,
+                                  int(relu), self._st()))
+        # moving statistics (decay 0.9; TF's fused kernel feeds the unbiased variance to the moving average)
+        M = N * H * W
+        mm, mv = self.params[scope + '/BatchNorm/moving_mean'], self.params[scope + '/BatchNorm/moving_variance']
+        mm.mul_(BN_DECAY).add_(mean, alpha=1 - BN_DECAY)
+        mv.mul_(BN_DECAY).add_(var, alpha=(1 - BN_DECAY) * M / max(M - 1, 1))
+        if tape is not None:
+            tape.append((l, x, raw, mean, invstd, scale, shift, relu))
+        return y
+
+    def _cba_bwd(self, rec, dy, need_dx=True):
+        l, x, raw, mean, invstd, scale, shift, relu = rec
+        N, Cc, H, W = raw.shape
+        draw = self._new(N, Cc, H, W)
+        check(lib.ic_bn_backward_f32(ptr(dy), ptr(raw), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+                                     ptr(self.params[l.scope + '/BatchNorm/gamma']), ptr(draw),
+                                     ptr(self.grads[l.scope + '/BatchNorm/gamma']),
+                                     ptr(self.grads[l.scope + '/BatchNorm/beta']),
+                                     N, Cc, H * W, int(relu), ptr(self.bn_ws), self._st()), 'bn backward')
+        self._wgrad(l, x, draw)
+        return self._raw_backward_data(l, draw) if need_dx else None
+
+    # ---- residual stack (autoencoder.py:224-234 / :252-262) ----
+    def _stack_names(self, kind):
+        root = _weights.ENC if kind == 'enc' else _weights.DEC
+        final = 'res_block_enc_final' if kind == 'enc' else 'dec_after_res'
+        blocks = [['{}/res_block_{}_{}/{}_{}_{}'.format(root, kind, b, kind, b, i) for i in (1, 2, 3)]
+                  for b in range(self.B)]
+        return blocks, '{}/{}'.format(root, final)
+
+    def _stack_fwd(self, kind, x, tape):
+        blocks, final = self._stack_names(kind)
+        res0 = net = x
+        for grp in blocks:
+            res_b = net
+            for i, blk in enumerate(grp):
+                t = self._cba_fwd(blk + '/conv1', net, True, tape=tape)
+                net = self._cba_fwd(blk + '/conv2', t, False, res1=net, res2=res_b if i == 2 else None, tape=tape)
+        t = self._cba_fwd(final + '/conv1', net, False, tape=tape)
+        return self._cba_fwd(final + '/conv2', t, False, res1=net, res2=res0, tape=tape)
+
+    def _stack_bwd(self, tape, g):
+        """tape holds the 6B+2 records of the stack in forward order; returns the gradient wrt the stack input."""
+        recs = list(tape)
+        # final block: out = conv2(conv1(net)) + net + res0
+        g_res0 = g
+        gt = self._cba_bwd(recs.pop(), g)
+        g_net = g + self._cba_bwd(recs.pop(), gt)
+        for b in reversed(range(self.B)):
+            g_resb = None
+            for i in (2, 1, 0):
+                gout = g_net                                   # gradient wrt this block's output
+                if i == 2:
+                    g_resb = gout                              # group skip taps the last block's output sum
+                gt = self._cba_bwd(recs.pop(), gout)
+                g_net = gout + self._cba_bwd(recs.pop(), gt)   # block input: skip + conv path
+            g_net = g_net + g_resb
+        assert not recs
+        return g_net + g_res0
+
+    # ------------------------------------------------------------------------------------------------
+    # the step
+    # ------------------------------------------------------------------------------------------------
+    def forward_backward(self, x):
+        """x: (N,3,H,W) float32 0..255 on the device.  Fills self.grads; returns a dict of python floats."""
+        cfg = self.ae_config
+        st = self._st()
+        N, _, H, W = x.shape
+        assert H % 8 == 0 and W % 8 == 0
+        C, L, k = self.C, self.L, self.k
+        h, w = H // 8, W // 8
+        # ===== forward: encoder =====
+        enc_tape_a, enc_tape_s, enc_tape_b = [], [], []
+        # _normalize (autoencoder.py:136-144): kept as its own tensor, h1's filter gradient needs the normalised input
+        xn = (x - self.img_mean.view(1, 3, 1, 1)) / self.img_std.view(1, 3, 1, 1) if cfg.normalization == 'FIXED' else x
+        net = self._cba_fwd(_weights.ENC + '/h1', xn.contiguous(), True, tape=enc_tape_a)
+        net = self._cba_fwd(_weights.ENC + '/h2', net, True, tape=enc_tape_a)
+        net = self._stack_fwd('enc', net, enc_tape_s)
+        bott = self._cba_fwd(_weights.ENC + '/to_bn', net, False, tape=enc_tape_b)
+        centers = self.params[_weights.ENC + '/centers']
+        mk = lambda: self._new(N, C, h, w)
+        hm, z, qsoft, qhard, qbar = (mk() if self.heatmap else None), mk(), mk(), mk(), mk()
+        symbols = torch.empty((N, C, h, w), dtype=torch.int64, device=self.dev)
+        if self.heatmap:
+            check(lib.ic_heatmap_quantize_f32(ptr(bott), ptr(centers), L, 1.0, ptr(hm), ptr(z), ptr(qsoft), ptr(qhard),
+                                              ptr(qbar), ptr(symbols), N, C, h, w, st))
+        else:
+            check(lib.ic_quantize_f32(ptr(bott), ptr(centers), L, 1.0, ptr(qsoft), ptr(qhard), ptr(symbols),
+                                      bott.numel(), st))
+            qbar = qsoft + (qhard - qsoft)
+        # ===== forward: decoder on qbar =====
+        dec_tape_a, dec_tape_s, dec_tape_b = [], [], []
+        net = self._cba_fwd(_weights.DEC + '/from_bn', qbar, True, tape=dec_tape_a)
+        net = self._stack_fwd('dec', net, dec_tape_s)
+        net = self._cba_fwd(_weights.DEC + '/h12', net, True, tape=dec_tape_b)
+        pre = self._cba_fwd(_weights.DEC + '/h13', net, False, tape=dec_tape_b)
+        # ===== forward: context model on stop_gradient(qbar) =====
+        pad_value = float(centers[0]) if self.pc_config.use_centers_for_padding else 0.0
+        wtab_t = []
+        for s in self.pc_scopes:
+            wtab_t += [self.params[s + '/weights'], self.params[s + '/biases']]
+        pc_need = lib.ic_pc_workspace_bytes(N, C, h, w, k)
+        pc_ws = torch.empty(pc_need, dtype=torch.uint8, device=self.dev)
+        logits = self._new(N, C, h, w, L)
+        bc = mk()
+        check(lib.ic_pc_bitcost_f32(ptr(qbar), ptr(symbols), _lib.ptr_table(wtab_t), k, L, pad_value, ptr(logits),
+                                    ptr(bc), N, C, h, w, ptr(pc_ws), pc_need, st), 'pc forward')
+        # ===== loss (train.py:303-336, :379-390) =====
+        xo = pre.detach().requires_grad_(True)
+        if cfg.normalization == 'FIXED':
+            x_out = torch.clamp(xo * self.img_std.view(1, 3, 1, 1) + self.img_mean.view(1, 3, 1, 1), 0, 255)
+        else:
+            x_out = torch.clamp(xo, 0, 255)
+        kind = cfg.distortion_to_minimize
+        mse_per_img = ((x_out - x) ** 2).mean(dim=(1, 2, 3))
+        if kind == 'ms_ssim':
+            msssim = ms_ssim.multiscale_ssim(x, x_out)
+            d_loss = float(cfg.K_ms_ssim) * (1.0 - msssim)
+        elif kind == 'mse':
+            msssim = None
+            d_loss = mse_per_img.mean()
+        else:
+            msssim = None
+            d_loss = float(cfg.K_psnr) - (10.0 * torch.log10(255.0 * 255.0 / mse_per_img)).mean()
+        d_loss.backward()
+        g_pre = xo.grad
+        count = float(bc.numel())
+        H_real = bc.mean()
+        H_mask = (bc * hm).mean() if self.heatmap else H_real
+        H_soft = 0.5 * (H_mask + H_real)
+        beta, H_t = float(cfg.beta), float(cfg.H_target)
+        active = bool(H_soft > H_t)
+        pc_loss = beta * max(float(H_soft) - H_t, 0.0)
+        if active:
+            d_bc = (hm + 1.0) * (0.5 * beta / count) if self.heatmap else torch.full_like(bc, beta / count)
+            d_hm = bc * (0.5 * beta / count) if self.heatmap else None
+        else:
+            d_bc, d_hm = torch.zeros_like(bc), (torch.zeros_like(bc) if self.heatmap else None)
+        # ===== backward: context model (its bucket is complete first) =====
+        self._pc_backward(qbar, symbols, logits, d_bc, pc_ws, pad_value, N, C, h, w)
+        self._bucket_ready('pc')
+        # ===== backward: decoder =====
+        g = self._cba_bwd(dec_tape_b.pop(), g_pre)
+        g = self._cba_bwd(dec_tape_b.pop(), g)
+        g = self._stack_bwd(dec_tape_s, g)
+        g_qbar = self._cba_bwd(dec_tape_a.pop(), g)
+        self._bucket_ready('dec')
+        # ===== backward: quantiser + importance map =====
+        d_bott = torch.empty_like(bott)
+        d_centers = self.grads[_weights.ENC + '/centers']
+        qws = self._scratch('qbwd', lib.ic_heatmap_quantize_bwd_workspace_bytes(L))
+        check(lib.ic_heatmap_quantize_bwd_f32(ptr(bott), ptr(centers), L, 1.0, ptr(g_qbar), ptr(d_hm), ptr(d_bott),
+                                              ptr(d_centers), N, C, h, w, int(self.heatmap), ptr(qws), st), 'quantiser backward')
+        if cfg.regularization_factor_centers != 0:
+            d_centers.add_(centers, alpha=float(cfg.regularization_factor_centers))
+        # ===== backward: encoder =====
+        g = self._cba_bwd(enc_tape_b.pop(), d_bott)
+        g = self._stack_bwd(enc_tape_s, g)
+        g = self._cba_bwd(enc_tape_a.pop(), g)
+        self._cba_bwd(enc_tape_a.pop(), g, need_dx=False)
+        self._bucket_ready('enc')
+        self._wait_buckets()
+        out = {'d_loss_scaled': float(d_loss), 'pc_loss': pc_loss, 'H_real': float(H_real), 'H_mask': float(H_mask),
+               'bpp': float(bc.sum()) / (N * H * W)}
+        if msssim is not None:
+            out['ms_ssim'] = float(msssim)
+        self.last = {'x_out': x_out.detach(), 'symbols': symbols, 'bc': bc, 'heatmap': hm, 'z': z, 'qbar': qbar}
+        return out
+
+    def regularization_loss(self):
+        """value of the L2 terms (their gradients are already folded into the filter gradients)."""
+        f = float(self.ae_config.regularization_factor)
+        tot = sum(float((t * t).sum()) for n, t in self.trainable.items()
+                  if n.startswith('autoencoder/') and n.endswith('/weights')) * 0.5 * f
+        c = self.params[_weights.ENC + '/centers']
+        tot += float(self.ae_config.regularization_factor_centers) * 0.5 * float((c * c).sum())
+        if self.pc_config.regularization_factor is not None:
+            tot += sum(float((t * t).sum()) for n, t in self.trainable.items()
+                       if n.startswith('probclass3d/') and n.endswith('/weights')) * 0.5 * float(self.pc_config.regularization_factor)
+        return tot
+
+    # ---- context-model backward (probclass.py:185-261 in reverse) ----
+    def _pc_backward(self, q, symbols, logits, d_bc, pc_ws, pad_value, N, C, h, w):
+        st, k, L = self._st(), self.k, self.L
+        f32 = pc_ws.view(torch.float32)
+        n0 = N * k * (C + 3) * (h + 6) * (w + 6)
+        n1 = N * k * (C + 2) * (h + 4) * (w + 4)
+        n2 = N * k * (C + 1) * (h + 2) * (w + 2)
+        b0, b1, b2 = f32[:n0], f32[n0:n0 + n1], f32[n0 + n1:n0 + n1 + n2]
+        s0, s1, s2, s3 = self.pc_scopes
+        P, G = self.params, self.grads
+        cs_ws = self._scratch('chsum', lib.ic_channel_sum_workspace_bytes(max(k, L)))
+
+        def wgrad(U, qv, V, scope, A, Bc, VD, VH, VW, first):
+            need = lib.ic_pc_wgrad_workspace_bytes(N, A, Bc, VD, VH, VW)
+            ws = self._scratch('pcwgrad', need)
+            check(lib.ic_pc_wgrad_f32(ptr(U), ptr(qv), pad_value, ptr(V), ptr(G[scope + '/weights']), N, A, Bc, VD, VH, VW,
+                                      int(first), ptr(ws), need, st), 'pc wgrad ' + scope)
+            check(lib.ic_channel_sum_f32(ptr(V), ptr(G[scope + '/biases']), N, Bc, VD * VH * VW, ptr(cs_ws), st))
+            rf = self.pc_config.regularization_factor
+            if rf is not None:
+                G[scope + '/weights'].add_(P[scope + '/weights'], alpha=float(rf))
+
+        def bwd_data(g, scope, res, act, Cin, Cout, OD, OH, OW, relu_mask):
+            dx = self._new(N, Cin, OD + 1, OH + 2, OW + 2)
+            check(lib.ic_pc_bwd_data_f32(ptr(g), ptr(P[scope + '/weights']), ptr(res), ptr(act), ptr(dx), N, Cin, Cout,
+                                         OD, OH, OW, 0, int(relu_mask), st), 'pc bwd data ' + scope)
+            return dx
+        # logits (post-ReLU) -> g3 planar (N, L, C*h*w)
+        g3 = self._new(N, L, C, h, w)
+        check(lib.ic_pc_dlogits_f32(ptr(logits), ptr(symbols), ptr(d_bc.contiguous()), ptr(g3), N, C * h * w, L, st))
+        wgrad(b2, None, g3, s3, k, L, C, h, w, False)
+        gb2 = bwd_data(g3, s3, None, None, k, L, C, h, w, False)                               # (N,k,C+1,h+2,w+2)
+        wgrad(b1, None, gb2, s2, k, k, C + 1, h + 2, w + 2, False)
+        gb1 = bwd_data(gb2, s2, None, b1, k, k, C + 1, h + 2, w + 2, True)                      # (N,k,C+2,h+4,w+4)
+        wgrad(b0, None, gb1, s1, k, k, C + 2, h + 4, w + 4, False)
+        gb0 = bwd_data(gb1, s1, gb2, b0, k, k, C + 2, h + 4, w + 4, True)                       # (N,k,C+3,h+6,w+6)
+        wgrad(None, q, gb0, s0, 1, k, C + 3, h + 6, w + 6, True)
+
+    # ---- data-parallel gradient exchange: three flat buckets, each reduced as soon as it is complete ----
+    def _bucket_ready(self, group):
+        import torch.distributed as dist
+        if self.pg is None and not (dist.is_available() and dist.is_initialized()):
+            return
+        world = dist.get_world_size(self.pg)
+        if world == 1:
+            return
+        flat = self.flat_grads[group]
+        # ProcessGroupNCCL orders the collective after the work already queued on the current stream
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self._pending.append((work, flat, world))
+
+    def _wait_buckets(self):
+        for work, flat, world in self._pending:
+            work.wait()
+            flat.div_(world)
+        self._pending = []
+
+
+class TFAdam(object):
+    """tf.train.AdamOptimizer (train.py:339-349 via training_helpers.py:38-48): beta1 0.9, beta2 0.999, eps 1e-8,
+    lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t); var -= lr_t * m / (sqrt(v) + eps)  (epsilon outside the bias
+    correction, unlike torch.optim.Adam)."""
+
+    def __init__(self, params, grads, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.params, self.grads = list(params), list(grads)
+        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+        self.t = 0
+
+    def step(self, lr=None):
+        self.t += 1
+        lr = self.lr if lr is None else lr
+        lr_t = lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        torch._foreach_mul_(self.m, self.b1)
+        torch._foreach_add_(self.m, self.grads, alpha=1.0 - self.b1)
+        torch._foreach_mul_(self.v, self.b2)
+        torch._foreach_addcmul_(self.v, self.grads, self.grads, value=1.0 - self.b2)
+        denom = torch._foreach_sqrt(self.v)
+        torch._foreach_add_(denom, self.eps)
+        torch._foreach_addcdiv_(self.params, self.m, denom, value=-lr_t)
+
+
+def learning_rate(config, step, num_itr_per_epoch):
+    """training_helpers.py:22-34: FIXED, or staircase exponential decay every decay_interval epochs."""
+    lr = float(config.lr_initial)
+    if config.lr_schedule == 'FIXED':
+        return lr
+    decay_steps = max(int(num_itr_per_epoch * config.lr_schedule_decay_interval), 1)
+    e = step / decay_steps
+    if config.lr_schedule_decay_staircase:
+        e = math.floor(e)
+    return lr * float(config.lr_schedule_decay_rate) ** e
+
+
+class Trainer(object):
+    """TrainGraph + the two Adam optimisers of get_train_op (AE variables with lr_ae, context model with lr_pc)."""
+
+    def __init__(self, ae_config, pc_config, weights, device='cuda', num_itr_per_epoch=1000, process_group=None):
+        self.graph = TrainGraph(ae_config, pc_config, weights, device, process_group)
+        g = self.graph
+        ae_names = g.group_names['enc'] + g.group_names['dec']
+        pc_names = g.group_names['pc']
+        self.opt_ae = TFAdam([g.trainable[n] for n in ae_names], [g.grads[n] for n in ae_names], float(ae_config.lr_initial))
+        self.opt_pc = TFAdam([g.trainable[n] for n in pc_names], [g.grads[n] for n in pc_names], float(pc_config.lr_initial))
+        self.num_itr_per_epoch = num_itr_per_epoch
+        self.global_step = 0
+
+    def step(self, x):
+        g = self.graph
+        out = g.forward_backward(x)
+        if g.ae_config.train_autoencoder:
+            self.opt_ae.step(learning_rate(g.ae_config, self.global_step, self.num_itr_per_epoch))
+        if g.ae_config.train_probclass:
+            self.opt_pc.step(learning_rate(g.pc_config, self.global_step, self.num_itr_per_epoch))
+        self.global_step += 1
+        return out
+
+    def state_weights(self):
+        """current variables as a checkpoint-style dict name -> numpy array."""
+        return OrderedDict((n, t.detach().cpu().numpy()) for n, t in self.graph.params.items())

@@ -177,6 +177,55 @@ int ic_ae_decode_f32(const float* q, const void* const* dec_tab_host, int B, int
                      float* x_out, int N, int H, int W,
                      void* workspace, size_t workspace_bytes, ic_stream_t stream);
 
+/* =============================================================================================
+ * Training (train.py:101-106, :303-349): training-mode BatchNorm, backward kernels.
+ * Forward in training mode = the conv entry points above with scale = 1, shift = 0, relu = 0 ("raw" conv),
+ * then ic_bn_stats_f32 + ic_bn_apply_f32.  Data gradients of the convs reuse the forward kernels (a conv's
+ * data gradient is the transposed conv with the same TF filter array and vice versa; the 3x3 stride-1 case takes
+ * ic_pack_conv3x3_c128_bwd_f32).  Filter gradients: ic_conv2d_wgrad_f32.
+ * ============================================================================================= */
+size_t ic_bn_workspace_bytes(int C);
+/* batch mean and BIASED variance per channel of x (N,C,HW) (autoencoder.py:114-125, is_training=True) */
+int ic_bn_stats_f32(const float* x, float* mean, float* var, int N, int C, int HW, void* workspace, ic_stream_t stream);
+/* y = act(x * scale[c] + shift[c]) + res1 + res2 */
+int ic_bn_apply_f32(const float* x, const float* scale, const float* shift, const float* res1, const float* res2,
+                    float* y, int N, int C, int HW, int relu, ic_stream_t stream);
+/* BN(+ReLU) backward: g = dy * [x*scale+shift > 0 if relu]; dbeta = sum g; dgamma = sum g*xhat;
+ * dx = gamma*invstd*(g - dbeta/M - xhat*dgamma/M), xhat = (x - mean)*invstd */
+int ic_bn_backward_f32(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
+                       const float* invstd, const float* gamma, float* dx, float* dgamma, float* dbeta,
+                       int N, int C, int HW, int relu, void* workspace, ic_stream_t stream);
+/* filter gradient, generic form dW[t][a][b] = sum U[n][a][s*q + t + o0] * V[n][b][q] (conv_wgrad.hip):
+ *   conv:            U = x (A = Cin, H x W), V = dy (B = Cout)            -> dw [KH][KW][Cin][Cout]
+ *   transposed conv: U = dy (A = Cout, 2H x 2W), V = x (B = Cin), stride 2 -> dw [KH][KW][Cout][Cin]
+ * w (nullable) and wd add the L2 term wd * w (slim.l2_regularizer, autoencoder.py:101-102). */
+size_t ic_conv2d_wgrad_workspace_bytes(int N, int A, int B, int VH, int VW, int KH, int KW);
+int ic_conv2d_wgrad_f32(const float* U, const float* V, float* dw, int N, int A, int UH, int UW, int B,
+                        int KH, int KW, int stride, const float* w, float wd,
+                        void* workspace, size_t workspace_bytes, ic_stream_t stream);
+int ic_pack_conv3x3_c128_bwd_f32(const float* w_tf, float* w_packed, ic_stream_t stream);
+/* importance map + quantiser backward (autoencoder.py:127-134,171-200; quantizer.py:43-100): d_qbar, d_heatmap
+ * (nullable) -> d_bottleneck (N,C+1,h,w), d_centers (L).  workspace: ic_heatmap_quantize_bwd_workspace_bytes(L). */
+size_t ic_heatmap_quantize_bwd_workspace_bytes(int L);
+int ic_heatmap_quantize_bwd_f32(const float* bottleneck, const float* centers, int L, float sigma,
+                                const float* d_qbar, const float* d_heatmap, float* d_bottleneck, float* d_centers,
+                                int N, int C, int h, int w, int heatmap_on, void* workspace, ic_stream_t stream);
+/* context model backward pieces (probclass.py:63-106,185-261) */
+int ic_pc_dlogits_f32(const float* logits, const int64_t* symbols, const float* d_bits, float* g,
+                      int N, int vol, int L, ic_stream_t stream);
+int ic_pc_bwd_data_f32(const float* g, const float* w, const float* res, const float* act, float* dx,
+                       int N, int Cin, int Cout, int OD, int OH, int OW, int first_mask, int relu_mask,
+                       ic_stream_t stream);
+size_t ic_pc_wgrad_workspace_bytes(int N, int A, int B, int VD, int VH, int VW);
+int ic_pc_wgrad_f32(const float* U, const float* q, float pad_value, const float* V, float* dw,
+                    int N, int A, int B, int VD, int VH, int VW, int first_mask,
+                    void* workspace, size_t workspace_bytes, ic_stream_t stream);
+size_t ic_channel_sum_workspace_bytes(int C);
+int ic_channel_sum_f32(const float* x, float* out, int N, int C, int M, void* workspace, ic_stream_t stream);
+/* The context-model backward reads the three feature volumes ic_pc_bitcost_f32 left in its workspace
+ * (layout: conv0 out (N,k,C+3,h+6,w+6) | res1/conv1 out (N,k,C+2,h+4,w+4) | res1 out (N,k,C+1,h+2,w+2) | packed
+ * filters): keep that workspace untouched between the forward call and the ic_pc_* backward calls. */
+
 /* device timing helper for bench.py: wall time between two points on `stream` measured with
  * hipEvents created on that stream's device (torch.cuda.Event only sees torch's own streams). */
 int ic_event_create(void** ev);

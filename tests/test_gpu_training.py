@@ -1,0 +1,219 @@
+"""-m gpu: training-mode kernels (BatchNorm, filter gradients, quantiser / context-model backward) and one whole
+training step against the CPU oracle's autograd (oracle/train_oracle.py)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import assert_close, dev, rel_err
+
+pytestmark = pytest.mark.gpu
+GTOL = 2e-4        # gradients: relative to the tensor scale, vs the float64 autograd of the oracle
+
+
+def _L():
+    from imgcomp_cvpr_amd import _lib
+    return _lib
+
+
+def test_bn_train_forward_backward(cuda):
+    L = _L()
+    rs = np.random.RandomState(0)
+    N, C, H, W = 3, 37, 6, 10
+    x = rs.normal(0.3, 2.0, (N, C, H, W)).astype(np.float32)
+    gamma = rs.uniform(0.5, 1.5, C).astype(np.float32)
+    beta = rs.normal(0, 0.3, C).astype(np.float32)
+    res = rs.normal(0, 1, (N, C, H, W)).astype(np.float32)
+    dy = rs.normal(0, 1, (N, C, H, W)).astype(np.float32)
+    for relu in (0, 1):
+        xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+        gt = torch.tensor(gamma, dtype=torch.float64, requires_grad=True)
+        bt = torch.tensor(beta, dtype=torch.float64, requires_grad=True)
+        y = F.batch_norm(xt, None, None, gt, bt, training=True, eps=1e-5)
+        if relu:
+            y = F.relu(y)
+        y = y + torch.tensor(res, dtype=torch.float64)
+        y.backward(torch.tensor(dy, dtype=torch.float64))
+        d = lambda a: dev(a, cuda)
+        xd, dyd = d(x), d(dy)
+        ws = torch.empty(L.lib.ic_bn_workspace_bytes(C), dtype=torch.uint8, device=cuda)
+        mean, var = torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+        L.check(L.lib.ic_bn_stats_f32(L.ptr(xd), L.ptr(mean), L.ptr(var), N, C, H * W, L.ptr(ws), L.current_stream()))
+        assert_close(mean, xt.detach().mean(dim=(0, 2, 3)), 'batch mean', 1e-6)
+        assert_close(var, xt.detach().var(dim=(0, 2, 3), unbiased=False), 'batch var (biased)', 1e-6)
+        invstd = torch.rsqrt(var + 1e-5)
+        scale = d(gamma) * invstd
+        shift = d(beta) - mean * scale
+        yd = torch.empty_like(xd)
+        resd, gammad = d(res), d(gamma)
+        L.check(L.lib.ic_bn_apply_f32(L.ptr(xd), L.ptr(scale), L.ptr(shift), L.ptr(resd), None, L.ptr(yd), N, C, H * W,
+                                      relu, L.current_stream()))
+        assert_close(yd, y.detach(), 'bn apply', 1e-5)
+        dx, dg, db = torch.empty_like(xd), torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+        L.check(L.lib.ic_bn_backward_f32(L.ptr(dyd), L.ptr(xd), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd),
+                                         L.ptr(gammad), L.ptr(dx), L.ptr(dg), L.ptr(db), N, C, H * W, relu, L.ptr(ws),
+                                         L.current_stream()))
+        torch.cuda.synchronize()
+        assert_close(db, bt.grad, 'dbeta', 1e-5)
+        assert_close(dg, gt.grad, 'dgamma', 1e-5)
+        assert_close(dx, xt.grad, 'bn dx', 1e-5)
+
+
+@pytest.mark.parametrize('name,kind,N,Cin,Cout,H,W,K,stride', [
+    ('res3x3', 'conv', 2, 128, 128, 9, 12, 3, 1),
+    ('h2', 'conv', 2, 64, 128, 12, 16, 5, 2),
+    ('h1', 'conv', 1, 3, 64, 16, 24, 5, 2),
+    ('to_bn', 'conv', 2, 128, 33, 8, 12, 5, 2),
+    ('from_bn', 'deconv', 2, 32, 128, 5, 6, 3, 2),
+    ('h12', 'deconv', 1, 128, 64, 6, 8, 5, 2),
+    ('h13', 'deconv', 2, 64, 3, 7, 9, 5, 2),
+])
+def test_conv_filter_gradients(cuda, name, kind, N, Cin, Cout, H, W, K, stride):
+    from oracle import train_oracle as T
+    L = _L()
+    rs = np.random.RandomState(len(name))
+    x = rs.normal(0, 1, (N, Cin, H, W)).astype(np.float32)
+    wshape = (K, K, Cin, Cout) if kind == 'conv' else (K, K, Cout, Cin)
+    w = rs.normal(0, 0.1, wshape).astype(np.float32)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    y = T._conv(xt, wt, stride) if kind == 'conv' else T._deconv(xt, wt)
+    dy = rs.normal(0, 1, tuple(y.shape)).astype(np.float32)
+    y.backward(torch.tensor(dy, dtype=torch.float64))
+    d = lambda a: dev(a, cuda)
+    xd, dyd, wd_ = d(x), d(dy), d(w)
+    dw = torch.full(wshape, float('nan'), device=cuda)
+    if kind == 'conv':
+        U, V, A, B, UH, UW = xd, dyd, Cin, Cout, H, W
+    else:
+        U, V, A, B, UH, UW = dyd, xd, Cout, Cin, 2 * H, 2 * W
+    VH, VW = -(-UH // stride), -(-UW // stride)
+    need = L.lib.ic_conv2d_wgrad_workspace_bytes(N, A, B, VH, VW, K, K)
+    ws = torch.empty(need, dtype=torch.uint8, device=cuda)
+    L.check(L.lib.ic_conv2d_wgrad_f32(L.ptr(U), L.ptr(V), L.ptr(dw), N, A, UH, UW, B, K, K, stride, L.ptr(wd_), 0.25,
+                                      L.ptr(ws), need, L.current_stream()))
+    torch.cuda.synchronize()
+    assert_close(dw, wt.grad + 0.25 * wt.detach(), 'dW ' + name, 1e-5)
+    # data gradient through the graph's dispatch (forward kernels reused as adjoints)
+    from imgcomp_cvpr_amd import training, config_parser as cp, weights as Wm
+    ae, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'low'))
+    pc, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
+    if not hasattr(test_conv_filter_gradients, '_g'):
+        test_conv_filter_gradients._g = training.TrainGraph(ae, pc, Wm.synthetic_weights(ae, pc), cuda)
+    g = test_conv_filter_gradients._g
+    if kind == 'conv' and K == 3:
+        dx = g._conv3x3(dyd, wd_, backward=True)
+    elif kind == 'conv':
+        dx = g._deconv_s(dyd, wd_, K, K, Cout, Cin)
+    else:
+        dx = g._conv_s(dyd, wd_, K, K, Cout, Cin, 2)
+    torch.cuda.synchronize()
+    assert_close(dx, xt.grad, 'dX ' + name, 1e-5)
+
+
+def test_quantizer_backward(cuda):
+    L = _L()
+    rs = np.random.RandomState(3)
+    N, C, h, w = 2, 8, 5, 7
+    bott = rs.normal(0, 1.5, (N, C + 1, h, w)).astype(np.float32)
+    centers = np.linspace(-2, 2, 6).astype(np.float32)
+    gq = rs.normal(0, 1, (N, C, h, w)).astype(np.float32)
+    gh = rs.normal(0, 1, (N, C, h, w)).astype(np.float32)
+    bt = torch.tensor(bott, dtype=torch.float64, requires_grad=True)
+    ct = torch.tensor(centers, dtype=torch.float64, requires_grad=True)
+    hm = torch.clamp(torch.clamp(torch.sigmoid(bt[:, 0:1]) * C - torch.arange(C, dtype=torch.float64).view(1, C, 1, 1), max=1.0), min=0.0)
+    z = hm * bt[:, 1:]
+    dist = (z.unsqueeze(-1) - ct) ** 2
+    qsoft = (torch.softmax(-dist, -1) * ct).sum(-1)
+    ((qsoft * torch.tensor(gq, dtype=torch.float64)).sum() + (hm * torch.tensor(gh, dtype=torch.float64)).sum()).backward()
+    d = lambda a: dev(a, cuda)
+    dbott = torch.empty((N, C + 1, h, w), device=cuda)
+    dc = torch.empty(6, device=cuda)
+    ws = torch.empty(L.lib.ic_heatmap_quantize_bwd_workspace_bytes(6), dtype=torch.uint8, device=cuda)
+    keep = [d(bott), d(centers), d(gq), d(gh)]          # hold the device tensors until the kernel has run
+    L.check(L.lib.ic_heatmap_quantize_bwd_f32(L.ptr(keep[0]), L.ptr(keep[1]), 6, 1.0, L.ptr(keep[2]), L.ptr(keep[3]),
+                                              L.ptr(dbott), L.ptr(dc), N, C, h, w, 1, L.ptr(ws), L.current_stream()))
+    torch.cuda.synchronize()
+    assert_close(dbott, bt.grad, 'd bottleneck', 1e-5)
+    assert_close(dc, ct.grad, 'd centers', 1e-5)
+
+
+def test_training_step_matches_oracle(cuda):
+    """forward values and EVERY parameter gradient of one step (batch 2, 32x32, MSE distortion: MS-SSIM is undefined
+    for images this small, it is covered by test_ms_ssim_loss_module) against float64 autograd on the CPU."""
+    from imgcomp_cvpr_amd import training, config_parser as cp, weights as W
+    from oracle import train_oracle as T
+    ae, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'med'))
+    pc, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
+    ae.distortion_to_minimize = 'mse'
+    ae.H_target = 0.5                                     # keep the rate term active
+    wts = W.synthetic_weights(ae, pc)
+    x = W.synthetic_image((2, 3, 32, 32), 'natural', 0)
+    total, comps, p = T.train_loss(x, wts, ae.as_dict(), pc.as_dict(), torch.float64)
+    total.backward()
+    g = training.TrainGraph(ae, pc, wts, cuda)
+    out = g.forward_backward(dev(x, cuda))
+    torch.cuda.synchronize()
+    assert torch.equal(g.last['symbols'].cpu(), comps['symbols']), 'symbol flip between fp32 and fp64: pick another seed'
+    assert_close(g.last['z'], comps['z'].detach(), 'z (training-mode BN)', 1e-4)
+    assert_close(g.last['bc'], comps['bc'].detach(), 'bit cost', 1e-4)
+    assert_close(g.last['x_out'], comps['x_out'].detach(), 'x_out', 1e-4)
+    assert abs(out['d_loss_scaled'] - float(comps['d_loss_scaled'])) < 1e-3 * abs(float(comps['d_loss_scaled']))
+    assert abs(out['pc_loss'] - float(comps['pc_loss'])) < 1e-3 * abs(float(comps['pc_loss'])) and out['pc_loss'] > 0
+    assert abs(g.regularization_loss() - float(comps['reg'])) < 1e-4 * float(comps['reg'])
+    worst = ('', 0.0)
+    for name, ref in p.items():
+        if ref.grad is None:
+            continue
+        e = rel_err(g.grads[name], ref.grad)
+        if e > worst[1]:
+            worst = (name, e)
+        assert e <= GTOL, 'gradient of {}: relative error {:.3e}'.format(name, e)
+    assert len([n for n in p if p[n].grad is not None]) == len(g.grads) == 219
+    print('worst gradient error', worst)
+
+
+def test_ms_ssim_loss_module(cuda):
+    """the torch MS-SSIM loss (ms_ssim.py) on the device equals the oracle's restatement, value and gradient."""
+    from imgcomp_cvpr_amd import ms_ssim, weights as W
+    from oracle import train_oracle as T
+    a = W.synthetic_image((2, 3, 128, 128), 'natural', 1)
+    b = np.clip(a.astype(np.float64) + np.random.RandomState(0).normal(0, 6, a.shape), 0, 255)
+    tb = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    ref = T.ms_ssim(torch.as_tensor(a).double(), tb)
+    ref.backward()
+    gb = dev(b, cuda).requires_grad_(True)
+    v = ms_ssim.multiscale_ssim(dev(a, cuda), gb)
+    v.backward()
+    assert abs(float(v) - float(ref)) < 1e-5
+    assert rel_err(gb.grad, tb.grad) < 1e-3
+
+
+def test_optimizer_and_schedule(cuda):
+    from imgcomp_cvpr_amd import training, config_parser as cp
+    ae, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'low'))
+    assert training.learning_rate(ae, 0, 100) == pytest.approx(8e-5)
+    assert training.learning_rate(ae, 199, 100) == pytest.approx(8e-5)
+    assert training.learning_rate(ae, 200, 100) == pytest.approx(8e-6)      # staircase x0.1 every 2 epochs
+    # TF Adam: first step moves every coordinate by ~lr regardless of the gradient's scale
+    p = torch.ones(4, device=cuda)
+    gr = torch.tensor([1.0, -2.0, 1e-3, 50.0], device=cuda)
+    opt = training.TFAdam([p], [gr], lr=0.1)
+    opt.step()
+    m, v = 0.1 * gr, 0.001 * gr * gr
+    lr_t = 0.1 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    assert torch.allclose(p, 1 - lr_t * m / (v.sqrt() + 1e-8), atol=1e-6)
+
+
+def test_two_steps_reduce_loss(cuda):
+    """a few optimiser steps on a fixed batch lower the loss (plumbing: grads reach the right variables)."""
+    from imgcomp_cvpr_amd import training, config_parser as cp, weights as W
+    ae, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'low'))
+    pc, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
+    ae.distortion_to_minimize = 'mse'
+    ae.lr_initial = 1e-3
+    tr = training.Trainer(ae, pc, W.synthetic_weights(ae, pc), cuda, num_itr_per_epoch=1000)
+    x = dev(W.synthetic_image((4, 3, 64, 64), 'natural', 2), cuda)
+    losses = [tr.step(x)['d_loss_scaled'] for _ in range(6)]
+    assert losses[-1] < losses[0], losses
+    assert all(np.isfinite(losses))
