@@ -1,0 +1,165 @@
+"""Training driver -- the train.py entry point of the reference (code/train.py) on the MI355X kernels.
+
+    python -m imgcomp_cvpr_amd.train AE_CONFIG PC_CONFIG [--log_dir_root DIR] [--dataset_train GLOB | --synthetic]
+                                     [--max_itr N] [--log_interval 100] [--save_interval 1000] [--restore FILE.npz]
+
+    multi-GPU (data parallel, one process per GPU, RCCL):
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \\
+           -m imgcomp_cvpr_amd.train AE_CONFIG PC_CONFIG --synthetic --max_itr 100
+
+What is kept from the reference: the config files and the `MMDD_HHMM cfg@path cfg@path` log-dir naming
+(logdir_helpers.py:34-56), the loss / optimiser recipe (training.py), random crops + horizontal flips of the
+training images (inputpipeline.py:199-213), img/s on the console (train.py:201-213,256), checkpoints every
+--save_interval iterations.  What is different: checkpoints are `.npz` files keyed by the TF variable names
+(the TF-1 bundle format is row N1 of the plan); the TF input queue is a plain loader; TensorBoard / Sheets logging
+is out of scope.  Under data parallelism the global batch of the config is split over the ranks; gradients are
+averaged with three bucketed RCCL all-reduces per step (training.GradBuckets), BatchNorm uses local statistics.
+"""
+import argparse
+import glob
+import os
+import time
+from datetime import datetime
+from os import path
+
+import numpy as np
+import torch
+
+from . import config_parser, sharding, training
+from . import weights as _weights
+
+
+def create_unique_log_dir(config_rel_paths, log_dir_root):
+    """`{MMDD_HHMM} {cfg paths with / -> @ and - -> *}` (logdir_helpers.py:34-56)."""
+    post = ' '.join(p.replace(path.sep, '@').replace('-', '*') for p in config_rel_paths)
+    os.makedirs(log_dir_root, exist_ok=True)
+    t = datetime.now()
+    while True:
+        d = path.join(log_dir_root, '{} {}'.format(t.strftime('%m%d_%H%M'), post))
+        if not any(n.split(' ')[0] == t.strftime('%m%d_%H%M') for n in os.listdir(log_dir_root)):
+            os.makedirs(d)
+            return d
+        t = t.replace(minute=(t.minute + 1) % 60, hour=(t.hour + (t.minute + 1) // 60) % 24)
+
+
+class CropLoader(object):
+    """random crop_size crops (+ random horizontal flip) of the images matching a glob, as (N,3,h,w) float 0..255
+    (inputpipeline.py:147-213).  `synthetic=True`: seeded synthetic images instead of files."""
+
+    def __init__(self, images_glob, crop_size, batch_size, seed=0, synthetic=False):
+        self.crop, self.batch = tuple(crop_size), batch_size
+        self.rs = np.random.RandomState(seed)
+        self.synthetic = synthetic
+        if synthetic:
+            self.images = [_weights.synthetic_image((1, 3, 2 * self.crop[0], 2 * self.crop[1]), 'natural', seed=1000 * seed + i)[0]
+                           for i in range(8)]
+        else:
+            self.paths = sorted(glob.glob(images_glob))
+            if not self.paths:
+                raise ValueError('Not matching any files: {}'.format(images_glob))
+            self.images = None
+
+    @property
+    def num_images(self):
+        return len(self.images) if self.synthetic else len(self.paths)
+
+    def _image(self, i):
+        if self.synthetic:
+            return self.images[i]
+        from PIL import Image
+        return np.transpose(np.asarray(Image.open(self.paths[i]).convert('RGB'), dtype=np.uint8), (2, 0, 1))
+
+    def get_batch(self):
+        out = np.empty((self.batch, 3) + self.crop, np.float32)
+        for b in range(self.batch):
+            im = self._image(self.rs.randint(self.num_images))
+            H, W = im.shape[1:]
+            if H < self.crop[0] or W < self.crop[1]:
+                raise ValueError('image smaller than crop size')
+            y, x = self.rs.randint(H - self.crop[0] + 1), self.rs.randint(W - self.crop[1] + 1)
+            c = im[:, y:y + self.crop[0], x:x + self.crop[1]]
+            out[b] = c[:, :, ::-1] if self.rs.rand() < 0.5 else c
+        return out
+
+
+def train(ae_config_path, pc_config_path, log_dir_root, loader_fn, max_itr, log_interval=100, save_interval=1000,
+          restore=None, device=None, verbose=True):
+    rank, world = sharding.rank_and_world()
+    ae_config, ae_rel = config_parser.parse(ae_config_path)
+    pc_config, pc_rel = config_parser.parse(pc_config_path)
+    device = device or 'cuda:{}'.format(torch.cuda.current_device())
+    batch_total = int(ae_config.batch_size)
+    if batch_total % world:
+        raise ValueError('batch_size {} not divisible by {} ranks'.format(batch_total, world))
+    loader = loader_fn(ae_config, batch_total // world, rank)
+    if restore:
+        with np.load(restore) as z:
+            weights = {k: z[k] for k in z.files}
+    else:
+        weights = _weights.synthetic_weights(ae_config, pc_config, gain=1.0, heatmap_bias=None)   # Xavier, as slim initialises
+        weights[_weights.ENC + '/centers'] = np.random.RandomState(666).uniform(
+            *map(float, ae_config.centers_initial_range), size=int(ae_config.num_centers)).astype(np.float32)
+    # every rank starts from identical variables (rank 0's)
+    num_itr_per_epoch = max(loader.num_images // max(batch_total, 1), 1)
+    tr = training.Trainer(ae_config, pc_config, weights, device, num_itr_per_epoch)
+    if world > 1:
+        import torch.distributed as dist
+        for t in tr.graph.params.values():
+            dist.broadcast(t, src=0)
+    log_dir = None
+    if rank == 0 and log_dir_root:
+        log_dir = create_unique_log_dir([ae_rel, pc_rel], log_dir_root)
+        os.makedirs(path.join(log_dir, 'ckpts'), exist_ok=True)
+        if verbose:
+            print('Log dir: {}'.format(log_dir))
+    t_last, n_last = time.time(), 0
+    hist = []
+    for itr in range(max_itr):
+        x = torch.as_tensor(loader.get_batch()).to(device)
+        out = tr.step(x)
+        hist.append(out)
+        if verbose and rank == 0 and (itr % log_interval == 0 or itr == max_itr - 1):
+            torch.cuda.synchronize()
+            dt = time.time() - t_last
+            ips = (itr + 1 - n_last) * batch_total / max(dt, 1e-9)
+            t_last, n_last = time.time(), itr + 1
+            print('{: 7d} | {} | {:.1f} img/s'.format(itr, ' '.join('{}: {:.4f}'.format(k, v) for k, v in out.items()), ips), flush=True)
+        if log_dir and (itr + 1) % save_interval == 0:
+            np.savez(path.join(log_dir, 'ckpts', 'ckpt-{}.npz'.format(itr + 1)), **tr.state_weights())
+    if log_dir:
+        np.savez(path.join(log_dir, 'ckpts', 'weights.npz'), **tr.state_weights())
+    return tr, hist, log_dir
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument('autoencoder_config_path')
+    p.add_argument('probclass_config_path')
+    p.add_argument('--log_dir_root', '-o', default='logs')
+    p.add_argument('--dataset_train', help='glob of training images')
+    p.add_argument('--synthetic', action='store_const', const=True, help='seeded synthetic images instead of files')
+    p.add_argument('--max_itr', type=int, default=1000)
+    p.add_argument('--log_interval', type=int, default=100)
+    p.add_argument('--save_interval', type=int, default=1000)
+    p.add_argument('--restore', help='.npz of variables to start from')
+    flags = p.parse_args(argv)
+    if 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        import torch.distributed as dist
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    if not flags.synthetic and not flags.dataset_train:
+        p.error('--dataset_train GLOB or --synthetic')
+
+    def loader_fn(ae_config, batch, rank):
+        return CropLoader(flags.dataset_train, ae_config.crop_size, batch, seed=rank, synthetic=bool(flags.synthetic))
+    here = path.dirname(path.abspath(__file__))
+
+    def resolve(pth, base):
+        return pth if path.isfile(pth) else path.join(here, base, pth)
+    train(resolve(flags.autoencoder_config_path, 'ae_configs'), resolve(flags.probclass_config_path, 'pc_configs'),
+          flags.log_dir_root, loader_fn, flags.max_itr, flags.log_interval, flags.save_interval, flags.restore)
+
+
+if __name__ == '__main__':
+    main()

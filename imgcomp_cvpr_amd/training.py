@@ -35,6 +35,38 @@ _IMG_MEAN = (121.85369873, 113.58860779, 100.63715363)
 _IMG_VAR = (4746.37695312, 4454.13964844, 4812.234375)
 
 
+class GradBuckets(object):
+    """Data-parallel gradient exchange over flat buckets: `ready(name)` starts an asynchronous all-reduce of that
+    bucket as soon as the caller has finished writing it, `wait()` blocks on all of them and turns the sums into
+    means.  Works on any process group (RCCL on the GPUs; gloo in the CPU tests).  World size 1: no-ops."""
+
+    def __init__(self, flat_tensors, process_group=None):
+        self.flat = flat_tensors            # dict name -> 1-D tensor
+        self.pg = process_group
+        self._pending = []
+
+    def _world(self):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1
+        return dist.get_world_size(self.pg)
+
+    def ready(self, name):
+        import torch.distributed as dist
+        world = self._world()
+        if world == 1:
+            return
+        # ProcessGroupNCCL orders the collective after the work already queued on the current stream
+        work = dist.all_reduce(self.flat[name], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self._pending.append((work, self.flat[name], world))
+
+    def wait(self):
+        for work, flat, world in self._pending:
+            work.wait()
+            flat.div_(world)
+        self._pending = []
+
+
 class _Layer(object):
     __slots__ = ('scope', 'kind', 'kh', 'kw', 'cin', 'cout', 'stride', 'group')
 
@@ -93,7 +125,7 @@ class TrainGraph(object):
         self.bn_ws = torch.empty(lib.ic_bn_workspace_bytes(256), dtype=torch.uint8, device=self.dev)
         self.packed3 = lib.ic_conv3x3_c128_packed_floats()
         self._ws = {}
-        self._pending = []
+        self.buckets = GradBuckets(self.flat_grads, process_group)
 
     # ------------------------------------------------------------------------------------------------
     # small helpers
@@ -361,7 +393,7 @@ class TrainGraph(object):
         self._cba_bwd(enc_tape_a.pop(), g, need_dx=False)
         self._bucket_ready('enc')
         self._wait_buckets()
-        out = {'d_loss_scaled': float(d_loss), 'pc_loss': pc_loss, 'H_real': float(H_real), 'H_mask': float(H_mask),
+        out = {'d_loss_scaled': float(d_loss.detach()), 'pc_loss': pc_loss, 'H_real': float(H_real), 'H_mask': float(H_mask),
                'bpp': float(bc.sum()) / (N * H * W)}
         if msssim is not None:
             out['ms_ssim'] = float(msssim)
@@ -409,7 +441,8 @@ class TrainGraph(object):
             return dx
         # logits (post-ReLU) -> g3 planar (N, L, C*h*w)
         g3 = self._new(N, L, C, h, w)
-        check(lib.ic_pc_dlogits_f32(ptr(logits), ptr(symbols), ptr(d_bc.contiguous()), ptr(g3), N, C * h * w, L, st))
+        d_bc = d_bc.contiguous()
+        check(lib.ic_pc_dlogits_f32(ptr(logits), ptr(symbols), ptr(d_bc), ptr(g3), N, C * h * w, L, st))
         wgrad(b2, None, g3, s3, k, L, C, h, w, False)
         gb2 = bwd_data(g3, s3, None, None, k, L, C, h, w, False)                               # (N,k,C+1,h+2,w+2)
         wgrad(b1, None, gb2, s2, k, k, C + 1, h + 2, w + 2, False)
@@ -420,22 +453,10 @@ class TrainGraph(object):
 
     # ---- data-parallel gradient exchange: three flat buckets, each reduced as soon as it is complete ----
     def _bucket_ready(self, group):
-        import torch.distributed as dist
-        if self.pg is None and not (dist.is_available() and dist.is_initialized()):
-            return
-        world = dist.get_world_size(self.pg)
-        if world == 1:
-            return
-        flat = self.flat_grads[group]
-        # ProcessGroupNCCL orders the collective after the work already queued on the current stream
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        self._pending.append((work, flat, world))
+        self.buckets.ready(group)
 
     def _wait_buckets(self):
-        for work, flat, world in self._pending:
-            work.wait()
-            flat.div_(world)
-        self._pending = []
+        self.buckets.wait()
 
 
 class TFAdam(object):

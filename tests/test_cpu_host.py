@@ -247,6 +247,54 @@ def test_image_sharding_over_gloo_world2(tmp_path):
         assert 'rank {} ok'.format(r) in o
 
 
+_BUCKET_WORKER = r'''
+import os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from imgcomp_cvpr_amd.training import GradBuckets
+rank = int(sys.argv[1])
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:{port}', rank=rank, world_size=2)
+flat = {{'pc': torch.full((5,), float(rank + 1)), 'dec': torch.arange(4.) * (rank + 1), 'enc': torch.ones(3) * (10 * rank)}}
+b = GradBuckets(flat)
+for name in ('pc', 'dec', 'enc'):        # same order on every rank, each launched as soon as "its backward is done"
+    b.ready(name)
+b.wait()
+assert torch.allclose(flat['pc'], torch.full((5,), 1.5)), flat['pc']
+assert torch.allclose(flat['dec'], torch.arange(4.) * 1.5), flat['dec']
+assert torch.allclose(flat['enc'], torch.ones(3) * 5.0), flat['enc']
+dist.barrier(); dist.destroy_process_group()
+print('rank', rank, 'buckets ok')
+'''
+
+
+def test_gradient_buckets_average_over_gloo_world2(tmp_path):
+    """the data-parallel gradient exchange of training.py (three flat buckets, async all-reduce, mean) on CPU."""
+    script = tmp_path / 'bworker.py'
+    script.write_text(_BUCKET_WORKER.format(root=ROOT, port=31000 + os.getpid() % 2000))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert 'rank {} buckets ok'.format(r) in o
+
+
+def test_train_host_logic(tmp_path):
+    from imgcomp_cvpr_amd import train, training, config_parser as cp
+    d1 = train.create_unique_log_dir(['ae_configs/cvpr/low', 'pc_configs/cvpr/res_shallow'], str(tmp_path))
+    d2 = train.create_unique_log_dir(['ae_configs/cvpr/low', 'pc_configs/cvpr/res_shallow'], str(tmp_path))
+    assert d1 != d2 and os.path.basename(d1).endswith('ae_configs@cvpr@low pc_configs@cvpr@res_shallow')
+    from imgcomp_cvpr_amd import val
+    assert val.is_log_date(os.path.basename(d1).split(' ')[0])
+    ld = train.CropLoader(None, (16, 24), 3, seed=1, synthetic=True)
+    b = ld.get_batch()
+    assert b.shape == (3, 3, 16, 24) and b.dtype == np.float32 and 0 <= b.min() and b.max() <= 255
+    ae, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'low'))
+    assert training.learning_rate(ae, 0, 10) == pytest.approx(8e-5) and training.learning_rate(ae, 20, 10) == pytest.approx(8e-6)
+    b1 = training.GradBuckets({'x': __import__('torch').ones(2)})
+    b1.ready('x'); b1.wait()                                  # world size 1: no-op
+
+
 def test_sharding_single_process():
     from imgcomp_cvpr_amd import sharding
     assert sharding.shard_indices(5, 1, 2) == [1, 3]

@@ -1,5 +1,7 @@
 """-m gpu: training-mode kernels (BatchNorm, filter gradients, quantiser / context-model backward) and one whole
 training step against the CPU oracle's autograd (oracle/train_oracle.py)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -217,3 +219,25 @@ def test_two_steps_reduce_loss(cuda):
     losses = [tr.step(x)['d_loss_scaled'] for _ in range(6)]
     assert losses[-1] < losses[0], losses
     assert all(np.isfinite(losses))
+
+
+def test_train_entry_point(cuda, tmp_path):
+    """python -m imgcomp_cvpr_amd.train on synthetic crops: runs, logs, writes an .npz checkpoint that val.py reads."""
+    from imgcomp_cvpr_amd import train, config_parser as cp, val, autoencoder
+    ae_p = cp.builtin_config_path('ae_configs', 'cvpr', 'low')
+    pc_p = cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow')
+    ae_over = tmp_path / 'ae_configs' / 'tiny'
+    ae_over.parent.mkdir()
+    ae_over.write_text('use {}\nbatch_size = 4\ncrop_size = (64, 64)\ndistortion_to_minimize = mse\n'.format(ae_p))
+
+    def loader_fn(ae_config, batch, rank):
+        return train.CropLoader(None, ae_config.crop_size, batch, seed=rank, synthetic=True)
+    tr, hist, log_dir = train.train(str(ae_over), pc_p, str(tmp_path / 'logs'), loader_fn, max_itr=3, log_interval=1,
+                                    save_interval=2, device=str(cuda), verbose=False)
+    assert len(hist) == 3 and all(np.isfinite(h['d_loss_scaled']) for h in hist)
+    assert os.path.isfile(os.path.join(log_dir, 'ckpts', 'ckpt-2.npz'))
+    wts = val.load_weights_for_job(log_dir, None, tr.graph.ae_config, tr.graph.pc_config)
+    assert set(wts) == set(tr.graph.params)
+    ae = autoencoder.get_network_cls(tr.graph.ae_config)(tr.graph.ae_config).load_weights(wts, cuda)
+    enc = ae.encode(torch.zeros((1, 3, 64, 64), device=cuda), is_training=False)       # inference on the trained variables
+    assert bool(torch.isfinite(enc.z).all())
