@@ -57,31 +57,27 @@ __global__ __launch_bounds__(64 * WA * WB) void conv_wgrad_kernel(const WgArgs a
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    constexpr int TROWS = NTH / 32;                            // thread rows; AT and BT are multiples of 32 >= TROWS
+    constexpr int RA = AT / TROWS, RB = BT / TROWS;            // U rows and V rows staged by each thread
+    static_assert(RA + RB == RPT, "row split");
     float st[RPT];
+    // channel validity and channel strides of this thread's rows do not depend on the chunk
     auto fetch = [&](int q0) {
         const int q = q0 + px;
         const bool live = q < q_end;
         const int qc = live ? q : q_begin;
+        size_t ubase, vbase;
+        unsigned ustride, vstride;
+        bool uok;
+        float qv = 0.f;
         if (!MODE3D) {
             const int n = qc / VHW, rem = qc - n * VHW;
             const int qy = rem / a.VW, qx = rem - qy * a.VW;
             const int iy = a.stride * qy + ty + a.oy0, ix = a.stride * qx + tx + a.ox0;
-            const bool uok = live && iy >= 0 && iy < a.UH && ix >= 0 && ix < a.UW;
-            const size_t ubase = (size_t)n * a.A * UHW + (uok ? iy * a.UW + ix : 0);
-            const size_t vbase = (size_t)n * a.B * VHW + rem;
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int r = trow + k * (NTH / 32);
-                float v = 0.f;
-                if (r < AT) {
-                    const int ch = a0 + r;
-                    if (uok && ch < a.A) v = a.U[ubase + (size_t)ch * UHW];
-                } else {
-                    const int ch = b0 + r - AT;
-                    if (live && ch < a.B) v = a.V[vbase + (size_t)ch * VHW];
-                }
-                st[k] = v;
-            }
+            uok = live && iy >= 0 && iy < a.UH && ix >= 0 && ix < a.UW;
+            ubase = (size_t)n * a.A * UHW + (uok ? iy * a.UW + ix : 0);
+            vbase = (size_t)n * a.B * VHW + rem;
+            ustride = UHW; vstride = VHW;
         } else {
             // position = (n, d, y, x) of the conv3d OUTPUT volume; the tap offset is never out of range (VALID)
             const int vvol = a.VD * VHW, uvol = a.UD * UHW;
@@ -90,32 +86,41 @@ __global__ __launch_bounds__(64 * WA * WB) void conv_wgrad_kernel(const WgArgs a
             const int y = r2 / a.VW, x = r2 - y * a.VW;
             const int t3 = a.taps[tap];
             const int ud = d + t3 / 9, uy = y + (t3 % 9) / 3, ux = x + t3 % 3;
-            const size_t ubase = (size_t)n * a.A * uvol + (size_t)ud * UHW + uy * a.UW + ux;
-            const size_t vbase = (size_t)n * a.B * vvol + rem;
-            float qv = 0.f;
+            uok = live;
+            ubase = (size_t)n * a.A * uvol + (size_t)ud * UHW + uy * a.UW + ux;
+            vbase = (size_t)n * a.B * vvol + rem;
+            ustride = uvol; vstride = vvol;
             if (a.q) {                                 // U = symbol volume padded on load (depth front 4, H/W 4 each side)
                 const int c = ud - 4, yy = uy - 4, xx = ux - 4;
                 const bool in = c >= 0 && yy >= 0 && yy < a.qh && xx >= 0 && xx < a.qw;
                 qv = in ? a.q[(((size_t)n * a.qC + c) * a.qh + yy) * a.qw + xx] : a.pad_value;
             }
+        }
+        // one 64-bit address per operand, then a constant step per staged row; rows of padded channels and padded
+        // positions are skipped (exec-masked), not loaded
+        const float* up = a.U + ubase + (size_t)(a0 + trow) * ustride;
+        const float* vp = a.V + vbase + (size_t)(b0 + trow) * vstride;
+        const size_t ustep = (size_t)TROWS * ustride, vstep = (size_t)TROWS * vstride;
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int r = trow + k * (NTH / 32);
-                float v = 0.f;
-                if (r < AT) {
-                    const int ch = a0 + r;
-                    if (live && ch < a.A) v = a.q ? qv : a.U[ubase + (size_t)ch * uvol];
-                } else {
-                    const int ch = b0 + r - AT;
-                    if (live && ch < a.B) v = a.V[vbase + (size_t)ch * vvol];
-                }
-                st[k] = v;
-            }
+        for (int k = 0; k < RA; ++k) {
+            const bool ok = uok && a0 + trow + k * TROWS < a.A;
+            float v = 0.f;
+            if (MODE3D && a.q) v = ok ? qv : 0.f;
+            else if (ok) v = *up;
+            up += ustep;
+            st[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+            float v = 0.f;
+            if (live && b0 + trow + k * TROWS < a.B) v = *vp;
+            vp += vstep;
+            st[RA + k] = v;
         }
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) lds[buf][(trow + k * (NTH / 32)) * WG_LS + px] = st[k];
+        for (int k = 0; k < RPT; ++k) lds[buf][(trow + k * TROWS) * WG_LS + px] = st[k];
     };
 
     fetch(q_begin);
@@ -177,7 +182,9 @@ static void wg_plan(int A, int B, long long P, int KH, int KW, int* TA, int* WA,
     *TB = tb_tiles >= 2 ? 2 : 1; *WB = tb_tiles > 2 ? 2 : 1;
     const int groups = ic_cdiv(A, 32 * *TA * *WA) * ic_cdiv(B, 32 * *TB * *WB);
     // aim at ~3 work-groups per CU; every slice covers a multiple of the chunk
-    long long want = (3 * 256 + (long long)KH * KW * groups - 1) / ((long long)KH * KW * groups);
+    const int waves = *WA * *WB;
+    // ~3 four-wave work-groups per CU; smaller work-groups (small channel counts) get proportionally more slices
+    long long want = (3 * 256 * 4 / waves + (long long)KH * KW * groups - 1) / ((long long)KH * KW * groups);
     long long maxs = (P + 4 * WG_KP - 1) / (4 * WG_KP);
     if (want > maxs) want = maxs;
     if (want < 1) want = 1;

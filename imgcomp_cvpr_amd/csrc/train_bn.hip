@@ -38,22 +38,25 @@ __device__ __forceinline__ void block_reduce2(double& a, double& b) {
 // MODE 0: (sum x, sum x^2)   MODE 1: (sum g, sum g * xhat)
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_stage1(const BnArgs a) {
+    // block (c, chunk): the channel's N planes are cut into tiles of 1024 positions, dealt round-robin to the chunks
+    // (one division per tile, none per element)
     const int c = blockIdx.x, chunk = blockIdx.y;
-    const long long M = (long long)a.N * a.HW;
-    const long long per = (M + BN_CHUNKS - 1) / BN_CHUNKS;
-    const long long lo = per * chunk, hi = lo + per < M ? lo + per : M;
+    const int tpp = (a.HW + 1023) / 1024, tiles = a.N * tpp;
     float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
     if (MODE == 1) { sc = a.scale[c]; sh = a.shift[c]; mu = a.mean[c]; is = a.invstd[c]; }
     double s0 = 0.0, s1 = 0.0;
-    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-        const long long n = i / a.HW, p = i - n * a.HW;
-        const size_t o = ((size_t)n * a.C + c) * a.HW + p;
-        const float xv = a.x[o];
-        if (MODE == 0) { s0 += xv; s1 += (double)xv * xv; }
-        else {
-            float g = a.dy[o];
-            if (a.relu && !(fmaf(xv, sc, sh) > 0.f)) g = 0.f;
-            s0 += g; s1 += (double)g * ((xv - mu) * is);
+    for (int t = chunk; t < tiles; t += BN_CHUNKS) {
+        const int n = t / tpp, p0 = (t - n * tpp) * 1024;
+        const size_t base = ((size_t)n * a.C + c) * a.HW;
+        const int hi = min(p0 + 1024, a.HW);
+        for (int p = p0 + threadIdx.x; p < hi; p += 256) {
+            const float xv = a.x[base + p];
+            if (MODE == 0) { s0 += xv; s1 += (double)xv * xv; }
+            else {
+                float g = a.dy[base + p];
+                if (a.relu && !(fmaf(xv, sc, sh) > 0.f)) g = 0.f;
+                s0 += g; s1 += (double)g * ((xv - mu) * is);
+            }
         }
     }
     block_reduce2(s0, s1);
@@ -79,30 +82,34 @@ __global__ void bn_reduce_stage2(const double* __restrict__ partial, int C, long
     }
 }
 
+// grid (plane chunks, N*C planes): one (n, c) plane per blockIdx.y -> channel constants are block-uniform
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ res1,
                                                        const float* __restrict__ res2, float* __restrict__ y,
                                                        int C, int HW, long long total, int relu) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int c = (int)((i / HW) % C);
-        float v = fmaf(x[i], scale[c], shift[c]);
+    const int c = blockIdx.y % C;
+    const float sc = scale[c], sh = shift[c];
+    const size_t base = (size_t)blockIdx.y * HW;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+        float v = fmaf(x[base + p], sc, sh);
         if (relu) v = fmaxf(v, 0.f);
-        if (res1) v += res1[i];
-        if (res2) v += res2[i];
-        y[i] = v;
+        if (res1) v += res1[base + p];
+        if (res2) v += res2[base + p];
+        y[base + p] = v;
     }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs a, long long total) {
     const double M = (double)a.N * a.HW;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int c = (int)((i / a.HW) % a.C);
-        const float xv = a.x[i];
-        float g = a.dy[i];
-        if (a.relu && !(fmaf(xv, a.scale[c], a.shift[c]) > 0.f)) g = 0.f;
-        const float xhat = (xv - a.mean[c]) * a.invstd[c];
-        const float mg = (float)(a.sums[c] / M), mgx = (float)(a.sums[a.C + c] / M);
-        a.out0[i] = a.gamma[c] * a.invstd[c] * (g - mg - xhat * mgx);
+    const int c = blockIdx.y % a.C;
+    const float sc = a.scale[c], sh = a.shift[c], mu = a.mean[c], is = a.invstd[c];
+    const float k = a.gamma[c] * is, mg = (float)(a.sums[c] / M), mgx = (float)(a.sums[a.C + c] / M);
+    const size_t base = (size_t)blockIdx.y * a.HW;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < a.HW; p += gridDim.x * 256) {
+        const float xv = a.x[base + p];
+        float g = a.dy[base + p];
+        if (a.relu && !(fmaf(xv, sc, sh) > 0.f)) g = 0.f;
+        a.out0[base + p] = k * (g - mg - (xv - mu) * is * mgx);
     }
 }
 
@@ -130,8 +137,8 @@ extern "C" int ic_bn_apply_f32(const float* x, const float* scale, const float* 
                                const float* res2, float* y, int N, int C, int HW, int relu, ic_stream_t stream) {
     IC_CHECK_ARG(x && scale && shift && y && N > 0 && C > 0 && HW > 0);
     const long long total = (long long)N * C * HW;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, res1, res2,
-                       y, C, HW, total, relu);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ic_cdiv(HW, 1024) < 1 ? 1 : ic_cdiv(HW, 1024), N * C), dim3(256), 0,
+                       (hipStream_t)stream, x, scale, shift, res1, res2, y, C, HW, total, relu);
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
@@ -152,7 +159,7 @@ extern "C" int ic_bn_backward_f32(const float* dy, const float* x, const float* 
     hipLaunchKernelGGL(bn_reduce_stage2<1>, dim3(ic_cdiv(C, 64)), dim3(64), 0, st, a.partial, C, (long long)N * HW, dbeta,
                        dgamma, sums);
     const long long total = (long long)N * C * HW;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, a, total);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ic_cdiv(HW, 1024) < 1 ? 1 : ic_cdiv(HW, 1024), N * C), dim3(256), 0, st, a, total);
     IC_LAUNCH_CHECK();
     return IC_OK;
 }

@@ -24,12 +24,33 @@ def _kernel1d(sigma, size):
     return g / np.sum(np.abs(g))
 
 
+_BANDS = {}
+
+
+def _band(n, k, dtype, device):
+    """(n, n - len(k) + 1) matrix B with B[i + j, i] = k[j]: right-multiplying by it is a 'VALID' correlation."""
+    key = (n, tuple(float(v) for v in k), dtype, str(device))
+    if key not in _BANDS:
+        _BANDS[key] = _make_band(n, k, dtype, device)
+    return _BANDS[key]
+
+
+def _make_band(n, k, dtype, device):
+    m = n - len(k) + 1
+    B = torch.zeros((n, m), dtype=dtype, device=device)
+    idx = torch.arange(m, device=device)
+    for j, kv in enumerate(k):
+        B[idx + j, idx] = float(kv)
+    return B
+
+
 def _separable_valid(img, k):
-    """depthwise 'VALID' correlation with the 1-D kernel k along W, then along H (img: NCHW)."""
-    c = img.shape[1]
-    kt = torch.as_tensor(np.asarray(k), dtype=img.dtype, device=img.device)
-    img = F.conv2d(img, kt.view(1, 1, 1, -1).expand(c, 1, 1, -1).contiguous(), groups=c)
-    return F.conv2d(img, kt.view(1, 1, -1, 1).expand(c, 1, -1, 1).contiguous(), groups=c)
+    """depthwise 'VALID' correlation with the 1-D kernel k along W, then along H (img: NCHW), written as two dense
+    matmuls against banded matrices (rocBLAS) -- depthwise F.conv2d falls onto MIOpen's naive kernels on ROCm."""
+    k = np.asarray(k, dtype=np.float64)
+    Bw = _band(img.shape[3], k, img.dtype, img.device)
+    Bh = _band(img.shape[2], k, img.dtype, img.device)
+    return torch.matmul(Bh.t(), torch.matmul(img, Bw))
 
 
 def _blur(img, sigma, size):
