@@ -181,10 +181,15 @@ static void wg_plan(int A, int B, long long P, int KH, int KW, int* TA, int* WA,
     *TA = ta_tiles >= 2 ? 2 : 1; *WA = ta_tiles > 2 ? 2 : 1;
     *TB = tb_tiles >= 2 ? 2 : 1; *WB = tb_tiles > 2 ? 2 : 1;
     const int groups = ic_cdiv(A, 32 * *TA * *WA) * ic_cdiv(B, 32 * *TB * *WB);
-    // aim at ~3 work-groups per CU; every slice covers a multiple of the chunk
+    // one full round of resident work-groups: a second, partly filled round costs a whole work-group time
+    // (711 work-groups on 512 slots ran as long as 1024 would have).  Residency is bounded by the LDS double buffer
+    // and by ~4 waves per SIMD of registers.
     const int waves = *WA * *WB;
-    // ~3 four-wave work-groups per CU; smaller work-groups (small channel counts) get proportionally more slices
-    long long want = (3 * 256 * 4 / waves + (long long)KH * KW * groups - 1) / ((long long)KH * KW * groups);
+    const int lds_bytes = 2 * 32 * (*TA * *WA + *TB * *WB) * WG_LS * 4;
+    int per_cu = 160 * 1024 / lds_bytes;
+    if (per_cu > 16 / waves) per_cu = 16 / waves;
+    if (per_cu < 1) per_cu = 1;
+    long long want = (256ll * per_cu) / ((long long)KH * KW * groups);
     long long maxs = (P + 4 * WG_KP - 1) / (4 * WG_KP);
     if (want > maxs) want = maxs;
     if (want < 1) want = 1;

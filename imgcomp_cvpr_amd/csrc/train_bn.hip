@@ -133,6 +133,45 @@ extern "C" int ic_bn_stats_f32(const float* x, float* mean, float* var, int N, i
     return IC_OK;
 }
 
+// stage 2 of the forward statistics with everything the host used to fold in a dozen tiny launches: invstd, the
+// folded scale/shift and the moving-average update (decay 0.9; TF's fused kernel feeds the UNBIASED variance to the
+// moving average while normalising with the biased one).
+__global__ void bn_train_fold_kernel(const double* __restrict__ partial, int C, long long M, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, float* __restrict__ moving_mean,
+                                     float* __restrict__ moving_var, float decay, float eps, float* __restrict__ mean,
+                                     float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < BN_CHUNKS; ++k) { s0 += partial[((size_t)c * BN_CHUNKS + k) * 2]; s1 += partial[((size_t)c * BN_CHUNKS + k) * 2 + 1]; }
+    const double m = s0 / (double)M;
+    double v = s1 / (double)M - m * m;
+    if (v < 0.0) v = 0.0;
+    const float mf = (float)m, vf = (float)v;
+    const float is = 1.0f / sqrtf(vf + eps);
+    const float sc = gamma[c] * is;
+    mean[c] = mf; invstd[c] = is; scale[c] = sc; shift[c] = beta[c] - mf * sc;
+    if (moving_mean) moving_mean[c] = moving_mean[c] * decay + mf * (1.f - decay);
+    if (moving_var) {
+        const float unbiased = vf * (float)((double)M / (double)(M > 1 ? M - 1 : 1));
+        moving_var[c] = moving_var[c] * decay + unbiased * (1.f - decay);
+    }
+}
+
+extern "C" int ic_bn_train_stats_f32(const float* x, const float* gamma, const float* beta, float* moving_mean,
+                                     float* moving_var, float decay, float eps, float* mean, float* invstd, float* scale,
+                                     float* shift, int N, int C, int HW, void* workspace, ic_stream_t stream) {
+    IC_CHECK_ARG(x && gamma && beta && mean && invstd && scale && shift && workspace && N > 0 && C > 0 && HW > 0);
+    BnArgs a{};
+    a.x = x; a.N = N; a.C = C; a.HW = HW; a.partial = (double*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_reduce_stage1<0>, dim3(C, BN_CHUNKS), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(bn_train_fold_kernel, dim3(ic_cdiv(C, 64)), dim3(64), 0, st, a.partial, C, (long long)N * HW, gamma,
+                       beta, moving_mean, moving_var, decay, eps, mean, invstd, scale, shift);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
 extern "C" int ic_bn_apply_f32(const float* x, const float* scale, const float* shift, const float* res1,
                                const float* res2, float* y, int N, int C, int HW, int relu, ic_stream_t stream) {
     IC_CHECK_ARG(x && scale && shift && y && N > 0 && C > 0 && HW > 0);

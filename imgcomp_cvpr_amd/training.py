@@ -222,21 +222,18 @@ class TrainGraph(object):
         l = self.layers[scope]
         raw = self._raw_forward(l, x)
         N, Cc, H, W = raw.shape
-        mean, var = self._new(Cc), self._new(Cc)
-        check(lib.ic_bn_stats_f32(ptr(raw), ptr(mean), ptr(var), N, Cc, H * W, ptr(self.bn_ws), self._st()))
-        gamma = self.params[scope + '/BatchNorm/gamma']
-        beta = self.params[scope + '/BatchNorm/beta']
-        invstd = torch.rsqrt(var + BN_EPS)
-        scale = gamma * invstd
-        shift = beta - mean * scale
+        stats = self._new(4, Cc)
+        mean, invstd, scale, shift = stats[0], stats[1], stats[2], stats[3]
+        # batch statistics, folded scale/shift and the moving-average update (decay 0.9) in one call
+        check(lib.ic_bn_train_stats_f32(ptr(raw), ptr(self.params[scope + '/BatchNorm/gamma']),
+                                        ptr(self.params[scope + '/BatchNorm/beta']),
+                                        ptr(self.params[scope + '/BatchNorm/moving_mean']),
+                                        ptr(self.params[scope + '/BatchNorm/moving_variance']), BN_DECAY, BN_EPS,
+                                        ptr(mean), ptr(invstd), ptr(scale), ptr(shift), N, Cc, H * W,
+                                        ptr(self.bn_ws), self._st()), 'bn statistics')
         y = self._new(N, Cc, H, W)
         check(lib.ic_bn_apply_f32(ptr(raw), ptr(scale), ptr(shift), ptr(res1), ptr(res2), ptr(y), N, Cc, H * W,
                                   int(relu), self._st()))
-        # moving statistics (decay 0.9; TF's fused kernel feeds the unbiased variance to the moving average)
-        M = N * H * W
-        mm, mv = self.params[scope + '/BatchNorm/moving_mean'], self.params[scope + '/BatchNorm/moving_variance']
-        mm.mul_(BN_DECAY).add_(mean, alpha=1 - BN_DECAY)
-        mv.mul_(BN_DECAY).add_(var, alpha=(1 - BN_DECAY) * M / max(M - 1, 1))
         if tape is not None:
             tape.append((l, x, raw, mean, invstd, scale, shift, relu))
         return y

@@ -177,6 +177,15 @@ int ic_ae_decode_f32(const float* q, const void* const* dec_tab_host, int B, int
                      float* x_out, int N, int H, int W,
                      void* workspace, size_t workspace_bytes, ic_stream_t stream);
 
+/* ic_bn_stats_f32 plus everything the training loop folds from it, in the same two launches:
+ *   mean, invstd = 1/sqrt(var + eps), scale = gamma * invstd, shift = beta - mean * scale   (all [C], outputs)
+ *   moving_mean / moving_var (optional, updated in place): m = m * decay + stat * (1 - decay), the variance fed to the
+ *   moving average being the unbiased one (slim.batch_norm fused=True, autoencoder.py:106-125).
+ * workspace: ic_bn_workspace_bytes(C). */
+int ic_bn_train_stats_f32(const float* x, const float* gamma, const float* beta, float* moving_mean,
+                          float* moving_var, float decay, float eps, float* mean, float* invstd, float* scale,
+                          float* shift, int N, int C, int HW, void* workspace, ic_stream_t stream);
+
 /* =============================================================================================
  * Training (train.py:101-106, :303-349): training-mode BatchNorm, backward kernels.
  * Forward in training mode = the conv entry points above with scale = 1, shift = 0, relu = 0 ("raw" conv),
