@@ -133,14 +133,20 @@ def main():
         yout = torch.empty_like(xin)
         wpk, sc, sh = ae._plan['autoencoder/encoder/res_block_enc_0/enc_0_1/conv2']
         def conv():
-            _lib.check(lib.ic_conv3x3_c128_bn_act_f32(_lib.ptr(xin), _lib.ptr(wpk), _lib.ptr(sc), _lib.ptr(sh),
-                                                      _lib.ptr(res), None, _lib.ptr(yout), N, h4, w4, 0, st))
+            _lib.check(lib.ic_conv3x3_c128_auto_f32(_lib.ptr(xin), _lib.ptr(wpk), _lib.ptr(sc), _lib.ptr(sh),
+                                                    _lib.ptr(res), None, _lib.ptr(yout), N, h4, w4, 0, st))
         ms_conv = timed(conv, 64)
         flop = CONV3_FLOP_PER_OUT_PX * N * h4 * w4
         achieved = flop / (ms_conv * 1e-3) / 1e12
-        roofline = {'kernel': 'conv3x3_c128_kernel (ic_conv3x3_c128_bn_act_f32)', 'bound': 'mfma',
+        wino = lib.ic_conv3x3_c128_pick_algo(N, h4, w4) == 1
+        # 'achieved' counts the ALGORITHMIC (direct-form) multiply-adds of the layer; the Winograd
+        # form issues 16/36 of them to the matrix cores -- 'executed_*' is what the MFMA pipe actually did.
+        executed = achieved * (16.0 / 36.0 if wino else 1.0)
+        roofline = {'kernel': ('wino3x3_c128_kernel' if wino else 'conv3x3_c128_kernel') + ' (ic_conv3x3_c128_auto_f32)',
+                    'algorithm': 'winograd F(2x2,3x3)' if wino else 'direct', 'bound': 'mfma',
                     'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                    'executed_tflops': round(executed, 2), 'executed_frac': round(executed / PEAK_F32_MFMA_TFLOPS, 4),
                     'avg_launch_us': round(ms_conv * 1e3, 2), 'flop_per_launch': flop,
                     'launches_per_step': 2 * (6 * int(ae_cfg.arch_param_B) + 2)}
         for e in ev:

@@ -163,7 +163,7 @@ class _CVPR(_Network):
         specs = _weights.ae_conv_specs(self._C, self._B, bool(cfg.heatmap))
         self._plan = {}           # scope -> (w_dev, scale_dev, shift_dev); keeps tensors alive
         enc_tab, dec_tab = [], []
-        packed_n = lib.ic_conv3x3_c128_packed_floats()
+        packed_n = lib.ic_conv3x3_c128_both_packed_floats()
         for scope, kind, shape in specs:
             w = self._params[scope + '/weights']
             scale, shift = fold_batch_norm(*(weights[scope + '/BatchNorm/' + k] for k in
@@ -176,7 +176,8 @@ class _CVPR(_Network):
             n_mfma = lib.ic_conv2d_mfma_packed_floats(kh, kw, cin, cout, stride, int(kind == 'deconv'))
             if kind == 'conv' and tuple(shape) == (3, 3, arch_param_n, arch_param_n):
                 wp = torch.empty(packed_n, dtype=torch.float32, device=dev)
-                check(lib.ic_pack_conv3x3_c128_f32(ptr(w), ptr(wp), st), 'ic_pack_conv3x3_c128_f32')
+                # direct-form and Winograd fragments side by side; the library picks the form per launch
+                check(lib.ic_pack_conv3x3_c128_both_f32(ptr(w), ptr(wp), 0, st), 'ic_pack_conv3x3_c128_both_f32')
                 w_use = wp
             elif n_mfma and not scope.endswith('/h1'):
                 # h2, to_bn, h12: matrix-core path, filter in MFMA fragment order

@@ -1,0 +1,392 @@
+// 3x3, stride 1, 128 -> 128 channel convolution of the residual stacks (autoencoder.py:224-234, :252-262: 32 of the 35
+// encoder convs and 32 of the 35 decoder layers) in Winograd F(2x2, 3x3) form on the fp32 matrix cores.
+//
+//   Y = At [ (G g Gt) (.) (Bt d B) ] A          g: 3x3 filter, d: 4x4 input patch, Y: 2x2 outputs ("tile")
+//
+// The channel contraction of the 16 transform positions is 16 independent GEMMs  M_p[co][tile] = sum_ci U_p[co][ci] V_p[ci][tile]
+// -- 16 / 36 of the multiply-adds of the direct form.  How it is laid onto a gfx950 wave:
+//
+//   * v_mfma_f32_32x32x2_f32 computes D[32 x 32] += A[32 x 2] B[2 x 32]; lane l supplies A[l & 31][l >> 5] and
+//     B[l >> 5][l & 31].  M axis = 32 output channels, N axis = 32 tiles, K = 2 input channels.
+//   * the B operand of position p is V_p[ci = 2 ks + (l >> 5)][tile = l & 31]: ONE input patch transform per lane yields
+//     the B operands of all 16 positions of that k-step.  Each lane loads the aligned pixel pair of its tile for the 4
+//     patch rows (coalesced dwordx2) and takes the two outer columns from its neighbour lanes by DPP row shifts, does
+//     the 32 add/subs of Bt d B in registers and feeds 16 MFMAs.  No LDS, no barrier: a wave never waits for another.
+//   * the A operands (transformed filters) are pre-packed in fragment order: 4 global_load_dwordx4 per k-step, each
+//     reading 1 KB contiguous across the wave (L2 resident, 1 MB per layer).
+//   * a wave owns (32 output channels) x (32 tiles) x (16 positions) = 16 accumulators of 16 registers = 256 AGPRs;
+//     the output transform At M A is then register-local (same lane, same register index across the 16 accumulators),
+//     followed by BN scale/shift, ReLU, residual adds and 8-byte stores (a tile row is 2 neighbouring pixels).
+//   * one wave per SIMD (512 registers): latency is hidden by a 4-stage register ring -- patch and filter fragments
+//     are requested 3 k-steps (~3000 clocks of MFMA work) before they are consumed.
+//   * work-group = 4 waves = the 4 output-channel tiles of the same 32 spatial tiles: the patch loads of the four
+//     waves hit the same lines (L1), the filter streams are disjoint.
+//
+// Rounding differs from the direct form (different summation tree); measured against the float64 oracle both stay
+// inside the 1e-4 parity bound (tests/test_gpu_ops.py).
+#include "common.h"
+#include "internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define WN_C 128
+#define WN_PACKED_FLOATS (16 * WN_C * WN_C)
+#define WN_STAGES 4
+#ifndef WN_ABL
+#define WN_ABL 0      // tuning builds only: 1 no patch loads, 2 no filter loads, 4 no transform in the main loop
+#endif
+
+struct WnArgs {
+    const float* x; const float* wp; const float* scale; const float* shift;
+    const float* res1; const float* res2; float* y;
+    int N, H, W, grows, gcols, relu;
+    unsigned long long* prof;   // tuning builds (WN_PROF) only
+};
+
+// ---- filter transform + packing -----------------------------------------------------------------------------------
+// U = G g Gt, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].
+// packed index: ((((cot * 64 + ks) * 4 + pos / 4) * 64 + lane) * 4 + pos % 4), cot = co / 32, ks = ci / 2,
+// lane = (ci & 1) * 32 + (co & 31): each of the 4 dwordx4 loads of a k-step reads 1 KB contiguous across the wave
+// (a 64-byte lane stride costs the L1 one line per lane and made the kernel L1-bound at 2200 clocks per k-step).
+// backward = 1 packs the adjoint (data-gradient) filter: g'[a][b][in = co][out = ci] = g[2 - a][2 - b][ci][co].
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w_tf, float* __restrict__ out, int backward) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;        // (in, out) pair
+    if (idx >= WN_C * WN_C) return;
+    const int cin = idx / WN_C, cout = idx % WN_C;
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            g[a][b] = backward ? w_tf[(((2 - a) * 3 + (2 - b)) * WN_C + cout) * WN_C + cin]
+                               : w_tf[((a * 3 + b) * WN_C + cin) * WN_C + cout];
+    float t[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+        t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+        t[3][b] = g[2][b];
+    }
+    float* o = out + (((size_t)(cout >> 5) * 64 + (cin >> 1)) * 4 * 64 + ((cin & 1) * 32 + (cout & 31))) * 4;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        f32x4 q = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
+        *(f32x4*)(o + a * 256) = q;
+    }
+}
+
+// ---- the convolution ----------------------------------------------------------------------------------------------
+// A wave owns 2 x 16 tiles (4 x 32 output pixels): a tile row is 16 lanes = one DPP row.
+__device__ __forceinline__ float dpp_from_left(float edge, float v) {    // lane i <- v of lane i-1; row lane 0 keeps edge
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x111, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_right(float edge, float v) {   // lane i <- v of lane i+1; row lane 15 keeps edge
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x101, 0xf, 0xf, false));
+}
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define WN_OOB 0x80000000u        // byte offset beyond any image (128 H W 4 < 2^31): the buffer load returns 0
+
+// VEC: even W, the pixel pair (2tx, 2tx+1) is one aligned 8-byte load.
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+template <bool VEC>
+__device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform (scalar) on purpose
+    const int lane = threadIdx.x & 63, li = lane & 31, kh = lane >> 5;
+    const int txl = li & 15;
+    const int ty = gy * 2 + (li >> 4), tx = gx * 16 + txl;
+    const int r0 = 2 * ty - 1;
+    const int H = a.H, W = a.W;
+    const int HW = H * W;
+
+    // All loads are raw buffer loads: descriptor + loop-invariant per-lane byte offset + per-k-step SCALAR offset, so
+    // the main loop has no vector address arithmetic; a padded position (row/column outside the image, tile outside
+    // the map) gets an out-of-range lane offset and the hardware returns 0 -- zero padding without a select, a clamp or
+    // a branch, and border work-groups run the same instruction stream as interior ones.
+    //
+    // Patch columns 2tx-1 .. 2tx+2: every lane loads its own aligned pair (2tx, 2tx+1); the outer two columns are the
+    // neighbour lanes' values (DPP row shift) except at the two ends of the 16-lane tile row, which load one extra
+    // dword per patch row.
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.x + (size_t)n * WN_C * HW), 0, WN_C * HW * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, WN_PACKED_FLOATS * 4, 0x00020000);
+    // VEC: the end-of-row value is fetched as the aligned pair that contains it -- lane 0: (2tx-2, 2tx-1), lane 15:
+    // (2tx+2, 2tx+3) -- so that each half is the 'old' operand of one DPP move and is overwritten in place (no copies).
+    const int ecol = VEC ? (txl == 0 ? 2 * tx - 2 : (txl == 15 ? 2 * tx + 2 : -1))
+                         : (txl == 0 ? 2 * tx - 1 : (txl == 15 ? 2 * tx + 2 : -1));
+    unsigned o0[4], o1[4], oe[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + i;
+        const bool rok = r >= 0 && r < H;
+        const unsigned rb = (unsigned)(kh * HW + r * W) * 4u;
+        o0[i] = (rok && 2 * tx < W) ? rb + 8u * tx : WN_OOB;
+        o1[i] = (rok && 2 * tx + 1 < W) ? rb + 8u * tx + 4u : WN_OOB;
+        oe[i] = (rok && ecol >= 0 && ecol < W) ? rb + 4u * ecol : WN_OOB;
+    }
+    const unsigned fo = lane * 16u;
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+    f32x2 pp[WN_STAGES][4];      // own pair of the 4 patch rows
+    f32x2 pe[WN_STAGES][4];      // end-of-row pair (only meaningful in lanes 0 / 15 of a tile row); !VEC: [0] only
+    f32x4 fl[WN_STAGES][4];
+
+    auto load_patch = [&](int s, int ks) {
+        const int so = ks * 2 * HW * 4;                     // scalar: channel pair 2 ks
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (VEC) {
+                pp[s][i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, o0[i], so, 0));
+                pe[s][i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, oe[i], so, 0));
+            } else {
+                pp[s][i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, o0[i], so, 0));
+                pp[s][i][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, o1[i], so, 0));
+                pe[s][i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, oe[i], so, 0));
+            }
+        }
+    };
+    auto load_filter = [&](int s, int ks) {
+        const int so = (wave * 64 + ks) * 4096;             // scalar: 4 KB per (channel tile, k-step)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            fl[s][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(fr, fo + q * 1024u, so, 0));
+    };
+
+    // (pinned in ring order: the wait counts at the loop head are the merge of this entry state and the back edge; a
+    // prologue load scheduled late would make every iteration wait for almost everything in flight)
+#pragma unroll
+    for (int s = 0; s < WN_STAGES - 1; ++s) {
+        load_patch(s, s);
+        __builtin_amdgcn_sched_barrier(0);
+        load_filter(s, s);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // Bt d B of one lane's patch -> the 16 B operands of a k-step.  Written on (x0, x1) / (left, right) pairs so that
+    // it maps onto packed fp32 adds: every vector instruction costs matrix-pipe time when there is one wave per SIMD.
+    auto transform = [&](int s, float (&v)[16]) {
+        f32x2 A[4], B[4];       // A = (x0, x1);  B = (right, left)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            A[i] = pp[s][i];
+            if (VEC) {
+                B[i][0] = dpp_from_right(pe[s][i][0], A[i][0]);
+                B[i][1] = dpp_from_left(pe[s][i][1], A[i][1]);
+            } else {
+                B[i][0] = dpp_from_right(pe[s][i][0], A[i][0]);
+                B[i][1] = dpp_from_left(pe[s][i][0], A[i][1]);
+            }
+        }
+        // rows: u0 = d0 - d2, u1 = d1 + d2, u2 = d2 - d1, u3 = d1 - d3 (on column pairs)
+        const f32x2 uA[4] = {pk_sub(A[0], A[2]), pk_add(A[1], A[2]), pk_sub(A[2], A[1]), pk_sub(A[1], A[3])};
+        const f32x2 uB[4] = {pk_sub(B[0], B[2]), pk_add(B[1], B[2]), pk_sub(B[2], B[1]), pk_sub(B[1], B[3])};
+        // columns (c0, c1, c2, c3) = (B.y, A.x, A.y, B.x): v0 = c0 - c2, v1 = c1 + c2, v2 = c2 - c1, v3 = c1 - c3
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x2 v30, v12;
+            // (v3, v0) = (A.x - B.x, B.y - A.y)
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v30) : "v"(uA[i]), "v"(uB[i]));
+            // (v1, v2) = (A.x + A.y, A.y - A.x)
+            asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(v12) : "v"(uA[i]));
+            v[4 * i] = v30[1]; v[4 * i + 1] = v12[0]; v[4 * i + 2] = v12[1]; v[4 * i + 3] = v30[0];
+        }
+    };
+
+    float v[2][16];
+    transform(0, v[0]);
+#ifdef WN_PROF
+    unsigned long long pd1 = 0, pd2 = 0, pd3 = 0, pt0 = __builtin_amdgcn_s_memtime();
+#endif
+    for (int k0 = 0; k0 < 64; k0 += WN_STAGES) {
+#pragma unroll
+        for (int s = 0; s < WN_STAGES; ++s) {
+            const int ks = k0 + s;
+            const int cur = s & 1, nxt = cur ^ 1;
+            // Request k-step ks + 3 into the ring slot whose filter was consumed one k-step ago and whose patch was
+            // transformed two k-steps ago.  Always issued (past the end it re-reads the last k-step) so the loop body
+            // is ONE basic block and outstanding loads are counted exactly.
+            const int sn = (s + WN_STAGES - 1) % WN_STAGES;
+            const int kn = ks + WN_STAGES - 1 < 64 ? ks + WN_STAGES - 1 : 63;
+            if (!(WN_ABL & 1)) load_patch(sn, kn);
+            if (!(WN_ABL & 2)) load_filter(sn, kn);
+            // the input transform of the NEXT k-step
+            transform((s + 1) % WN_STAGES, v[nxt]);
+#pragma unroll
+            for (int p = 0; p < 16; ++p)
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fl[s][p >> 2][p & 3], v[cur][p], acc[p], 0, 0, 0);
+            // Issue order inside the k-step: one memory request and a few transform instructions behind every MFMA.
+            // With one wave per SIMD nothing else can fill the issue slot, so whatever is not tucked behind a running
+            // MFMA is exposed; left alone, the scheduler sinks the loads next to their uses (to cut register pressure)
+            // and turns the ring into load-wait-use.
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // 1 MFMA
+                if (p < (VEC ? 12 : 16)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                 // a little VALU
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef WN_PROF
+            const unsigned long long q3 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+            pd1 += q3 - pt0; pt0 = q3;
+#endif
+        }
+    }
+#ifdef WN_PROF
+    if (a.prof && lane == 0) {
+        unsigned long long* d = a.prof + 4 * ((size_t)blockIdx.x * 4 + wave);
+        d[0] = pd1; d[1] = pd2; d[2] = pd3; d[3] = __builtin_amdgcn_s_memtime();
+    }
+#endif
+
+    // ---- At M A, BN fold, activation, residuals, store ----
+    const int oy = 2 * ty, ox = 2 * tx;
+    if (oy >= H || ox >= W) return;
+    const bool row1 = oy + 1 < H, col1 = ox + 1 < W;
+    const bool vec = col1 && ((W & 1) == 0);
+    const long long obase = (long long)n * WN_C * HW + (long long)oy * W + ox;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = 32 * wave + 8 * (r >> 2) + 4 * kh + (r & 3);
+        float t0[4], t1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float m0 = acc[j][r], m1 = acc[4 + j][r], m2 = acc[8 + j][r], m3 = acc[12 + j][r];
+            t0[j] = m0 + m1 + m2;
+            t1[j] = m1 - m2 - m3;
+        }
+        float o00 = t0[0] + t0[1] + t0[2], o01 = t0[1] - t0[2] - t0[3];
+        float o10 = t1[0] + t1[1] + t1[2], o11 = t1[1] - t1[2] - t1[3];
+        const float sc = a.scale[co], sh = a.shift[co];
+        o00 = fmaf(o00, sc, sh); o01 = fmaf(o01, sc, sh); o10 = fmaf(o10, sc, sh); o11 = fmaf(o11, sc, sh);
+        if (a.relu) { o00 = fmaxf(o00, 0.f); o01 = fmaxf(o01, 0.f); o10 = fmaxf(o10, 0.f); o11 = fmaxf(o11, 0.f); }
+        const long long o = obase + (long long)co * HW;
+        if (vec) {
+            f32x2 q0 = {o00, o01}, q1 = {o10, o11};
+            if (a.res1) {
+                const f32x2 e0 = *(const f32x2*)(a.res1 + o);
+                q0 += e0;
+                if (row1) q1 += *(const f32x2*)(a.res1 + o + W);
+            }
+            if (a.res2) {
+                const f32x2 e0 = *(const f32x2*)(a.res2 + o);
+                q0 += e0;
+                if (row1) q1 += *(const f32x2*)(a.res2 + o + W);
+            }
+            *(f32x2*)(a.y + o) = q0;
+            if (row1) *(f32x2*)(a.y + o + W) = q1;
+        } else {
+            if (a.res1) {
+                o00 += a.res1[o];
+                if (col1) o01 += a.res1[o + 1];
+                if (row1) { o10 += a.res1[o + W]; if (col1) o11 += a.res1[o + W + 1]; }
+            }
+            if (a.res2) {
+                o00 += a.res2[o];
+                if (col1) o01 += a.res2[o + 1];
+                if (row1) { o10 += a.res2[o + W]; if (col1) o11 += a.res2[o + W + 1]; }
+            }
+            a.y[o] = o00;
+            if (col1) a.y[o + 1] = o01;
+            if (row1) { a.y[o + W] = o10; if (col1) a.y[o + W + 1] = o11; }
+        }
+    }
+}
+
+// VEC = even W (aligned pixel pairs); odd widths get their own kernel.
+template <bool VEC>
+__global__ __launch_bounds__(256) void wino3x3_c128_kernel(const WnArgs a) {
+    const int gx = blockIdx.x % a.gcols;
+    const int t = blockIdx.x / a.gcols;
+    wino_body<VEC>(a, t / a.grows, t % a.grows, gx);
+}
+
+extern "C" size_t ic_wino3x3_c128_packed_floats(void) { return WN_PACKED_FLOATS; }
+
+extern "C" int ic_pack_wino3x3_c128_f32(const float* w_tf, float* w_packed, int backward, ic_stream_t stream) {
+    IC_CHECK_ARG(w_tf && w_packed);
+    hipLaunchKernelGGL(wino_pack_kernel, dim3(WN_C * WN_C / 256), dim3(256), 0, (hipStream_t)stream, w_tf, w_packed, backward);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
+static unsigned long long* g_wino_prof = nullptr;
+// tuning only: key 0 = device buffer (as two 32-bit halves: key 0 low, key 1 high) for WN_PROF builds
+extern "C" void ic_wino3x3_c128_set_tuning(int key, int value) {
+    static unsigned long long bits = 0;
+    if (key == 0) bits = (bits & 0xffffffff00000000ull) | (unsigned)value;
+    if (key == 1) { bits = (bits & 0xffffffffull) | ((unsigned long long)(unsigned)value << 32); g_wino_prof = (unsigned long long*)bits; }
+}
+
+extern "C" int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
+                                          const float* res1, const float* res2, float* y, int N, int H, int W, int relu,
+                                          ic_stream_t stream) {
+    IC_CHECK_ARG(x && w_packed && scale && shift && y);
+    IC_CHECK_ARG(N > 0 && H > 0 && W > 0);
+    if ((long long)WN_C * H * W * 4 >= (1ll << 31)) return IC_ERR_UNSUPPORTED;    // per-image byte offsets are 31-bit
+    WnArgs a{};
+    a.x = x; a.wp = w_packed; a.scale = scale; a.shift = shift; a.res1 = res1; a.res2 = res2; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.relu = relu;
+    a.grows = ic_cdiv(H, 4); a.gcols = ic_cdiv(W, 32); a.prof = g_wino_prof;
+    const dim3 grid((unsigned)((long long)N * a.grows * a.gcols));
+    if ((W & 1) == 0) hipLaunchKernelGGL(wino3x3_c128_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(wino3x3_c128_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
+// ---- both forms behind one packed filter: what the network / training entry points use ---------------------------------
+// blob = [direct-form fragments (ic_conv3x3_c128_packed_floats) | Winograd fragments (16 x 128 x 128)].
+// The form is picked per launch from the shape: the Winograd kernel runs one wave per SIMD and needs ~43 us whatever
+// the map size (64 k-steps x ~1230 clocks), so small maps stay on the direct kernel.
+static int g_algo = -1;   // -1 automatic, 0 direct, 1 Winograd
+extern "C" int ic_conv3x3_c128_set_algo(int algo) { const int prev = g_algo; g_algo = algo; return prev; }
+
+extern "C" size_t ic_conv3x3_c128_both_packed_floats(void) { return ic_conv3x3_c128_packed_floats() + WN_PACKED_FLOATS; }
+
+extern "C" int ic_pack_conv3x3_c128_both_f32(const float* w_tf, float* w_packed, int backward, ic_stream_t stream) {
+    IC_CHECK_ARG(w_tf && w_packed);
+    int rc = backward ? ic_pack_conv3x3_c128_bwd_f32(w_tf, w_packed, stream) : ic_pack_conv3x3_c128_f32(w_tf, w_packed, stream);
+    if (rc) return rc;
+    return ic_pack_wino3x3_c128_f32(w_tf, w_packed + ic_conv3x3_c128_packed_floats(), backward, stream);
+}
+
+extern "C" int ic_conv3x3_c128_pick_algo(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    if ((long long)WN_C * H * W * 4 >= (1ll << 31)) return 0;
+    if (g_algo >= 0) return g_algo;
+    const long long groups = (long long)N * ic_cdiv(H, 4) * ic_cdiv(W, 32);
+    const double rounds = (double)((groups + 255) / 256);
+    const double wino_us = rounds * (groups > 128 ? 52.0 : 43.0);           // full chip: lower clocks
+    const double direct_us = 2.0 * 9 * WN_C * WN_C * (double)N * H * W / 1.05e8 + 8.0;
+    return wino_us < direct_us ? 1 : 0;
+}
+
+extern "C" int ic_conv3x3_c128_auto_f32(const float* x, const float* w_both, const float* scale, const float* shift,
+                                        const float* res1, const float* res2, float* y, int N, int H, int W, int relu,
+                                        ic_stream_t stream) {
+    IC_CHECK_ARG(x && w_both && scale && shift && y && N > 0 && H > 0 && W > 0);
+    if (ic_conv3x3_c128_pick_algo(N, H, W) == 1)
+        return ic_wino3x3_c128_bn_act_f32(x, w_both + ic_conv3x3_c128_packed_floats(), scale, shift, res1, res2, y, N, H, W,
+                                          relu, stream);
+    return ic_conv3x3_c128_bn_act_f32(x, w_both, scale, shift, res1, res2, y, N, H, W, relu, stream);
+}

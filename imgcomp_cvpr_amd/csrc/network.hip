@@ -5,7 +5,7 @@
 #include "internal.h"
 
 // ---- residual stack shared by encoder and decoder (autoencoder.py:224-234 / :252-262) ----
-// tab: 3 pointers {packed filter, scale, shift} per conv, 6B+2 convs.  bufs[0] holds the stack input
+// tab: 3 pointers {packed filter (both forms, ic_pack_conv3x3_c128_both_f32), scale, shift} per conv, 6B+2 convs.  bufs[0] holds the stack input
 // (kept for the global skip), bufs[4] is the temporary.  Returns the buffer index holding the output.
 static int res_stack(const void* const* tab, int B, float* const bufs[5], int N, int H, int W,
                      hipStream_t st, int* out_idx) {
@@ -18,9 +18,9 @@ static int res_stack(const void* const* tab, int B, float* const bufs[5], int N,
             while (O == G || O == cur) ++O;              // one of {1,2,3} is always free
             const float* const* l1 = (const float* const*)tab + 3 * li;
             const float* const* l2 = l1 + 3;
-            if ((rc = ic_conv3x3_c128_bn_act_f32(bufs[cur], l1[0], l1[1], l1[2], nullptr, nullptr, T, N, H, W, 1, st)))
+            if ((rc = ic_conv3x3_c128_auto_f32(bufs[cur], l1[0], l1[1], l1[2], nullptr, nullptr, T, N, H, W, 1, st)))
                 return rc;
-            if ((rc = ic_conv3x3_c128_bn_act_f32(T, l2[0], l2[1], l2[2], bufs[cur], i == 2 ? bufs[G] : nullptr,
+            if ((rc = ic_conv3x3_c128_auto_f32(T, l2[0], l2[1], l2[2], bufs[cur], i == 2 ? bufs[G] : nullptr,
                                                  bufs[O], N, H, W, 0, st)))
                 return rc;
             cur = O; li += 2;
@@ -32,9 +32,9 @@ static int res_stack(const void* const* tab, int B, float* const bufs[5], int N,
         while (O == cur) ++O;
         const float* const* l1 = (const float* const*)tab + 3 * li;
         const float* const* l2 = l1 + 3;
-        if ((rc = ic_conv3x3_c128_bn_act_f32(bufs[cur], l1[0], l1[1], l1[2], nullptr, nullptr, T, N, H, W, 0, st)))
+        if ((rc = ic_conv3x3_c128_auto_f32(bufs[cur], l1[0], l1[1], l1[2], nullptr, nullptr, T, N, H, W, 0, st)))
             return rc;
-        if ((rc = ic_conv3x3_c128_bn_act_f32(T, l2[0], l2[1], l2[2], bufs[cur], bufs[0], bufs[O], N, H, W, 0, st)))
+        if ((rc = ic_conv3x3_c128_auto_f32(T, l2[0], l2[1], l2[2], bufs[cur], bufs[0], bufs[O], N, H, W, 0, st)))
             return rc;
         cur = O;
     }

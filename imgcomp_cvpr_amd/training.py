@@ -123,7 +123,7 @@ class TrainGraph(object):
         self.img_mean = torch.tensor(_IMG_MEAN, device=self.dev)
         self.img_std = torch.sqrt(torch.tensor(_IMG_VAR, device=self.dev) + 1e-10)
         self.bn_ws = torch.empty(lib.ic_bn_workspace_bytes(256), dtype=torch.uint8, device=self.dev)
-        self.packed3 = lib.ic_conv3x3_c128_packed_floats()
+        self.packed3 = lib.ic_conv3x3_c128_both_packed_floats()
         self._ws = {}
         self.buckets = GradBuckets(self.flat_grads, process_group)
 
@@ -147,10 +147,9 @@ class TrainGraph(object):
     def _conv3x3(self, x, w_tf, backward=False):
         N, _, H, W = x.shape
         wp = self._new(self.packed3)
-        f = lib.ic_pack_conv3x3_c128_bwd_f32 if backward else lib.ic_pack_conv3x3_c128_f32
-        check(f(ptr(w_tf), ptr(wp), self._st()))
+        check(lib.ic_pack_conv3x3_c128_both_f32(ptr(w_tf), ptr(wp), int(backward), self._st()))
         y = self._new(N, 128, H, W)
-        check(lib.ic_conv3x3_c128_bn_act_f32(ptr(x), ptr(wp), ptr(self.ones), ptr(self.zeros), None, None, ptr(y),
+        check(lib.ic_conv3x3_c128_auto_f32(ptr(x), ptr(wp), ptr(self.ones), ptr(self.zeros), None, None, ptr(y),
                                              N, H, W, 0, self._st()), 'conv3x3')
         return y
 

@@ -88,6 +88,32 @@ int ic_conv3x3_c128_set_tuning(int key, int value);
  * {start, prologue done, main loop done, end}; NULL disables (default). */
 void ic_conv3x3_c128_set_debug_buffer(void* dev_u64);
 
+/* The same layer (3x3, stride 1, 128 -> 128, autoencoder.py:274-287) in Winograd F(2x2,3x3) form: 16/36 of the
+ * multiply-adds of the direct form, each wave transforming its own input patches in registers (no LDS, no barrier).
+ * Same contract as ic_conv3x3_c128_bn_act_f32 with its own packed filter (16 x 128 x 128 floats = G g Gt in MFMA
+ * A-fragment order); backward != 0 packs the adjoint filter used for the data gradient in training.
+ * Results differ from the direct form by fp32 rounding only (both within 1e-4 of the float64 oracle). */
+size_t ic_wino3x3_c128_packed_floats(void);
+int ic_pack_wino3x3_c128_f32(const float* w_tf, float* w_packed, int backward, ic_stream_t stream);
+int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale,
+                               const float* shift, const float* res1, const float* res2, float* y,
+                               int N, int H, int W, int relu, ic_stream_t stream);
+/* tuning only (profiling builds). */
+void ic_wino3x3_c128_set_tuning(int key, int value);
+
+/* Both forms behind ONE packed filter [direct fragments | Winograd fragments]; this is what ic_ae_encode_f32 /
+ * ic_ae_decode_f32 expect in their tables for the 3x3 layers and what the training step uses (backward != 0: adjoint).
+ * ic_conv3x3_c128_auto_f32 picks the form per launch from (N, H, W) -- ic_conv3x3_c128_pick_algo returns the choice
+ * (0 direct, 1 Winograd); ic_conv3x3_c128_set_algo(-1 | 0 | 1) overrides it process-wide (tests, benchmarks) and
+ * returns the previous setting. */
+size_t ic_conv3x3_c128_both_packed_floats(void);
+int ic_pack_conv3x3_c128_both_f32(const float* w_tf, float* w_packed, int backward, ic_stream_t stream);
+int ic_conv3x3_c128_pick_algo(int N, int H, int W);
+int ic_conv3x3_c128_set_algo(int algo);
+int ic_conv3x3_c128_auto_f32(const float* x, const float* w_both, const float* scale, const float* shift,
+                             const float* res1, const float* res2, float* y, int N, int H, int W, int relu,
+                             ic_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * MFMA path for the strided 5x5 layers around the residual stacks: h2 (autoencoder.py:223, conv 64->128),
  * to_bn (:237, conv 128->C+1) and h12 (:264, transposed conv 128->64).  Filters are re-ordered once by

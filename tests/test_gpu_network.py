@@ -20,6 +20,15 @@ def nets(cuda, configs, syn_weights):
     return ae, pc
 
 
+@pytest.fixture(params=[0, 1], ids=['direct3x3', 'winograd3x3'])
+def algo(request):
+    """force one form of the 3x3 layers for the whole network (the default picks per launch from the shape)."""
+    from imgcomp_cvpr_amd import _lib
+    prev = _lib.lib.ic_conv3x3_c128_set_algo(request.param)
+    yield request.param
+    _lib.lib.ic_conv3x3_c128_set_algo(prev)
+
+
 def _boundary_margin(z64, centers):
     """distance of every z to the nearest quantiser decision midpoint (float64)."""
     c = np.sort(np.asarray(centers, np.float64))
@@ -28,7 +37,7 @@ def _boundary_margin(z64, centers):
 
 
 @pytest.mark.parametrize('shape,kind', [((1, 3, 64, 64), 'natural'), ((2, 3, 40, 72), 'noise')])
-def test_encode_matches_oracle(cuda, configs, syn_weights, nets, shape, kind):
+def test_encode_matches_oracle(cuda, configs, syn_weights, nets, shape, kind, algo):
     from imgcomp_cvpr_amd import weights as W
     from oracle import oracle as O
     ae, pc = nets
@@ -56,7 +65,7 @@ def test_encode_matches_oracle(cuda, configs, syn_weights, nets, shape, kind):
 
 
 @pytest.mark.parametrize('shape', [(1, 32, 8, 8), (2, 32, 5, 9)])
-def test_decode_matches_oracle(cuda, configs, syn_weights, nets, shape):
+def test_decode_matches_oracle(cuda, configs, syn_weights, nets, shape, algo):
     from oracle import oracle as O
     ae, _ = nets
     ae_cfg, _ = configs
@@ -76,7 +85,7 @@ def test_decode_matches_oracle(cuda, configs, syn_weights, nets, shape):
     assert not bool(((u_hip != u_ref) & ~near_int).any())
 
 
-def test_val_wiring(cuda, configs, syn_weights, nets):
+def test_val_wiring(cuda, configs, syn_weights, nets, algo):
     """encode -> decode(qhard) ; bitcost(qbar, symbols, pad=centers[0]) -> bpp (val.py:85-89)."""
     from imgcomp_cvpr_amd import bits, weights as W
     from oracle import oracle as O
@@ -105,7 +114,7 @@ def test_val_wiring(cuda, configs, syn_weights, nets):
     assert abs(float(bits.bitcost_to_bpp(bc2, xd)) - bpp) < 1e-3
 
 
-def test_full_size_properties(cuda, configs, syn_weights, nets):
+def test_full_size_properties(cuda, configs, syn_weights, nets, algo):
     """BASELINE configs[1] shape (Kodak 512x768, batch 1): size-independent properties --
     determinism, batch-independence (image n of a batch == the image alone), tile-variant independence."""
     from imgcomp_cvpr_amd import weights as W, _lib

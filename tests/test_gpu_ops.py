@@ -158,6 +158,79 @@ def test_conv3x3_c128_mfma(cuda, variant, N, H, W):
         L.lib.ic_conv3x3_c128_set_variant(prev)
 
 
+@pytest.mark.parametrize('shape', [-1, 0, 1])
+@pytest.mark.parametrize('N,H,W', [(1, 16, 64), (2, 13, 21), (1, 7, 5), (1, 40, 72)])
+def test_conv3x3_c128_winograd(cuda, shape, N, H, W):
+    """the Winograd F(2x2,3x3) form of the same layer: interior and border groups, odd sizes, ReLU / residuals,
+    and the adjoint packing (data gradient) against the adjoint of the oracle's conv."""
+    L = _lib()
+    rs = np.random.RandomState(300 + H)
+    x = rs.normal(0, 1, (N, 128, H, W)).astype(np.float32)
+    w = rs.normal(0, 0.05, (3, 3, 128, 128)).astype(np.float32)
+    scale, shift = _bn(rs, 128)
+    r1 = rs.normal(0, 1, (N, 128, H, W)).astype(np.float32)
+    r2 = rs.normal(0, 1, (N, 128, H, W)).astype(np.float32)
+    d = lambda a: dev(a, cuda)
+    xd, wd, sd, hd, r1d, r2d = d(x), d(w), d(scale), d(shift), d(r1), d(r2)
+    wp = torch.empty(L.lib.ic_wino3x3_c128_packed_floats(), device=cuda)
+    L.check(L.lib.ic_pack_wino3x3_c128_f32(L.ptr(wd), L.ptr(wp), 0, L.current_stream()))
+    L.lib.ic_wino3x3_c128_set_tuning(0, shape)
+    try:
+        for relu, res in ((1, ()), (0, (r1d,)), (0, (r1d, r2d))):
+            y = torch.full((N, 128, H, W), float('nan'), device=cuda)
+            L.check(L.lib.ic_wino3x3_c128_bn_act_f32(
+                L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(res[0]) if len(res) > 0 else None,
+                L.ptr(res[1]) if len(res) > 1 else None, L.ptr(y), N, H, W, relu, L.current_stream()))
+            torch.cuda.synchronize()
+            ref = _ref_conv(x, w, scale, shift, 1, relu, res=[r.cpu().numpy() for r in res])
+            assert_close(y, ref, 'winograd shape {} relu {} nres {}'.format(shape, relu, len(res)))
+        # adjoint packing: conv with the flipped, channel-swapped filter
+        L.check(L.lib.ic_pack_wino3x3_c128_f32(L.ptr(wd), L.ptr(wp), 1, L.current_stream()))
+        ones, zeros = torch.ones(128, device=cuda), torch.zeros(128, device=cuda)
+        y = torch.full((N, 128, H, W), float('nan'), device=cuda)
+        L.check(L.lib.ic_wino3x3_c128_bn_act_f32(L.ptr(xd), L.ptr(wp), L.ptr(ones), L.ptr(zeros), None, None, L.ptr(y),
+                                                 N, H, W, 0, L.current_stream()))
+        torch.cuda.synchronize()
+        w_adj = np.ascontiguousarray(w[::-1, ::-1].transpose(0, 1, 3, 2))
+        ref = _ref_conv(x, w_adj, np.ones(128, np.float32), np.zeros(128, np.float32), 1, 0)
+        assert_close(y, ref, 'winograd adjoint shape {}'.format(shape))
+    finally:
+        L.lib.ic_wino3x3_c128_set_tuning(0, -1)
+
+
+def test_conv3x3_c128_auto_selection(cuda):
+    """one packed blob, both forms: the shape rule keeps small maps on the direct kernel, sends chip-filling ones to
+    Winograd, the override works, and both give the oracle's result through the same entry point."""
+    L = _lib()
+    assert L.lib.ic_conv3x3_c128_both_packed_floats() == 9 * 128 * 128 + 16 * 128 * 128
+    assert L.lib.ic_conv3x3_c128_pick_algo(1, 16, 16) == 0
+    assert L.lib.ic_conv3x3_c128_pick_algo(1, 128, 192) == 1
+    assert L.lib.ic_conv3x3_c128_pick_algo(32, 32, 32) == 1
+    N, H, W = 1, 24, 40
+    rs = np.random.RandomState(7)
+    x = rs.normal(0, 1, (N, 128, H, W)).astype(np.float32)
+    w = rs.normal(0, 0.05, (3, 3, 128, 128)).astype(np.float32)
+    scale, shift = _bn(rs, 128)
+    xd, wd, sd, hd = dev(x, cuda), dev(w, cuda), dev(scale, cuda), dev(shift, cuda)
+    wp = torch.empty(L.lib.ic_conv3x3_c128_both_packed_floats(), device=cuda)
+    L.check(L.lib.ic_pack_conv3x3_c128_both_f32(L.ptr(wd), L.ptr(wp), 0, L.current_stream()))
+    ref = _ref_conv(x, w, scale, shift, 1, 1)
+    outs = []
+    for algo in (0, 1):
+        prev = L.lib.ic_conv3x3_c128_set_algo(algo)
+        try:
+            assert L.lib.ic_conv3x3_c128_pick_algo(N, H, W) == algo
+            y = torch.full((N, 128, H, W), float('nan'), device=cuda)
+            L.check(L.lib.ic_conv3x3_c128_auto_f32(L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), None, None, L.ptr(y),
+                                                   N, H, W, 1, L.current_stream()))
+            torch.cuda.synchronize()
+            assert_close(y, ref, 'auto entry, algo {}'.format(algo))
+            outs.append(y)
+        finally:
+            L.lib.ic_conv3x3_c128_set_algo(prev)
+    assert not torch.equal(outs[0], outs[1]), 'the override did not switch kernels'
+
+
 def test_conv3x3_mfma_matches_direct_kernel(cuda):
     """the two implementations of the same op agree (independent code paths on the device)."""
     L = _lib()
