@@ -73,11 +73,19 @@ def main():
     x = torch.as_tensor(x_np).float().to(dev)
     pad_value = float(wts['autoencoder/encoder/centers'][0])
 
+    # The context model and the decoder both hang off the encoder output and do not depend on each other (val.py:85-89):
+    # the bitcost goes on a second HIP stream and fills the CUs the decoder's one-wave-per-SIMD convs leave idle.
+    side = torch.cuda.Stream(device=dev)
+
     def step():
+        cur = torch.cuda.current_stream(dev)
         enc = ae.encode(x, is_training=False)
-        bc = pc.bitcost(enc.qbar, enc.symbols, is_training=False, pad_value=pad_value)
-        bpp = bits.bitcost_to_bpp(bc, x)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            bc = pc.bitcost(enc.qbar, enc.symbols, is_training=False, pad_value=pad_value)
+            bpp = bits.bitcost_to_bpp(bc, x)
         x_out = ae.decode(enc.qhard, is_training=False)
+        cur.wait_stream(side)
         return bpp, x_out
 
     def barrier():

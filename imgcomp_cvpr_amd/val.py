@@ -166,14 +166,20 @@ class Fetcher(object):
             weights, self.device)
         self.pc_config = pc_config
         self._bpp_fetcher = None
+        self._side = torch.cuda.Stream(device=self.device)
 
     def __call__(self, img_chw_uint8, want_symbols=False, want_image=False):
         x_uint8 = torch.as_tensor(img_chw_uint8)[None]
         x = x_uint8.to(self.device).float()
         enc = self.ae.encode(x, is_training=False)
+        # decoder and context model are independent consumers of the encoder output: run them on two streams
+        cur = torch.cuda.current_stream(self.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            bc = self.pc.bitcost(enc.qbar, enc.symbols, is_training=False, pad_value=self.pc.auto_pad_value(self.ae))
+            bpp = bits.bitcost_to_bpp(bc, x)
         x_out = self.ae.decode(enc.qhard, is_training=False)
-        bc = self.pc.bitcost(enc.qbar, enc.symbols, is_training=False, pad_value=self.pc.auto_pad_value(self.ae))
-        bpp = bits.bitcost_to_bpp(bc, x)
+        cur.wait_stream(self._side)
         x_out_uint8 = x_out.to(torch.uint8).cpu().numpy()          # tf.cast truncates (val.py:91)
         otp = {'bpp': float(bpp),
                'ms-ssim': float(metrics.msssim_nchw_uint8(x_uint8.numpy(), x_out_uint8)),
