@@ -205,7 +205,8 @@ class _CVPR(_Network):
 
     def _encode(self, x, is_training):
         if is_training:
-            raise NotImplementedError('training-mode BatchNorm / backward kernels are not built yet (DESIGN.md)')
+            raise NotImplementedError('is_training=True: the training forward keeps a tape for its hand-written backward and '
+                                      'lives in imgcomp_cvpr_amd.training.TrainGraph (see train.py)')
         _lib.require_cuda(x, 'x')
         x = x.contiguous()
         N, three, H, W = x.shape
@@ -234,7 +235,8 @@ class _CVPR(_Network):
 
     def _decode(self, q, is_training):
         if is_training:
-            raise NotImplementedError('training-mode BatchNorm / backward kernels are not built yet (DESIGN.md)')
+            raise NotImplementedError('is_training=True: the training forward keeps a tape for its hand-written backward and '
+                                      'lives in imgcomp_cvpr_amd.training.TrainGraph (see train.py)')
         _lib.require_cuda(q, 'q')
         q = q.contiguous()
         N, C, hh, ww = q.shape
