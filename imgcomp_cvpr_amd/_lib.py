@@ -7,7 +7,7 @@ imgcomp_cvpr_amd/csrc``) first.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_longlong, c_size_t, c_void_p, POINTER
+from ctypes import c_char_p, c_float, c_int, c_int64, c_longlong, c_size_t, c_uint32, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # IMGCOMP_HIP_LIB: tuning aid (A/B two builds of the library on one GPU box); default = the in-tree build
@@ -23,6 +23,7 @@ class HipLibraryError(RuntimeError):
 PROTOTYPES = {
     'ic_abi_version': (c_int, []),
     'ic_strerror': (c_char_p, [c_int]),
+    'ic_crc32c': (c_uint32, [c_void_p, c_size_t, c_uint32]),
     'ic_conv2d_bn_act_f32': (c_int, [c_void_p] * 7 + [c_int] * 9 + [c_void_p, c_void_p, c_void_p]),
     'ic_deconv2d_bn_act_f32': (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p, c_void_p, c_void_p]),
     'ic_conv3x3_c128_packed_floats': (c_size_t, []),

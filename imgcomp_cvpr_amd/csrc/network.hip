@@ -3,6 +3,7 @@
 // One host call enqueues all 36 stages of encode (or decode) on the caller's stream: batch-1 inference
 // (val.py runs one image per step, code/val.py:157-158) is otherwise bound by per-op host overhead.
 #include "internal.h"
+#include <string.h>
 
 // ---- residual stack shared by encoder and decoder (autoencoder.py:224-234 / :252-262) ----
 // tab: 3 pointers {packed filter (both forms, ic_pack_conv3x3_c128_both_f32), scale, shift} per conv, 6B+2 convs.  bufs[0] holds the stack input
@@ -148,6 +149,38 @@ extern "C" const char* ic_strerror(int code) {
         case IC_ERR_WORKSPACE: return "workspace too small";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
+}
+
+// CRC-32C (Castagnoli) of a HOST buffer: the checksum of TF-1 checkpoint tensors and table blocks
+// (tensorflow/core/lib/hash/crc32c.h; saver.py:46-100 writes them, tf_checkpoint.py reads/writes them).
+// Slicing-by-8 on the host; not a device function.
+static uint32_t g_crc_tab[8][256];
+static bool g_crc_init = false;
+static void crc_init() {
+    for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+        g_crc_tab[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+        for (int t = 1; t < 8; ++t) g_crc_tab[t][i] = (g_crc_tab[t - 1][i] >> 8) ^ g_crc_tab[0][g_crc_tab[t - 1][i] & 0xff];
+    g_crc_init = true;
+}
+
+extern "C" uint32_t ic_crc32c(const void* data, size_t n, uint32_t crc) {
+    if (!g_crc_init) crc_init();
+    const unsigned char* p = (const unsigned char*)data;
+    uint32_t c = crc ^ 0xFFFFFFFFu;
+    while (n >= 8) {
+        uint32_t lo, hi;
+        memcpy(&lo, p, 4); memcpy(&hi, p + 4, 4);
+        lo ^= c;
+        c = g_crc_tab[7][lo & 0xff] ^ g_crc_tab[6][(lo >> 8) & 0xff] ^ g_crc_tab[5][(lo >> 16) & 0xff] ^ g_crc_tab[4][lo >> 24] ^
+            g_crc_tab[3][hi & 0xff] ^ g_crc_tab[2][(hi >> 8) & 0xff] ^ g_crc_tab[1][(hi >> 16) & 0xff] ^ g_crc_tab[0][hi >> 24];
+        p += 8; n -= 8;
+    }
+    while (n--) c = g_crc_tab[0][(c ^ *p++) & 0xff] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
 }
 
 extern "C" int ic_event_create(void** ev) {

@@ -1,7 +1,7 @@
 """Training driver -- the train.py entry point of the reference (code/train.py) on the MI355X kernels.
 
     python -m imgcomp_cvpr_amd.train AE_CONFIG PC_CONFIG [--log_dir_root DIR] [--dataset_train GLOB | --synthetic]
-                                     [--max_itr N] [--log_interval 100] [--save_interval 1000] [--restore FILE.npz]
+                                     [--max_itr N] [--log_interval 100] [--save_interval 1000] [--restore CKPT|DIR|FILE.npz]
 
     multi-GPU (data parallel, one process per GPU, RCCL):
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \\
@@ -10,9 +10,10 @@
 What is kept from the reference: the config files and the `MMDD_HHMM cfg@path cfg@path` log-dir naming
 (logdir_helpers.py:34-56), the loss / optimiser recipe (training.py), random crops + horizontal flips of the
 training images (inputpipeline.py:199-213), img/s on the console (train.py:201-213,256), checkpoints every
---save_interval iterations.  What is different: checkpoints are `.npz` files keyed by the TF variable names
-(the TF-1 bundle format is row N1 of the plan); the TF input queue is a plain loader; TensorBoard / Sheets logging
-is out of scope.  Under data parallelism the global batch of the config is split over the ranks; gradients are
+--save_interval iterations in the reference's on-disk format -- `ckpts/ckpt-<itr>.index` + `.data-00000-of-00001`
+(TF-1 tensor bundle, tf_checkpoint.py) + `ckpts/var_names.pkl` (saver.py:19-43) -- so the reference's own val.py can
+restore what this train.py wrote and vice versa.  What is different: the TF input queue is a plain loader;
+TensorBoard / Sheets logging is out of scope; --restore takes the variables only (Adam moments start at zero).  Under data parallelism the global batch of the config is split over the ranks; gradients are
 averaged with three bucketed RCCL all-reduces per step (training.GradBuckets), BatchNorm uses local statistics.
 """
 import argparse
@@ -93,8 +94,8 @@ def train(ae_config_path, pc_config_path, log_dir_root, loader_fn, max_itr, log_
         raise ValueError('batch_size {} not divisible by {} ranks'.format(batch_total, world))
     loader = loader_fn(ae_config, batch_total // world, rank)
     if restore:
-        with np.load(restore) as z:
-            weights = {k: z[k] for k in z.files}
+        from . import tf_checkpoint
+        weights = tf_checkpoint.load_weights(restore)
     else:
         weights = _weights.synthetic_weights(ae_config, pc_config, gain=1.0, heatmap_bias=None)   # Xavier, as slim initialises
         weights[_weights.ENC + '/centers'] = np.random.RandomState(666).uniform(
@@ -124,11 +125,20 @@ def train(ae_config_path, pc_config_path, log_dir_root, loader_fn, max_itr, log_
             ips = (itr + 1 - n_last) * batch_total / max(dt, 1e-9)
             t_last, n_last = time.time(), itr + 1
             print('{: 7d} | {} | {:.1f} img/s'.format(itr, ' '.join('{}: {:.4f}'.format(k, v) for k, v in out.items()), ips), flush=True)
-        if log_dir and (itr + 1) % save_interval == 0:
-            np.savez(path.join(log_dir, 'ckpts', 'ckpt-{}.npz'.format(itr + 1)), **tr.state_weights())
-    if log_dir:
-        np.savez(path.join(log_dir, 'ckpts', 'weights.npz'), **tr.state_weights())
+        if log_dir and ((itr + 1) % save_interval == 0 or itr == max_itr - 1):
+            save_checkpoint(path.join(log_dir, 'ckpts'), tr.state_weights(), itr + 1)
     return tr, hist, log_dir
+
+
+def save_checkpoint(ckpt_dir, variables, global_step):
+    """saver.py:46-100: `ckpt-<global_step>` as a TF-1 tensor bundle + var_names.pkl (written once per directory)."""
+    from . import tf_checkpoint
+    os.makedirs(ckpt_dir, exist_ok=True)
+    tensors = dict(variables)
+    tensors['global_step'] = np.array(global_step, np.int64)
+    if not path.exists(path.join(ckpt_dir, 'var_names.pkl')):
+        tf_checkpoint.write_var_names(ckpt_dir, sorted(tensors))
+    tf_checkpoint.write_bundle(path.join(ckpt_dir, 'ckpt-{}'.format(global_step)), tensors)
 
 
 def main(argv=None):
@@ -141,7 +151,7 @@ def main(argv=None):
     p.add_argument('--max_itr', type=int, default=1000)
     p.add_argument('--log_interval', type=int, default=100)
     p.add_argument('--save_interval', type=int, default=1000)
-    p.add_argument('--restore', help='.npz of variables to start from')
+    p.add_argument('--restore', help='variables to start from: TF-1 checkpoint prefix, ckpts/ or log dir, or an .npz')
     flags = p.parse_args(argv)
     if 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) > 1:
         import torch.distributed as dist

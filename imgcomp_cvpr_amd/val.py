@@ -1,7 +1,7 @@
 """Inference driver -- the val.py entry point of the reference (code/val.py) on the MI355X hot path.
 
     python -m imgcomp_cvpr_amd.val LOG_DIR_ROOT JOB_IDS IMAGES [--save_ours] [--how_many N] [--real_bpp]
-                                   [--weights synthetic|FILE.npz] [--reset]
+                                   [--weights synthetic|FILE.npz|CKPT] [--restore_itr N] [--reset]
 
 Per image (batch 1, as val.py:157-158): encode -> decode(qhard) -> bitcost(qbar, symbols, pad=centers[0]) -> bpp;
 output truncated to uint8; MS-SSIM (float64 numpy, metrics.py) and PSNR on the host; `measures.csv`
@@ -10,9 +10,10 @@ arithmetic-coded size is measured too and |bpp_theory - bpp_loss| < 1e-3 is asse
 
 Job directories are named as the reference names them, `MMDD_HHMM ae_configs@cvpr@low pc_configs@cvpr@res_shallow`
 (logdir_helpers.py:34-56); the configs are recovered from the name (logdir_helpers.py:130-151) and resolved against
-$CONFIG_BASE_AE / $CONFIG_BASE_PC or this package's config trees.  Weights: `JOB_DIR/ckpts/weights.npz` (variable
-names and layouts of the TF checkpoint) or `--weights synthetic`.  Reading the TF-1 tensor
-bundle itself (`ckpt-*.index/.data`) is row N1 of the plan and not built yet.
+$CONFIG_BASE_AE / $CONFIG_BASE_PC or this package's config trees.  Weights: the newest `JOB_DIR/ckpts/ckpt-<itr>`
+(or the newest with iteration <= --restore_itr, saver.py:102-127) read straight from the TF-1 tensor bundle
+(`.index` + `.data-00000-of-00001`, tf_checkpoint.py), or `--weights` = 'synthetic' | an .npz keyed by variable name |
+a checkpoint prefix / ckpts directory / log dir.
 
 Under torch.distributed.run (one process per GPU) the image list is sharded round-robin over the ranks; rank 0
 writes the merged measures.
@@ -244,16 +245,15 @@ def save_img(img_name, img_out, out_dir):
     Image.fromarray(np.transpose(img_out[0], (1, 2, 0))).save(path.join(d, img_name))
 
 
-def load_weights_for_job(job_dir, weights_arg, ae_config, pc_config):
+def load_weights_for_job(job_dir, weights_arg, ae_config, pc_config, restore_itr=-1):
     if weights_arg == 'synthetic':
         return _weights.synthetic_weights(ae_config, pc_config)
-    p = weights_arg or path.join(job_dir, 'ckpts', 'weights.npz')
-    if not path.isfile(p):
-        raise FileNotFoundError(
-            '{} not found.  Checkpoints of the reference are TF-1 tensor bundles (ckpt-*.index/.data); convert them '
-            'to an .npz keyed by variable name, or pass --weights synthetic.'.format(p))
-    with np.load(p) as z:
-        return {k[:-2] if k.endswith(':0') else k: z[k] for k in z.files}
+    from . import tf_checkpoint
+    p = weights_arg or job_dir
+    if not path.exists(p) and not path.exists(p + '.index'):
+        raise FileNotFoundError('{} not found (expected a TF-1 checkpoint prefix, a ckpts/ or log dir, or an .npz); '
+                                'or pass --weights synthetic'.format(p))
+    return tf_checkpoint.load_weights(p, itr=restore_itr)
 
 
 def main(argv=None):
@@ -266,7 +266,10 @@ def main(argv=None):
     p.add_argument('--reset', action='store_const', const=True, help='Remove previous output')
     p.add_argument('--real_bpp', action='store_const', const=True,
                    help='If given, calculate real bpp using arithmetic encoding.')
-    p.add_argument('--weights', help="'synthetic' or an .npz of checkpoint variables (default JOB_DIR/ckpts/weights.npz)")
+    p.add_argument('--weights', help="'synthetic', an .npz of checkpoint variables, or a TF-1 checkpoint prefix / ckpts dir "
+                                     "(default: newest checkpoint in JOB_DIR/ckpts)")
+    p.add_argument('--restore_itr', type=int, default=-1, help='Restore the newest checkpoint with iteration <= this '
+                                                               '(val.py:215-217); -1 = newest.')
     p.add_argument('--device', default=None)
     flags, unknown = p.parse_known_args(argv)
     if unknown:
@@ -288,7 +291,7 @@ def main(argv=None):
         ae_p, pc_p = config_paths_from_log_dir(job_dir, bases)
         ae_config, _ = config_parser.parse(ae_p)
         pc_config, _ = config_parser.parse(pc_p)
-        weights = load_weights_for_job(job_dir, flags.weights, ae_config, pc_config)
+        weights = load_weights_for_job(job_dir, flags.weights, ae_config, pc_config, flags.restore_itr)
         out_dir = path.join(flags.log_dir_root, '{} {}'.format(log_date_from_log_dir(job_dir), dataset_name))
         if flags.reset and path.isdir(out_dir) and sharding.rank_and_world()[0] == 0:
             import shutil

@@ -39,6 +39,10 @@ int ic_abi_version(void);
 /* static string for a return code of this library (hipGetErrorString for codes > 0) */
 const char* ic_strerror(int code);
 
+/* host utility: CRC-32C (Castagnoli) of a host buffer, continuing from `crc` (0 to start) -- the checksum of TF-1
+ * checkpoint blocks and tensors (saver.py:46-100 -> tf.train.Saver; imgcomp_cvpr_amd/tf_checkpoint.py). */
+uint32_t ic_crc32c(const void* host_data, size_t bytes, uint32_t crc);
+
 /* ---------------------------------------------------------------------------------------------
  * Generic direct convolution + folded BatchNorm + activation (+ up to two residual adds).
  * Replaces slim.conv2d(..., normalizer_fn=slim.batch_norm) at autoencoder.py:222 (h1), :223 (h2),

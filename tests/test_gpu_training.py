@@ -222,7 +222,8 @@ def test_two_steps_reduce_loss(cuda):
 
 
 def test_train_entry_point(cuda, tmp_path):
-    """python -m imgcomp_cvpr_amd.train on synthetic crops: runs, logs, writes an .npz checkpoint that val.py reads."""
+    """python -m imgcomp_cvpr_amd.train on synthetic crops: runs, logs, writes TF-1 bundle checkpoints + var_names.pkl
+    in the reference's ckpts/ layout; val.py restores the newest / a given iteration; --restore continues from them."""
     from imgcomp_cvpr_amd import train, config_parser as cp, val, autoencoder
     ae_p = cp.builtin_config_path('ae_configs', 'cvpr', 'low')
     pc_p = cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow')
@@ -235,9 +236,20 @@ def test_train_entry_point(cuda, tmp_path):
     tr, hist, log_dir = train.train(str(ae_over), pc_p, str(tmp_path / 'logs'), loader_fn, max_itr=3, log_interval=1,
                                     save_interval=2, device=str(cuda), verbose=False)
     assert len(hist) == 3 and all(np.isfinite(h['d_loss_scaled']) for h in hist)
-    assert os.path.isfile(os.path.join(log_dir, 'ckpts', 'ckpt-2.npz'))
+    from imgcomp_cvpr_amd import tf_checkpoint as T
+    ckpts = os.path.join(log_dir, 'ckpts')
+    assert sorted(os.listdir(ckpts)) == ['ckpt-2.data-00000-of-00001', 'ckpt-2.index', 'ckpt-3.data-00000-of-00001',
+                                         'ckpt-3.index', 'var_names.pkl']
+    assert [i for i, _ in T.all_ckpts_with_iterations(ckpts)] == [2, 3]
+    assert int(T.read_bundle(os.path.join(ckpts, 'ckpt-3'), names=['global_step'], verify=True)['global_step']) == 3
     wts = val.load_weights_for_job(log_dir, None, tr.graph.ae_config, tr.graph.pc_config)
     assert set(wts) == set(tr.graph.params)
+    final = tr.state_weights()
+    assert all(np.array_equal(wts[k], final[k]) for k in wts)
+    w2 = val.load_weights_for_job(log_dir, None, tr.graph.ae_config, tr.graph.pc_config, restore_itr=2)
+    assert any(not np.array_equal(w2[k], final[k]) for k in w2)              # the earlier checkpoint
+    tr2, hist2, _ = train.train(str(ae_over), pc_p, None, loader_fn, max_itr=1, restore=log_dir, device=str(cuda), verbose=False)
+    assert np.isfinite(hist2[0]['d_loss_scaled'])
     ae = autoencoder.get_network_cls(tr.graph.ae_config)(tr.graph.ae_config).load_weights(wts, cuda)
     enc = ae.encode(torch.zeros((1, 3, 64, 64), device=cuda), is_training=False)       # inference on the trained variables
     assert bool(torch.isfinite(enc.z).all())
