@@ -43,22 +43,41 @@ def create_unique_log_dir(config_rel_paths, log_dir_root):
         t = t.replace(minute=(t.minute + 1) % 60, hour=(t.hour + (t.minute + 1) // 60) % 24)
 
 
-class CropLoader(object):
-    """random crop_size crops (+ random horizontal flip) of the images matching a glob, as (N,3,h,w) float 0..255
-    (inputpipeline.py:147-213).  `synthetic=True`: seeded synthetic images instead of files."""
+NUM_CROPS_PER_IMG = 8            # train.py:38 of the reference
 
-    def __init__(self, images_glob, crop_size, batch_size, seed=0, synthetic=False):
+
+class CropLoader(object):
+    """random crop_size crops (+ random horizontal flip) of the images matching a glob, as (N,3,h,w) float 0..255.
+    Mirrors inputpipeline.py:147-213: every decoded image yields NUM_CROPS_PER_IMG crops (one flip decision per
+    image, tf_helpers.random_flip on the stacked crops), crops from different images are mixed through a shuffle pool
+    (tf.train.shuffle_batch_join: capacity 1000, min_after_dequeue 800 -- scaled down for small data sets), and
+    decoding runs on background threads so the GPU step (~1000 img/s) does not wait for PNG decoding.
+    `synthetic=True`: seeded synthetic images, filled synchronously (deterministic; tests and benchmarks)."""
+
+    def __init__(self, images_glob, crop_size, batch_size, seed=0, synthetic=False, num_crops_per_img=NUM_CROPS_PER_IMG,
+                 num_threads=4, capacity=1000, min_after_dequeue=800):
         self.crop, self.batch = tuple(crop_size), batch_size
         self.rs = np.random.RandomState(seed)
         self.synthetic = synthetic
+        self.crops_per_img = num_crops_per_img
         if synthetic:
             self.images = [_weights.synthetic_image((1, 3, 2 * self.crop[0], 2 * self.crop[1]), 'natural', seed=1000 * seed + i)[0]
                            for i in range(8)]
+            self._pool = None
         else:
             self.paths = sorted(glob.glob(images_glob))
             if not self.paths:
                 raise ValueError('Not matching any files: {}'.format(images_glob))
             self.images = None
+            import threading
+            self._pool, self._lock = [], threading.Condition()
+            self._capacity = max(capacity, 2 * batch_size)
+            self._min_after = min(min_after_dequeue, self._capacity - batch_size)
+            self._stop = False
+            self._threads = [threading.Thread(target=self._worker, args=(seed * 1000 + 17 * t + 1,), daemon=True)
+                             for t in range(num_threads)]
+            for t in self._threads:
+                t.start()
 
     @property
     def num_images(self):
@@ -70,16 +89,51 @@ class CropLoader(object):
         from PIL import Image
         return np.transpose(np.asarray(Image.open(self.paths[i]).convert('RGB'), dtype=np.uint8), (2, 0, 1))
 
+    def _crops_of(self, im, rs):
+        H, W = im.shape[1:]
+        if H < self.crop[0] or W < self.crop[1]:
+            raise ValueError('image smaller than crop size')
+        flip = rs.rand() < 0.5
+        out = []
+        for _ in range(self.crops_per_img):
+            y, x = rs.randint(H - self.crop[0] + 1), rs.randint(W - self.crop[1] + 1)
+            c = im[:, y:y + self.crop[0], x:x + self.crop[1]]
+            out.append(np.ascontiguousarray(c[:, :, ::-1] if flip else c))
+        return out
+
+    def _worker(self, seed):
+        rs = np.random.RandomState(seed)
+        while not self._stop:
+            crops = self._crops_of(self._image(rs.randint(self.num_images)), rs)
+            with self._lock:
+                while len(self._pool) + len(crops) > self._capacity and not self._stop:
+                    self._lock.wait(0.1)
+                self._pool.extend(crops)
+                self._lock.notify_all()
+
+    def close(self):
+        if self._pool is not None:
+            self._stop = True
+            with self._lock:
+                self._lock.notify_all()
+
     def get_batch(self):
         out = np.empty((self.batch, 3) + self.crop, np.float32)
-        for b in range(self.batch):
-            im = self._image(self.rs.randint(self.num_images))
-            H, W = im.shape[1:]
-            if H < self.crop[0] or W < self.crop[1]:
-                raise ValueError('image smaller than crop size')
-            y, x = self.rs.randint(H - self.crop[0] + 1), self.rs.randint(W - self.crop[1] + 1)
-            c = im[:, y:y + self.crop[0], x:x + self.crop[1]]
-            out[b] = c[:, :, ::-1] if self.rs.rand() < 0.5 else c
+        if self.synthetic:
+            b = 0
+            while b < self.batch:
+                for c in self._crops_of(self._image(self.rs.randint(self.num_images)), self.rs)[:self.batch - b]:
+                    out[b] = c
+                    b += 1
+            return out
+        with self._lock:
+            while len(self._pool) < self._min_after + self.batch:
+                self._lock.wait(0.1)
+            for b in range(self.batch):
+                j = self.rs.randint(len(self._pool))
+                self._pool[j], self._pool[-1] = self._pool[-1], self._pool[j]
+                out[b] = self._pool.pop()
+            self._lock.notify_all()
         return out
 
 

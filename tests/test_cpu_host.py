@@ -397,3 +397,36 @@ def test_tf_checkpoint_bundle_round_trip(tmp_path):
     open(prefix + '.data-00000-of-00001', 'wb').write(bytes(data))
     with pytest.raises(ValueError):
         T.read_bundle(prefix, verify=True)
+
+
+def test_crop_loader_files_and_synthetic(tmp_path):
+    """N4: training input -- crops come out of decoded files through the background shuffle pool, NUM_CROPS_PER_IMG crops
+    per decoded image share one flip decision (inputpipeline.py:199-213); the synthetic mode is deterministic."""
+    from PIL import Image
+    from imgcomp_cvpr_amd import train
+    imgs = []
+    for i in range(3):
+        a = np.random.RandomState(i).randint(0, 255, (80, 112, 3), dtype=np.uint8)
+        Image.fromarray(a).save(str(tmp_path / 'im{}.png'.format(i)))
+        imgs.append(np.transpose(a, (2, 0, 1)))
+    L = train.CropLoader(str(tmp_path / '*.png'), (64, 48), 8, seed=0, capacity=64, min_after_dequeue=24, num_threads=2)
+    try:
+        for _ in range(4):
+            b = L.get_batch()
+            assert b.shape == (8, 3, 64, 48) and b.dtype == np.float32
+            for c in b:                                  # every crop is a window of one of the files, possibly mirrored
+                found = False
+                for im in imgs:
+                    for cand in (c, c[:, :, ::-1]):
+                        y0 = np.where((im[0, :, :1] == cand[0, 0, 0]))[0]
+                        win = np.lib.stride_tricks.sliding_window_view(im, (3, 64, 48))[0]
+                        found = found or bool((win == cand.astype(np.uint8)).all(axis=(2, 3, 4)).any())
+                assert found
+    finally:
+        L.close()
+    with pytest.raises(ValueError):
+        train.CropLoader(str(tmp_path / '*.jpg'), (64, 48), 8)
+    S1 = train.CropLoader(None, (64, 64), 6, seed=1, synthetic=True)
+    S2 = train.CropLoader(None, (64, 64), 6, seed=1, synthetic=True)
+    assert np.array_equal(S1.get_batch(), S2.get_batch())
+    assert train.NUM_CROPS_PER_IMG == 8
