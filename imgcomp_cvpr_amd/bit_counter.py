@@ -4,8 +4,10 @@
 Differences from the reference, all on the speed side, none in the stream:
   * encode: the frequency tables of ALL contexts come from ONE parallel pass of the context model
     (PredictionNetwork.get_all) instead of two sess.run per symbol (bit_counter.py:125-126);
-  * decode stays sequential by nature (a table depends on the symbols decoded so far) and asks the
-    prediction network one context at a time, exactly like bit_counter.py:137-164.
+  * decode stays sequential by nature (a table depends on the symbols decoded so far); by default the whole loop
+    runs on the device without host round trips (PredictionNetwork.decode_stream -> ic_pc_decode_f32); with
+    device_decode=False it asks the prediction network one context at a time from Python, exactly like
+    bit_counter.py:137-164 (both are tested to return the same symbols).
 Raster order C -> H -> W, the first symbol is not coded (only its -log2 p enters the theoretical cost),
 and the three run-time checks of the reference are kept (bit_counter.py:51,56,68).
 """
@@ -19,11 +21,11 @@ from . import arithmetic_coding as ac
 from . import probclass
 
 
-def encode_decode_to_file_ctx(syms, prediction_net, syms_format='HWC', verbose=False):
+def encode_decode_to_file_ctx(syms, prediction_net, syms_format='HWC', verbose=False, device_decode=True):
     """:return: number of bits needed to encode all symbols in `syms` (HWC / CHW, or a batch of them)."""
     _print = print if verbose else (lambda *a, **k: None)
     if len(syms.shape) == 4:
-        return int(np.sum([encode_decode_to_file_ctx(syms[b, ...], prediction_net, syms_format, verbose)
+        return int(np.sum([encode_decode_to_file_ctx(syms[b, ...], prediction_net, syms_format, verbose, device_decode)
                            for b in range(syms.shape[0])]))
     assert len(syms.shape) == 3, 'Expected HWC or CHW'
     assert syms_format in ('HWC', 'CHW')
@@ -44,8 +46,12 @@ def encode_decode_to_file_ctx(syms, prediction_net, syms_format='HWC', verbose=F
         assert actual_num_bits == virtual_num_bits, '{} != {}'.format(actual_num_bits, virtual_num_bits)
 
         _print('Decoding symbols to shape {}, first_sym={}...'.format(syms_padded.shape, first_sym))
-        syms_dec_padded = _decode(fout_p, syms_padded.shape, ctx_shape, first_sym, prediction_net.get_freqs)
-        syms_dec = prediction_net.undo_pad_symbols_volume(syms_dec_padded)
+        if device_decode and hasattr(prediction_net, 'decode_stream'):
+            with open(fout_p, 'rb') as fin:
+                syms_dec = prediction_net.decode_stream(fin.read(), syms.shape, first_sym)
+        else:
+            syms_dec_padded = _decode(fout_p, syms_padded.shape, ctx_shape, first_sym, prediction_net.get_freqs)
+            syms_dec = prediction_net.undo_pad_symbols_volume(syms_dec_padded)
         np.testing.assert_array_equal(syms, syms_dec)
         _print('Decoded symbols match input!')
     finally:

@@ -332,9 +332,11 @@ static int launch_pc_mfma(const PcLayerArgs& a, const float* wpk, int k, bool fi
     return IC_OK;
 }
 
+// prepacked: the three MFMA filter packings already sit at the end of the workspace (a caller that runs the network
+// many times on small volumes -- the sequential decoder -- packs once with pc_pack_filters).
 static int pc_forward(const float* q, int prepadded, const int64_t* symbols, const float* const* wt, int k, int L,
                       float pad_value, float* logits, float* bits, int N, int C, int h, int w,
-                      void* workspace, size_t workspace_bytes, hipStream_t st) {
+                      void* workspace, size_t workspace_bytes, hipStream_t st, bool prepacked = false) {
     IC_CHECK_ARG(q && wt && workspace && N > 0 && C > 0 && h > 0 && w > 0 && k > 0 && L > 0);
     for (int i = 0; i < 8; ++i) IC_CHECK_ARG(wt[i] != nullptr);
     IC_CHECK_ARG(!bits || symbols);
@@ -355,7 +357,7 @@ static int pc_forward(const float* q, int prepadded, const int64_t* symbols, con
     float* pk1 = b2 + (size_t)N * k * (C + 1) * (h + 2) * (w + 2);
     float* pk2 = pk1 + pc_packed_floats(k, k);
     float* pk3 = pk2 + pc_packed_floats(k, k);
-    if (use_mfma) {
+    if (use_mfma && !prepacked) {
         const int t1 = (int)pc_packed_floats(k, k), t3 = (int)pc_packed_floats(k, L);
         hipLaunchKernelGGL(pc_pack_kernel, dim3(ic_cdiv(t1, 256)), dim3(256), 0, st, wt[2], pk1, k, k, ic_cdiv(k, 32), t1);
         hipLaunchKernelGGL(pc_pack_kernel, dim3(ic_cdiv(t1, 256)), dim3(256), 0, st, wt[4], pk2, k, k, ic_cdiv(k, 32), t1);
@@ -408,12 +410,8 @@ extern "C" int ic_pc_bitcost_f32(const float* q, const int64_t* symbols, const f
 // pr = softmax(logits); freqs = max(int64(pr * resolution), 1).  One lane per context; a fixed per-row fp32
 // expression (max, exp, sequential sum, divide, multiply, truncate), so the encoder (all contexts at once) and
 // the decoder (one context at a time) derive IDENTICAL tables from identical logits.
-__global__ __launch_bounds__(256) void logits_to_freqs_kernel(const float* __restrict__ logits, long long count, int L,
-                                                              float resolution, long long* __restrict__ freqs,
-                                                              float* __restrict__ pr) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= count) return;
-    const float* l = logits + i * L;
+__device__ __forceinline__ void pc_table_row(const float* __restrict__ l, int L, float resolution, long long* __restrict__ freqs,
+                                             float* __restrict__ pr) {
     float m = l[0];
     for (int j = 1; j < L; ++j) m = fmaxf(m, l[j]);
     float e[16];
@@ -421,10 +419,18 @@ __global__ __launch_bounds__(256) void logits_to_freqs_kernel(const float* __res
     for (int j = 0; j < L; ++j) { e[j] = expf(l[j] - m); s += e[j]; }
     for (int j = 0; j < L; ++j) {
         const float p = e[j] / s;
-        if (pr) pr[i * L + j] = p;
+        if (pr) pr[j] = p;
         long long f = (long long)__fmul_rn(p, resolution);
-        freqs[i * L + j] = f < 1 ? 1 : f;
+        freqs[j] = f < 1 ? 1 : f;
     }
+}
+
+__global__ __launch_bounds__(256) void logits_to_freqs_kernel(const float* __restrict__ logits, long long count, int L,
+                                                              float resolution, long long* __restrict__ freqs,
+                                                              float* __restrict__ pr) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    pc_table_row(logits + i * L, L, resolution, freqs + i * L, pr ? pr + i * L : nullptr);
 }
 
 extern "C" int ic_pc_logits_to_freqs_f32(const float* logits, long long count, int L, float resolution,
@@ -434,6 +440,229 @@ extern "C" int ic_pc_logits_to_freqs_f32(const float* logits, long long count, i
     hipLaunchKernelGGL(logits_to_freqs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        logits, count, L, resolution, (long long*)freqs, pr);
     IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
+// ---- sequential decoder (row N3: bit_counter.py:137-164 without the host in the loop) ----------------------------------
+// A symbol's frequency table depends on the symbols decoded before it, so decoding is one context at a time by nature.
+// The reference (and bit_counter._decode here) does a host round trip per symbol: gather the 5x9x9 context, run the
+// network, fetch the table, step the arithmetic decoder in Python -- ~160 us per symbol.  Here the whole loop is
+// enqueued on the stream: per symbol the SAME four context-model kernels as the parallel encoder side run on the
+// gathered context (identical fp32 expression per logit -> identical tables, the property tested by
+// test_blockwise_logits_bit_identical_to_full_volume), then ONE small kernel turns the logits into the integer table
+// (pc_table_row, shared with logits_to_freqs_kernel), steps the arithmetic decoder (32-bit range coder, the reference's
+// arithmetic_coding.py:ArithmeticDecoder restated for the device), stores the symbol, writes its centre into the padded
+// volume and gathers the next context.  No host synchronisation until the end.
+#define PC_AC_BITS 32
+struct PcDecState {
+    unsigned long long low, high, code;
+    long long byte_pos;
+    int bit_left, cur_byte;
+    int error;                 // 1: frequency total too large, 2: internal
+    long long next;            // raster index of the next symbol to decode
+};
+
+struct PcDecArgs {
+    const unsigned char* bits; long long nbytes;
+    PcDecState* st;
+    const float* centers; const float* logits;
+    float* vol;                // padded volume (C+4, h+8, w+8) of centre values
+    float* ctx;                // (5, 9, 9) context of the next symbol
+    long long* symbols;        // (C, h, w)
+    int C, h, w, L, first_sym;
+    float resolution;
+};
+
+__device__ __forceinline__ int pc_dec_bit(const PcDecArgs& a, PcDecState& s) {
+    if (s.bit_left == 0) {
+        if (s.byte_pos >= a.nbytes) return 0;          // past the end the stream reads as zeros (arithmetic_coding.py)
+        s.cur_byte = a.bits[s.byte_pos++];
+        s.bit_left = 8;
+    }
+    --s.bit_left;
+    return (s.cur_byte >> s.bit_left) & 1;
+}
+
+__device__ void pc_dec_gather(const PcDecArgs& a, long long idx) {
+    // context of symbol idx = padded block [c, c+5) x [y, y+9) x [x, x+9)
+    const int HW = a.h * a.w;
+    const int c = (int)(idx / HW), r = (int)(idx - (long long)c * HW);
+    const int y = r / a.w, x = r - y * a.w;
+    const int PH = a.h + 8, PW = a.w + 8;
+    for (int e = threadIdx.x; e < 5 * 9 * 9; e += blockDim.x) {
+        const int d = e / 81, r2 = e - d * 81;
+        a.ctx[e] = a.vol[((size_t)(c + d) * PH + y + r2 / 9) * PW + x + r2 % 9];
+    }
+}
+
+__global__ __launch_bounds__(256) void pc_dec_fill_kernel(float* __restrict__ vol, long long n, const float* __restrict__ centers) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) vol[i] = centers[0];                       // symbol 0 everywhere: pad_symbols_volume pads with 0
+}
+
+__global__ __launch_bounds__(256) void pc_dec_init_kernel(const PcDecArgs a) {
+    if (threadIdx.x == 0) {
+        PcDecState s;
+        s.low = 0; s.high = (1ull << PC_AC_BITS) - 1; s.code = 0;
+        s.byte_pos = 0; s.bit_left = 0; s.cur_byte = 0; s.error = 0; s.next = 1;
+        for (int i = 0; i < PC_AC_BITS; ++i) s.code = (s.code << 1) | (unsigned)pc_dec_bit(a, s);
+        *a.st = s;
+        a.symbols[0] = a.first_sym;                       // the first symbol is not coded (bit_counter.py:117-121,152)
+        a.vol[((size_t)4 * (a.h + 8) + 4) * (a.w + 8) + 4] = a.centers[a.first_sym];
+    }
+    __syncthreads();
+    if ((long long)a.C * a.h * a.w > 1) pc_dec_gather(a, 1);
+}
+
+__global__ __launch_bounds__(256) void pc_dec_step_kernel(const PcDecArgs a) {
+    __shared__ long long sh_next;
+    if (threadIdx.x == 0) {
+        PcDecState s = *a.st;
+        const unsigned long long MASK = (1ull << PC_AC_BITS) - 1, TOP = 1ull << (PC_AC_BITS - 1), SECOND = TOP >> 1;
+        const unsigned long long MAX_TOTAL = (1ull << (PC_AC_BITS - 2)) + 2;
+        long long fr[16];
+        pc_table_row(a.logits, a.L, a.resolution, fr, nullptr);
+        unsigned long long total = 0;
+        for (int j = 0; j < a.L; ++j) total += (unsigned long long)fr[j];
+        if (total > MAX_TOTAL) s.error = 1;
+        const unsigned long long r = s.high - s.low + 1;
+        const unsigned long long value = ((s.code - s.low + 1) * total - 1) / r;
+        int sym = 0;
+        unsigned long long cum = 0;
+        while (sym + 1 < a.L && cum + (unsigned long long)fr[sym] <= value) { cum += (unsigned long long)fr[sym]; ++sym; }
+        const unsigned long long cum_lo = cum, cum_hi = cum + (unsigned long long)fr[sym];
+        s.high = s.low + cum_hi * r / total - 1;
+        s.low = s.low + cum_lo * r / total;
+        while (((s.low ^ s.high) & TOP) == 0) {
+            s.code = ((s.code << 1) & MASK) | (unsigned)pc_dec_bit(a, s);
+            s.low = (s.low << 1) & MASK;
+            s.high = ((s.high << 1) & MASK) | 1;
+        }
+        while ((s.low & ~s.high & SECOND) != 0) {
+            s.code = (s.code & TOP) | ((s.code << 1) & (MASK >> 1)) | (unsigned)pc_dec_bit(a, s);
+            s.low = (s.low << 1) & (MASK >> 1);
+            s.high = ((s.high << 1) & (MASK >> 1)) | TOP | 1;
+        }
+        const long long idx = s.next;
+        const int HW = a.h * a.w;
+        const int c = (int)(idx / HW), rr = (int)(idx - (long long)c * HW);
+        a.symbols[idx] = sym;
+        a.vol[((size_t)(c + 4) * (a.h + 8) + rr / a.w + 4) * (a.w + 8) + rr % a.w + 4] = a.centers[sym];
+        s.next = idx + 1;
+        *a.st = s;
+        sh_next = s.next;
+        __threadfence_block();
+    }
+    __syncthreads();
+    if (sh_next < (long long)a.C * a.h * a.w) pc_dec_gather(a, sh_next);
+}
+
+static size_t pc_dec_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+extern "C" size_t ic_pc_decode_workspace_bytes(int C, int h, int w, int k) {
+    if (C <= 0 || h <= 0 || w <= 0 || k <= 0) return 0;
+    return pc_dec_align((size_t)(C + 4) * (h + 8) * (w + 8) * sizeof(float)) + pc_dec_align(405 * sizeof(float)) +
+           pc_dec_align(16 * sizeof(float)) + pc_dec_align(sizeof(PcDecState)) + ic_pc_workspace_bytes(1, 1, 1, 1, k);
+}
+
+extern "C" int ic_pc_decode_f32(const uint8_t* bitstream, long long nbytes, int first_sym, const float* const* wtab_host,
+                                const float* centers, int k, int L, float resolution, int64_t* symbols, int* status,
+                                int C, int h, int w, void* workspace, size_t workspace_bytes, ic_stream_t stream) {
+    IC_CHECK_ARG(bitstream && wtab_host && centers && symbols && status && workspace);
+    IC_CHECK_ARG(nbytes >= 0 && C > 0 && h > 0 && w > 0 && k > 0 && L > 0 && first_sym >= 0 && first_sym < L);
+    if (L > 16) return IC_ERR_UNSUPPORTED;
+    if (workspace_bytes < ic_pc_decode_workspace_bytes(C, h, w, k)) return IC_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* p = (char*)workspace;
+    PcDecArgs a{};
+    a.bits = bitstream; a.nbytes = nbytes; a.centers = centers; a.symbols = (long long*)symbols;
+    a.C = C; a.h = h; a.w = w; a.L = L; a.first_sym = first_sym; a.resolution = resolution;
+    const long long nvol = (long long)(C + 4) * (h + 8) * (w + 8);
+    a.vol = (float*)p; p += pc_dec_align((size_t)nvol * sizeof(float));
+    a.ctx = (float*)p; p += pc_dec_align(405 * sizeof(float));
+    float* logits = (float*)p; p += pc_dec_align(16 * sizeof(float));
+    a.logits = logits;
+    a.st = (PcDecState*)p; p += pc_dec_align(sizeof(PcDecState));
+    void* pcws = p;
+    const size_t pcws_bytes = ic_pc_workspace_bytes(1, 1, 1, 1, k);
+    // filters packed once (pc_forward's own layout: after the three feature volumes of the 5x9x9 context)
+    const bool use_mfma = pc_mfma_supported(k, L);
+    if (use_mfma) {
+        float* pk1 = (float*)pcws + (size_t)k * (4 * 7 * 7 + 3 * 5 * 5 + 2 * 3 * 3);
+        float* pk2 = pk1 + pc_packed_floats(k, k);
+        float* pk3 = pk2 + pc_packed_floats(k, k);
+        const int t1 = (int)pc_packed_floats(k, k), t3 = (int)pc_packed_floats(k, L);
+        hipLaunchKernelGGL(pc_pack_kernel, dim3(ic_cdiv(t1, 256)), dim3(256), 0, st, wtab_host[2], pk1, k, k, ic_cdiv(k, 32), t1);
+        hipLaunchKernelGGL(pc_pack_kernel, dim3(ic_cdiv(t1, 256)), dim3(256), 0, st, wtab_host[4], pk2, k, k, ic_cdiv(k, 32), t1);
+        hipLaunchKernelGGL(pc_pack_kernel, dim3(ic_cdiv(t3, 256)), dim3(256), 0, st, wtab_host[6], pk3, k, L, 1, t3);
+    }
+    hipLaunchKernelGGL(pc_dec_fill_kernel, dim3((unsigned)((nvol + 255) / 256)), dim3(256), 0, st, a.vol, nvol, centers);
+    hipLaunchKernelGGL(pc_dec_init_kernel, dim3(1), dim3(256), 0, st, a);
+    IC_LAUNCH_CHECK();
+    const long long n = (long long)C * h * w;
+    auto one_symbol = [&]() -> int {
+        int rc = pc_forward(a.ctx, 1, nullptr, wtab_host, k, L, 0.f, logits, nullptr, 1, 1, 1, 1, pcws, pcws_bytes, st, true);
+        if (rc) return rc;
+        hipLaunchKernelGGL(pc_dec_step_kernel, dim3(1), dim3(256), 0, st, a);
+        return IC_OK;
+    };
+    // Every symbol runs the same five kernels with the SAME arguments (context, logits and coder state live at fixed
+    // addresses), so a block of PC_DEC_GRAPH symbols is captured once into a hipGraph and replayed: the host cost of
+    // ~1 M kernel launches per Kodak image (58 us per symbol, launch-bound) drops to one graph launch per block.
+    long long i = 1;
+    constexpr int PC_DEC_GRAPH = 128;
+    if (n - 1 >= 2 * PC_DEC_GRAPH) {
+        // capture is not allowed on the legacy default stream (torch's current stream by default): the loop runs on a
+        // private stream ordered after / before the caller's by events
+        static hipStream_t own = nullptr;
+        static hipEvent_t ev_in = nullptr, ev_out = nullptr;
+        bool ok = true;
+        if (!own) {
+            ok = hipStreamCreateWithFlags(&own, hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&ev_out, hipEventDisableTiming) == hipSuccess;
+            if (!ok) { own = nullptr; (void)hipGetLastError(); }
+        }
+        if (ok) {
+            const hipStream_t caller = st;
+            ok = hipEventRecord(ev_in, caller) == hipSuccess && hipStreamWaitEvent(own, ev_in, 0) == hipSuccess;
+            if (ok) {
+                st = own;
+                hipGraph_t graph = nullptr;
+                hipGraphExec_t exec = nullptr;
+                if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess) {
+                    int rc = IC_OK;
+                    for (int j = 0; j < PC_DEC_GRAPH && rc == IC_OK; ++j) rc = one_symbol();
+                    const hipError_t e = hipStreamEndCapture(st, &graph);
+                    if (rc == IC_OK && e == hipSuccess && graph &&
+                        hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                        bool launched = true;
+                        for (; launched && i + PC_DEC_GRAPH <= n; i += PC_DEC_GRAPH) launched = hipGraphLaunch(exec, st) == hipSuccess;
+                        // the executable graph must outlive its last launch: wait before destroying it
+                        (void)hipStreamSynchronize(st);
+                        (void)hipGraphExecDestroy(exec);
+                        if (!launched) { (void)hipGraphDestroy(graph); return IC_ERR_ARG; }
+                    }
+                    if (graph) (void)hipGraphDestroy(graph);
+                }
+                (void)hipGetLastError();
+                for (; i < n; ++i) {
+                    int rc = one_symbol();
+                    if (rc) return rc;
+                }
+                if (hipMemcpyAsync(status, &a.st->error, sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess) return IC_ERR_ARG;
+                if (hipEventRecord(ev_out, own) != hipSuccess || hipStreamWaitEvent(caller, ev_out, 0) != hipSuccess) return IC_ERR_ARG;
+                IC_LAUNCH_CHECK();
+                return IC_OK;
+            }
+        }
+    }
+    for (; i < n; ++i) {
+        int rc = one_symbol();
+        if (rc) return rc;
+    }
+    IC_LAUNCH_CHECK();
+    if (hipMemcpyAsync(status, &a.st->error, sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess) return IC_ERR_ARG;
     return IC_OK;
 }
 

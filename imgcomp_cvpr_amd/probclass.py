@@ -287,6 +287,26 @@ class PredictionNetwork(object):
         """(pr, freqs), each (num_contexts, L), contexts in the order of iter_over_blocks."""
         return self._tables(symbols_padded)
 
+    def decode_stream(self, stream_bytes, symbols_shape, first_sym):
+        """Row N3: the whole sequential decode on the device (ic_pc_decode_f32) -- per symbol the same context-model
+        kernels as get_freqs, the table, the arithmetic-decoder step and the gather of the next context are enqueued
+        back to back without a host round trip.  stream_bytes: what the encoder wrote; symbols_shape: un-padded
+        (C,h,w); first_sym: the uncoded first symbol.  -> (C,h,w) int64 numpy."""
+        C, h, w = (int(v) for v in symbols_shape)
+        dev = self.centers.device
+        data = torch.frombuffer(bytearray(stream_bytes) or bytearray(1), dtype=torch.uint8).to(dev)
+        out = torch.empty((C, h, w), dtype=torch.int64, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        need = lib.ic_pc_decode_workspace_bytes(C, h, w, self.pc._k)
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        centers = self.centers.contiguous().float()
+        check(lib.ic_pc_decode_f32(ptr(data), len(stream_bytes), int(first_sym), self.pc._tab, ptr(centers), self.pc._k,
+                                   self.pc.L, self.freqs_resolution, ptr(out), ptr(status), C, h, w, ptr(ws), need,
+                                   _lib.current_stream(dev)), 'ic_pc_decode_f32')
+        if int(status.item()) != 0:
+            raise ValueError('Cannot decode symbol because total is too large')
+        return out.cpu().numpy()
+
     def get_pr(self, input_ctx):
         """:param input_ctx: symbols of ONE context, CHW = input_ctx_shape -> (L,) float32."""
         assert tuple(input_ctx.shape) == tuple(self.input_ctx_shape), '{} != {}'.format(

@@ -166,6 +166,37 @@ def test_real_bpp_round_trip(cuda, configs, syn_weights, nets):
     n1 = bit_counter.encode_decode_to_file_ctx(sym[0], pred, syms_format='CHW')
     n2 = bit_counter.encode_decode_to_file_ctx(np.transpose(sym[0], (1, 2, 0)), pred, syms_format='HWC')
     assert n1 == n2 == int(round(bpp_real * 32 * 48))
+    # the reference's host loop (one context per round trip) and the on-device decoder agree
+    n3 = bit_counter.encode_decode_to_file_ctx(sym[0], pred, syms_format='CHW', device_decode=False)
+    assert n3 == n1
+
+
+def test_device_decoder_stream(cuda, configs, syn_weights, nets, tmp_path):
+    """row N3: ic_pc_decode_f32 decodes what the host-side encoder wrote -- symbols of a real encoder output (skewed
+    statistics, long runs), a truncated stream decodes without faulting (zeros past the end, as the reference's
+    bit reader), a single-symbol volume needs no bits."""
+    from imgcomp_cvpr_amd import probclass, bit_counter, weights as W
+    import tempfile
+    ae, pc = nets
+    _, pc_cfg = configs
+    pred = probclass.PredictionNetwork(pc, pc_cfg, ae.get_centers_variable())
+    x = dev(W.synthetic_image((1, 3, 64, 96), 'natural', seed=3), cuda)
+    sym = ae.encode(x, False).symbols[0].cpu().numpy()                      # (32, 8, 12): 3072 symbols
+    padded = pred.pad_symbols_volume(sym)
+    fd, path = tempfile.mkstemp(dir=str(tmp_path))
+    nbits, first, _ = bit_counter._encode(fd, padded, sym, pred)
+    data = open(path, 'rb').read()
+    assert len(data) * 8 == nbits
+    out = pred.decode_stream(data, sym.shape, first)
+    assert out.dtype == np.int64 and np.array_equal(out, sym)
+    ref = pred.undo_pad_symbols_volume(bit_counter._decode(path, padded.shape, pred.input_ctx_shape, first, pred.get_freqs))
+    assert np.array_equal(ref, sym)
+    cut = pred.decode_stream(data[:len(data) // 2], sym.shape, first)
+    assert cut.shape == sym.shape and cut.min() >= 0 and cut.max() < 6 and not np.array_equal(cut, sym)
+    n_same = int(np.argmax(cut.reshape(-1) != sym.reshape(-1)))
+    assert n_same > sym.size // 4                                        # everything before the cut is still right
+    one = pred.decode_stream(b'', (1, 1, 1), 4)
+    assert one.tolist() == [[[4]]]
 
 
 def test_blockwise_logits_bit_identical_to_full_volume(cuda, configs, syn_weights, nets):
