@@ -150,10 +150,22 @@ def main():
         # 'achieved' counts the ALGORITHMIC (direct-form) multiply-adds of the layer; the Winograd
         # form issues 16/36 of them to the matrix cores -- 'executed_*' is what the MFMA pipe actually did.
         executed = achieved * (16.0 / 36.0 if wino else 1.0)
+        # HBM-side bytes per launch: PMC counters cannot be read from inside this process; they are collected with
+        # rocprofv3 --pmc on the same kernel and shape (tools/pmc_wino.sh) and committed under profiles/
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_conv3x3_traffic.json')) as f:
+                tj = json.load(f)
+            if tj['shape'] == [N, 128, h4, w4]:
+                e = tj['winograd F(2x2,3x3)' if wino else 'direct']
+                traffic, traffic_src = e['fetch_bytes'] + e['write_bytes'], tj['source']
+        except (IOError, OSError, KeyError, ValueError):
+            pass
         roofline = {'kernel': ('wino3x3_c128_kernel' if wino else 'conv3x3_c128_kernel') + ' (ic_conv3x3_c128_auto_f32)',
                     'algorithm': 'winograd F(2x2,3x3)' if wino else 'direct', 'bound': 'mfma',
                     'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                    'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_unit': 'bytes per launch',
+                    'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': int(3 * 512 * N * h4 * w4 + (1048576 if wino else 589824)),
                     'executed_tflops': round(executed, 2), 'executed_frac': round(executed / PEAK_F32_MFMA_TFLOPS, 4),
                     'avg_launch_us': round(ms_conv * 1e3, 2), 'flop_per_launch': flop,
                     'launches_per_step': 2 * (6 * int(ae_cfg.arch_param_B) + 2)}
