@@ -263,6 +263,8 @@ static void phase_taps(int K, int pad, int p, int* nt, int* o0, int* kb) {
 }
 
 static bool supported(int KH, int KW, int Cin, int Cout, int stride, int transposed) {
+    // 3x3 / 2 conv 128 -> <= 128: the data gradient of from_bn (adjoint of its 3x3 / 2 transposed conv) in training
+    if (KH == 3 && KW == 3 && stride == 2 && !transposed) return Cin == 128 && Cout <= 128;
     if (KH != 5 || KW != 5 || stride != 2) return false;
     if (!transposed) return (Cin == 64 && Cout == 128) || (Cin == 128 && Cout <= 128);
     return Cin == 128 && Cout == 64;
@@ -318,7 +320,11 @@ extern "C" int ic_conv2d_mfma_bn_act_f32(const float* x, const float* w_packed, 
         ph.wp = w_packed; ph.py = 0; ph.px = 0;
         ph.oy0 = -ic_same_pad_before(H, KH, 2); ph.ox0 = -ic_same_pad_before(W, KW, 2);
         a.GH = ic_cdiv(H, 2); a.GW = ic_cdiv(W, 2); a.OH = a.GH; a.OW = a.GW; a.OS = 1;
-        if (Cin == 64) {            // h2: 4 channel tiles x 32 pixels per work-group
+        if (KH == 3) {              // from_bn's adjoint: as to_bn, 9 taps
+            a.tiles_x = ic_cdiv(a.GW, 16); a.tiles_y = ic_cdiv(a.GH, 2);
+            hipLaunchKernelGGL((conv_mfma_kernel<3, 3, 2, 128, 1, 1, 4, 1, 2, 16, 3>),
+                               dim3(a.tiles_x * a.tiles_y * N, ncot), dim3(256), 0, st, a, ph);
+        } else if (Cin == 64) {     // h2: 4 channel tiles x 32 pixels per work-group
             a.tiles_x = ic_cdiv(a.GW, 16); a.tiles_y = ic_cdiv(a.GH, 2);
             hipLaunchKernelGGL((conv_mfma_kernel<5, 5, 2, 64, 4, 1, 1, 1, 2, 16, 5>),
                                dim3(a.tiles_x * a.tiles_y * N, ncot / 4), dim3(256), 0, st, a, ph);

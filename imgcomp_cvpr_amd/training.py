@@ -145,12 +145,22 @@ class TrainGraph(object):
 
     # ---- raw convolution (no BN, no activation): forward and data-gradient use ----
     def _conv3x3(self, x, w_tf, backward=False):
+        """raw 3x3 128->128 conv (backward: its adjoint = the data gradient).  The filter is re-packed every call (it
+        changes every step) -- only in the form the launch will use."""
         N, _, H, W = x.shape
-        wp = self._new(self.packed3)
-        check(lib.ic_pack_conv3x3_c128_both_f32(ptr(w_tf), ptr(wp), int(backward), self._st()))
         y = self._new(N, 128, H, W)
-        check(lib.ic_conv3x3_c128_auto_f32(ptr(x), ptr(wp), ptr(self.ones), ptr(self.zeros), None, None, ptr(y),
-                                             N, H, W, 0, self._st()), 'conv3x3')
+        st = self._st()
+        if lib.ic_conv3x3_c128_pick_algo(N, H, W) == 1:
+            wp = self._new(lib.ic_wino3x3_c128_packed_floats())
+            check(lib.ic_pack_wino3x3_c128_f32(ptr(w_tf), ptr(wp), int(backward), st))
+            check(lib.ic_wino3x3_c128_bn_act_f32(ptr(x), ptr(wp), ptr(self.ones), ptr(self.zeros), None, None, ptr(y),
+                                                 N, H, W, 0, st), 'conv3x3 (winograd)')
+        else:
+            wp = self._new(lib.ic_conv3x3_c128_packed_floats())
+            f = lib.ic_pack_conv3x3_c128_bwd_f32 if backward else lib.ic_pack_conv3x3_c128_f32
+            check(f(ptr(w_tf), ptr(wp), st))
+            check(lib.ic_conv3x3_c128_bn_act_f32(ptr(x), ptr(wp), ptr(self.ones), ptr(self.zeros), None, None, ptr(y),
+                                                 N, H, W, 0, st), 'conv3x3')
         return y
 
     def _conv_s(self, x, w_tf, kh, kw, cin, cout, stride):

@@ -98,25 +98,29 @@ def test_deconv2d(cuda, name, N, Cin, H, W, Cout, K, relu, denorm):
     ('to_bn_hi', 1, 128, 10, 18, 65, 0, 0),
     ('h12', 1, 128, 9, 13, 64, 1, 1),
     ('h12_b', 2, 128, 8, 32, 64, 1, 1),
+    ('from_bn_adjoint_k3', 2, 128, 12, 20, 32, 0, 0),
+    ('from_bn_adjoint_k3_odd', 1, 128, 11, 17, 64, 0, 1),
 ])
 def test_conv2d_mfma_strided(cuda, name, N, Cin, H, W, Cout, transposed, relu):
-    """matrix-core path of h2 / to_bn / h12 (packed filters, transposed conv as four phases)."""
+    """matrix-core path of h2 / to_bn / h12 (packed filters, transposed conv as four phases) and of the 3x3 / 2 conv
+    that is from_bn's data gradient."""
     L = _lib()
+    K = 3 if '_k3' in name else 5
     rs = np.random.RandomState(zlib.crc32(name.encode()) % 1000 + 7)
     x = rs.normal(0, 1, (N, Cin, H, W)).astype(np.float32)
-    wshape = (5, 5, Cout, Cin) if transposed else (5, 5, Cin, Cout)
+    wshape = (K, K, Cout, Cin) if transposed else (K, K, Cin, Cout)
     w = rs.normal(0, 0.05, wshape).astype(np.float32)
     scale, shift = _bn(rs, Cout)
-    n = L.lib.ic_conv2d_mfma_packed_floats(5, 5, Cin, Cout, 2, transposed)
+    n = L.lib.ic_conv2d_mfma_packed_floats(K, K, Cin, Cout, 2, transposed)
     assert n > 0
     d = lambda a: dev(a, cuda)
     xd, wd, sd, hd = d(x), d(w), d(scale), d(shift)
     wp = torch.empty(n, device=cuda)
-    L.check(L.lib.ic_pack_conv2d_mfma_f32(L.ptr(wd), L.ptr(wp), 5, 5, Cin, Cout, 2, transposed, L.current_stream()))
+    L.check(L.lib.ic_pack_conv2d_mfma_f32(L.ptr(wd), L.ptr(wp), K, K, Cin, Cout, 2, transposed, L.current_stream()))
     oshape = (N, Cout, 2 * H, 2 * W) if transposed else (N, Cout, -(-H // 2), -(-W // 2))
     y = torch.full(oshape, float('nan'), device=cuda)
     L.check(L.lib.ic_conv2d_mfma_bn_act_f32(L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(y), N, Cin, H, W, Cout,
-                                            5, 5, 2, transposed, relu, L.current_stream()))
+                                            K, K, 2, transposed, relu, L.current_stream()))
     torch.cuda.synchronize()
     ref = _ref_conv(x, w, scale, shift, 2, relu, transposed=bool(transposed))
     assert_close(y, ref, 'conv2d mfma ' + name)
