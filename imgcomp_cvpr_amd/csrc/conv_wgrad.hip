@@ -16,8 +16,9 @@
 
 typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define WG_KP 32            // positions per LDS chunk
-#define WG_LS 33            // LDS row stride (floats)
+#define WG_LS 36            // LDS row stride (floats): 16-byte aligned rows, 36 * row mod 64 spreads 16 rows over all banks
 
 struct WgArgs {
     const float* U; const float* V; float* partial;
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(64 * WA * WB) void conv_wgrad_kernel(const WgArgs a
     constexpr int ROWS = AT + BT;
     constexpr int RPT = ROWS / (NTH / 32);                     // rows each thread stages (its pixel column is fixed)
     static_assert(ROWS % (NTH / 32) == 0, "rows divide evenly over the thread rows");
-    __shared__ float lds[2][ROWS * WG_LS];
+    __shared__ __attribute__((aligned(16))) float lds[2][ROWS * WG_LS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wa = wave % WA, wb = wave / WA;
@@ -132,18 +133,25 @@ __global__ __launch_bounds__(64 * WA * WB) void conv_wgrad_kernel(const WgArgs a
         const bool more = q0 + WG_KP < q_end;
         if (more) fetch(q0 + WG_KP);
         const float* __restrict__ L = lds[buf];
+        // k-step order inside the chunk: k-step 4 j4 + e multiplies positions (4 j4 + e, 16 + 4 j4 + e) -- the MFMA's two
+        // k lanes take position p and p + 16 instead of 2 ks and 2 ks + 1 (any pairing sums the same products), so a
+        // lane's operands of four consecutive k-steps are 16 contiguous bytes: one ds_read_b128 instead of four b32.
 #pragma unroll
-        for (int ks = 0; ks < WG_KP / 2; ++ks) {
-            float av[TA], bv[TB];
-#pragma unroll
-            for (int i = 0; i < TA; ++i) av[i] = L[(32 * (TA * wa + i) + li) * WG_LS + 2 * ks + kh];
-#pragma unroll
-            for (int j = 0; j < TB; ++j) bv[j] = L[(AT + 32 * (TB * wb + j) + li) * WG_LS + 2 * ks + kh];
+        for (int j4 = 0; j4 < WG_KP / 8; ++j4) {
+            f32x4 av[TA], bv[TB];
 #pragma unroll
             for (int i = 0; i < TA; ++i)
+                av[i] = *(const f32x4*)(L + (32 * (TA * wa + i) + li) * WG_LS + 16 * kh + 4 * j4);
 #pragma unroll
-                for (int j = 0; j < TB; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TB; ++j)
+                bv[j] = *(const f32x4*)(L + (AT + 32 * (TB * wb + j) + li) * WG_LS + 16 * kh + 4 * j4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TA; ++i)
+#pragma unroll
+                    for (int j = 0; j < TB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
         }
         if (more) stash(buf ^ 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
