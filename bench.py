@@ -211,6 +211,7 @@ def main():
         out.update(extra)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()                 # rank 0 is still timing the stage split / dominant kernel: leave together
         dist.destroy_process_group()
 
 
