@@ -1,6 +1,8 @@
 """Training driver -- the train.py entry point of the reference (code/train.py) on the MI355X kernels.
 
-    python -m imgcomp_cvpr_amd.train AE_CONFIG PC_CONFIG [--log_dir_root DIR] [--dataset_train GLOB | --synthetic]
+    python -m imgcomp_cvpr_amd.train AE_CONFIG PC_CONFIG [--log_dir_root DIR] [--dataset_train DS | --synthetic]
+        DS as in inputpipeline.get_dataset: imgnet_train / imgnet_test (TFRecord shards under $RECORDS_ROOT),
+        a paths .pkl, or an image glob
                                      [--max_itr N] [--log_interval 100] [--save_interval 1000] [--restore CKPT|DIR|FILE.npz]
 
     multi-GPU (data parallel, one process per GPU, RCCL):
@@ -65,9 +67,8 @@ class CropLoader(object):
                            for i in range(8)]
             self._pool = None
         else:
-            self.paths = sorted(glob.glob(images_glob))
-            if not self.paths:
-                raise ValueError('Not matching any files: {}'.format(images_glob))
+            from . import datasets
+            self.dataset = datasets.get_dataset(images_glob)          # record shards, paths pickle or image glob
             self.images = None
             import threading
             self._pool, self._lock = [], threading.Condition()
@@ -81,13 +82,10 @@ class CropLoader(object):
 
     @property
     def num_images(self):
-        return len(self.images) if self.synthetic else len(self.paths)
+        return len(self.images) if self.synthetic else self.dataset.num_images
 
     def _image(self, i):
-        if self.synthetic:
-            return self.images[i]
-        from PIL import Image
-        return np.transpose(np.asarray(Image.open(self.paths[i]).convert('RGB'), dtype=np.uint8), (2, 0, 1))
+        return self.images[i]
 
     def _crops_of(self, im, rs):
         H, W = im.shape[1:]
@@ -103,8 +101,13 @@ class CropLoader(object):
 
     def _worker(self, seed):
         rs = np.random.RandomState(seed)
-        while not self._stop:
-            crops = self._crops_of(self._image(rs.randint(self.num_images)), rs)
+        for im_hwc in self.dataset.stream(rs):
+            if self._stop:
+                return
+            H, W = im_hwc.shape[:2]
+            if H < self.crop[0] or W < self.crop[1]:
+                continue                                   # tf.random_crop would fail the queue runner; skip instead
+            crops = self._crops_of(np.transpose(im_hwc, (2, 0, 1)), rs)
             with self._lock:
                 while len(self._pool) + len(crops) > self._capacity and not self._stop:
                     self._lock.wait(0.1)
@@ -200,7 +203,7 @@ def main(argv=None):
     p.add_argument('autoencoder_config_path')
     p.add_argument('probclass_config_path')
     p.add_argument('--log_dir_root', '-o', default='logs')
-    p.add_argument('--dataset_train', help='glob of training images')
+    p.add_argument('--dataset_train', help='imgnet_train | paths .pkl | image glob (inputpipeline.get_dataset)')
     p.add_argument('--synthetic', action='store_const', const=True, help='seeded synthetic images instead of files')
     p.add_argument('--max_itr', type=int, default=1000)
     p.add_argument('--log_interval', type=int, default=100)
@@ -213,7 +216,7 @@ def main(argv=None):
         torch.cuda.set_device(local)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     if not flags.synthetic and not flags.dataset_train:
-        p.error('--dataset_train GLOB or --synthetic')
+        p.error('--dataset_train DS or --synthetic')
 
     def loader_fn(ae_config, batch, rank):
         return CropLoader(flags.dataset_train, ae_config.crop_size, batch, seed=rank, synthetic=bool(flags.synthetic))

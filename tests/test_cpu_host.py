@@ -430,3 +430,59 @@ def test_crop_loader_files_and_synthetic(tmp_path):
     S2 = train.CropLoader(None, (64, 64), 6, seed=1, synthetic=True)
     assert np.array_equal(S1.get_batch(), S2.get_batch())
     assert train.NUM_CROPS_PER_IMG == 8
+
+
+def test_datasets_tfrecord_pickle_glob(tmp_path, monkeypatch):
+    """N4: the three dataset forms of inputpipeline.get_dataset -- TFRecord shards ('image/encoded' feature, CRC-checked
+    container), a paths pickle relative to its directory, an image glob -- all stream decoded RGB images; the crop loader
+    runs on top of a record set."""
+    import io
+    import pickle
+    from PIL import Image
+    from imgcomp_cvpr_amd import datasets as D, train
+    imgs, encoded = [], []
+    for i in range(5):
+        a = np.random.RandomState(i).randint(0, 255, (70 + i, 90, 3), dtype=np.uint8)
+        buf = io.BytesIO()
+        Image.fromarray(a).save(buf, format='PNG')
+        imgs.append(a)
+        encoded.append(buf.getvalue())
+        Image.fromarray(a).save(str(tmp_path / 'im{}.png'.format(i)))
+    (tmp_path / 'train').mkdir()
+    D.write_tfrecord(str(tmp_path / 'train' / 'a.tfrecord'),
+                     [D.make_example({'image/format': b'PNG', 'image/encoded': e}) for e in encoded[:3]])
+    D.write_tfrecord(str(tmp_path / 'train' / 'b.tfrecord'),
+                     [D.make_example({'image/encoded': e, 'image/class/label': b'7'}) for e in encoded[3:]])
+    recs = list(D.iter_tfrecord(str(tmp_path / 'train' / 'a.tfrecord'), verify=True))
+    assert len(recs) == 3 and D.example_bytes_feature(recs[1], 'image/encoded') == encoded[1]
+    assert D.example_bytes_feature(recs[0], 'image/format') == b'PNG'
+    with pytest.raises(KeyError):
+        D.example_bytes_feature(recs[0], 'nope')
+    raw = bytearray(open(str(tmp_path / 'train' / 'a.tfrecord'), 'rb').read())
+    raw[40] ^= 1
+    open(str(tmp_path / 'bad.tfrecord'), 'wb').write(bytes(raw))
+    with pytest.raises(ValueError):
+        list(D.iter_tfrecord(str(tmp_path / 'bad.tfrecord'), verify=True))
+    monkeypatch.setenv('RECORDS_ROOT', str(tmp_path))
+    ds = D.get_dataset('imgnet_train')
+    assert ds.num_images == 1281167 and len(ds.files) == 2
+    it = ds.stream(np.random.RandomState(0))
+    got = [next(it) for _ in range(10)]                               # two epochs
+    for g in got:
+        assert any(g.shape == a.shape and np.array_equal(g, a) for a in imgs)
+    assert len({g.shape[0] for g in got}) == 5
+    with pytest.raises(ValueError):
+        D.get_dataset('imgnet_test')                                  # no $RECORDS_ROOT/val shards
+    with open(str(tmp_path / 'paths.pkl'), 'wb') as f:
+        pickle.dump(['im0.png', 'im3.png'], f)
+    dp = D.get_dataset(str(tmp_path / 'paths.pkl'))
+    assert dp.num_images == 2 and next(dp.stream(np.random.RandomState(1))).shape[1] == 90
+    dg = D.get_dataset(str(tmp_path / '*.png'))
+    assert dg.num_images == 5
+    with pytest.raises(ValueError):
+        D.get_dataset(str(tmp_path / '*.bmp'))
+    L = train.CropLoader('imgnet_train', (64, 64), 4, seed=0, capacity=32, min_after_dequeue=8, num_threads=2)
+    try:
+        assert L.get_batch().shape == (4, 3, 64, 64) and L.num_images == 1281167
+    finally:
+        L.close()
