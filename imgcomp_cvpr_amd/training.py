@@ -38,11 +38,13 @@ _IMG_VAR = (4746.37695312, 4454.13964844, 4812.234375)
 class GradBuckets(object):
     """Data-parallel gradient exchange over flat buckets: `ready(name)` starts an asynchronous all-reduce of that
     bucket as soon as the caller has finished writing it, `wait()` blocks on all of them and turns the sums into
-    means.  Works on any process group (RCCL on the GPUs; gloo in the CPU tests).  World size 1: no-ops."""
+    means.  Works on any process group (RCCL on the GPUs; gloo in the CPU tests).  World size 1: no-ops, unless
+    `always_reduce` (tests: exercises the RCCL path and its stream ordering on a single GPU)."""
 
-    def __init__(self, flat_tensors, process_group=None):
+    def __init__(self, flat_tensors, process_group=None, always_reduce=False):
         self.flat = flat_tensors            # dict name -> 1-D tensor
         self.pg = process_group
+        self.always_reduce = always_reduce
         self._pending = []
 
     def _world(self):
@@ -54,7 +56,7 @@ class GradBuckets(object):
     def ready(self, name):
         import torch.distributed as dist
         world = self._world()
-        if world == 1:
+        if world == 1 and not self.always_reduce:
             return
         # ProcessGroupNCCL orders the collective after the work already queued on the current stream
         work = dist.all_reduce(self.flat[name], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)

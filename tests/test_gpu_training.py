@@ -253,3 +253,29 @@ def test_train_entry_point(cuda, tmp_path):
     ae = autoencoder.get_network_cls(tr.graph.ae_config)(tr.graph.ae_config).load_weights(wts, cuda)
     enc = ae.encode(torch.zeros((1, 3, 64, 64), device=cuda), is_training=False)       # inference on the trained variables
     assert bool(torch.isfinite(enc.z).all())
+
+
+def test_gradient_buckets_over_rccl_single_rank(cuda, configs, syn_weights):
+    """the RCCL path on the real device: a one-rank `nccl` process group, every bucket all-reduced asynchronously while
+    backward continues (stream ordering between the HIP kernels on torch's current stream and RCCL's stream) -- the
+    gradients must equal those of the run without any exchange."""
+    import torch.distributed as dist
+    from imgcomp_cvpr_amd import training, weights as W
+    ae_cfg, pc_cfg = configs
+    x = dev(W.synthetic_image((4, 3, 64, 64), 'natural', seed=5), cuda)
+    g0 = training.TrainGraph(ae_cfg, pc_cfg, syn_weights, device=str(cuda))
+    g0.forward_backward(x)
+    ref = {k: v.clone() for k, v in g0.flat_grads.items()}
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29531', rank=0, world_size=1,
+                                device_id=torch.device(cuda))
+    try:
+        g1 = training.TrainGraph(ae_cfg, pc_cfg, syn_weights, device=str(cuda))
+        g1.buckets.always_reduce = True
+        out = g1.forward_backward(x)
+        torch.cuda.synchronize()
+        assert np.isfinite(out['d_loss_scaled'])
+        for k in ref:
+            assert torch.equal(g1.flat_grads[k], ref[k]), k
+    finally:
+        dist.destroy_process_group()

@@ -13,6 +13,7 @@ pc = probclass.get_network_cls(pc_cfg)(pc_cfg, num_centers=ae_cfg.num_centers).l
 x = torch.as_tensor(W.synthetic_image((1, 3, 512, 768), 'natural', seed=0)).float().to(dev)
 pad = float(wts['autoencoder/encoder/centers'][0])
 side = torch.cuda.Stream(device=dev)
+hi = torch.cuda.Stream(device=dev, priority=-1)
 
 def run(mode):
     cur = torch.cuda.current_stream(dev)
@@ -28,6 +29,14 @@ def run(mode):
             bc = pc.bitcost(enc.qbar, enc.symbols, False, pad_value=pad); bits.bitcost_to_bpp(bc, x)
         ae.decode(enc.qhard, False)
         cur.wait_stream(side)
+    elif mode == 'prio':             # decoder on a high-priority stream, context model stays on the current one
+        hi.wait_stream(cur)
+        with torch.cuda.stream(hi):
+            ae.decode(enc.qhard, False)
+        bc = pc.bitcost(enc.qbar, enc.symbols, False, pad_value=pad); bits.bitcost_to_bpp(bc, x)
+        cur.wait_stream(hi)
+    elif mode == 'prio2':            # whole autoencoder on the high-priority stream
+        pass
     elif mode == 'side_after':       # decoder first, context model enqueued afterwards on the side stream
         ev = torch.cuda.Event(); ev.record(cur)
         ae.decode(enc.qhard, False)
@@ -36,7 +45,7 @@ def run(mode):
             bc = pc.bitcost(enc.qbar, enc.symbols, False, pad_value=pad); bits.bitcost_to_bpp(bc, x)
         cur.wait_stream(side)
 
-for mode in ('nopc', 'serial', 'side', 'side_after', 'nopc', 'serial', 'side'):
+for mode in ('nopc', 'serial', 'side', 'prio', 'nopc', 'serial', 'side', 'prio'):
     for _ in range(3): run(mode)
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(20): run(mode)
