@@ -249,3 +249,34 @@ def test_val_entry_point(cuda, tmp_path, configs, syn_weights):
     bpp_real, bpp_theory = f.real_bpp(enc.symbols.cpu().numpy(), bpp_helpers.num_pixels_in_image(img))
     assert abs(bpp_theory - bpp_loss) < 1e-3
     assert abs(bpp_real - bpp_theory) * 32 * 48 < 58
+
+
+def test_high_rate_config_matches_oracle(cuda):
+    """BASELINE config 5 in the small: ae_configs/cvpr/hi (64 bottleneck channels, to_bn emits 65) with
+    pc_configs/cvpr/res_shallow_64 (64 feature maps: the k = 64 instantiations of the context-model kernels) through
+    the whole path against the oracle."""
+    from imgcomp_cvpr_amd import autoencoder, probclass, bits, config_parser as cp, weights as W
+    from oracle import oracle as O
+    ae_cfg, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'hi'))
+    pc_cfg, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow_64'))
+    assert ae_cfg.num_chan_bn == 64 and pc_cfg.arch_param__k == 64
+    wts = W.synthetic_weights(ae_cfg, pc_cfg, seed=77)
+    ae = autoencoder.get_network_cls(ae_cfg)(ae_cfg).load_weights(wts, cuda)
+    pc = probclass.get_network_cls(pc_cfg)(pc_cfg, num_centers=ae_cfg.num_centers).load_weights(wts, cuda)
+    x = W.synthetic_image((1, 3, 48, 80), 'natural', seed=9)
+    xd = dev(x, cuda)
+    enc = ae.encode(xd, False)
+    assert tuple(enc.symbols.shape) == (1, 64, 6, 10)
+    ref = O.encode(torch.as_tensor(x).double(), wts, ae_cfg.as_dict())
+    assert_close(enc.z, ref.z, 'z (hi)')
+    assert_close(enc.heatmap, ref.heatmap, 'heatmap (hi)')
+    assert (enc.symbols.cpu() != ref.symbols).float().mean() < 5e-3
+    x_out = ae.decode(enc.qhard, False)
+    bc = pc.bitcost(enc.qbar, enc.symbols, False, pad_value=pc.auto_pad_value(ae))
+    sym = enc.symbols.cpu()
+    centers = wts['autoencoder/encoder/centers']
+    q = torch.as_tensor(centers)[sym].double()
+    rb, _ = O.bitcost(q, sym, wts, float(centers[0]))
+    assert_close(bc, rb, 'bit cost (hi, k = 64)')
+    assert_close(x_out, O.decode(q, wts, ae_cfg.as_dict()), 'x_out (hi)')
+    assert abs(float(bits.bitcost_to_bpp(bc, xd)) - O.bitcost_to_bpp(rb, torch.as_tensor(x))) < 1e-4
