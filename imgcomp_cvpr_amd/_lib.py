@@ -57,6 +57,7 @@ PROTOTYPES = {
                                   c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),
     'ic_pc_logits_to_freqs_f32': (c_int, [c_void_p, c_longlong, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     'ic_pc_decode_workspace_bytes': (c_size_t, [c_int] * 4),
+    'ic_pc_decode_set_mode': (c_int, [c_int]),
     'ic_pc_decode_f32': (c_int, [c_void_p, c_longlong, c_int, POINTER(c_void_p), c_void_p, c_int, c_int, c_float,
                                  c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'ic_sum_f32': (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p]),

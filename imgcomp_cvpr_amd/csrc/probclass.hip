@@ -144,6 +144,7 @@ typedef float pc_f32x16 __attribute__((ext_vector_type(16)));
 typedef float pc_f32x4 __attribute__((ext_vector_type(4)));
 
 #define PC_NT 14          // live taps of the "other" mask, order (kd,kh,kw)
+#define PC_NP 4           // partial sums per output (see pc_mfma_kernel)
 __device__ __forceinline__ constexpr int pc_tap_kd(int t) { return t < 9 ? 0 : 1; }
 __device__ __forceinline__ constexpr int pc_tap_kh(int t) { return t < 9 ? t / 3 : (t < 12 ? 0 : 1); }
 __device__ __forceinline__ constexpr int pc_tap_kw(int t) { return t < 9 ? t % 3 : (t < 12 ? t - 9 : t - 12); }
@@ -204,13 +205,22 @@ __global__ __launch_bounds__(256) void pc_mfma_kernel(const PcLayerArgs a, const
     const pc_f32x4* __restrict__ wp = reinterpret_cast<const pc_f32x4*>(wpk) + (size_t)cot * 64 + lane;
     const int wstep = ncot * 64;
 
-    pc_f32x16 acc;
+    // The K sequence (chunk, 8-channel group, tap, k-step) is cut into PC_NP contiguous parts with one accumulator each,
+    // summed as (p0 + p1) + (p2 + p3) in the epilogue.  A dependent fp32 MFMA chain issues only every ~128 clocks; the
+    // parts are what lets the sequential decoder (pc_dec_fused_kernel) run one output's sum on four waves at once and
+    // still reproduce these logits bit for bit.
+    constexpr int STEPS_PER_CHUNK = C8 * PC_NT * 4, STEPS = NCH * STEPS_PER_CHUNK;
+    static_assert(STEPS % PC_NP == 0, "K steps divide into the partial sums");
+    pc_f32x16 accp[PC_NP];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int p = 0; p < PC_NP; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accp[p][r] = 0.f;
     pc_f32x4 ring[RD];
 #pragma unroll
     for (int t = 0; t < RD - 2; ++t) ring[t] = wp[(size_t)t * wstep];
 
+#pragma unroll
     for (int c = 0; c < NCH; ++c) {
         if (c > 0) __syncthreads();                       // everyone done reading the previous brick
         const float* xc = xin + (size_t)c * KC * cstride;
@@ -233,11 +243,15 @@ __global__ __launch_bounds__(256) void pc_mfma_kernel(const PcLayerArgs a, const
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const float bv = lds[boff + (8 * c8 + 2 * ks) * CS + tapoff];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[t % RD][ks], bv, acc, 0, 0, 0);
+                    const int part = (c * STEPS_PER_CHUNK + (c8 * PC_NT + t) * 4 + ks) / (STEPS / PC_NP);
+                    accp[part] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[t % RD][ks], bv, accp[part], 0, 0, 0);
                 }
             }
         }
     }
+    pc_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = (accp[0][r] + accp[1][r]) + (accp[2][r] + accp[3][r]);
 
     // epilogue: D[i][j], i = (r&3) + 8*(r>>2) + 4*kh output channel of tile `cot`, j = voxel
     const int oy = y0 + q / TC, ox = x0 + q % TC;
@@ -456,8 +470,9 @@ extern "C" int ic_pc_logits_to_freqs_f32(const float* logits, long long count, i
 #define PC_AC_BITS 32
 struct PcDecState {
     unsigned long long low, high, code;
-    long long byte_pos;
+    long long byte_pos;        // index of cur_byte (-1 before the first byte)
     int bit_left, cur_byte;
+    int nxt_byte;              // byte byte_pos + 1, requested one byte early so that its load latency is off the path
     int error;                 // 1: frequency total too large, 2: internal
     long long next;            // raster index of the next symbol to decode
 };
@@ -475,8 +490,10 @@ struct PcDecArgs {
 
 __device__ __forceinline__ int pc_dec_bit(const PcDecArgs& a, PcDecState& s) {
     if (s.bit_left == 0) {
-        if (s.byte_pos >= a.nbytes) return 0;          // past the end the stream reads as zeros (arithmetic_coding.py)
-        s.cur_byte = a.bits[s.byte_pos++];
+        s.cur_byte = s.nxt_byte;
+        s.byte_pos += 1;
+        const long long np = s.byte_pos + 1;
+        s.nxt_byte = np < a.nbytes ? a.bits[np] : 0;   // past the end the stream reads as zeros (arithmetic_coding.py)
         s.bit_left = 8;
     }
     --s.bit_left;
@@ -504,7 +521,7 @@ __global__ __launch_bounds__(256) void pc_dec_init_kernel(const PcDecArgs a) {
     if (threadIdx.x == 0) {
         PcDecState s;
         s.low = 0; s.high = (1ull << PC_AC_BITS) - 1; s.code = 0;
-        s.byte_pos = 0; s.bit_left = 0; s.cur_byte = 0; s.error = 0; s.next = 1;
+        s.byte_pos = -1; s.bit_left = 0; s.cur_byte = 0; s.nxt_byte = a.nbytes > 0 ? a.bits[0] : 0; s.error = 0; s.next = 1;
         for (int i = 0; i < PC_AC_BITS; ++i) s.code = (s.code << 1) | (unsigned)pc_dec_bit(a, s);
         *a.st = s;
         a.symbols[0] = a.first_sym;                       // the first symbol is not coded (bit_counter.py:117-121,152)
@@ -514,41 +531,50 @@ __global__ __launch_bounds__(256) void pc_dec_init_kernel(const PcDecArgs a) {
     if ((long long)a.C * a.h * a.w > 1) pc_dec_gather(a, 1);
 }
 
+// one symbol: integer table from the logits, range-decoder step (arithmetic_coding.py:ArithmeticDecoder.read + _narrow)
+__device__ int pc_dec_symbol(const PcDecArgs& a, PcDecState& s, const float* logits) {
+    const unsigned long long MASK = (1ull << PC_AC_BITS) - 1, TOP = 1ull << (PC_AC_BITS - 1), SECOND = TOP >> 1;
+    const unsigned long long MAX_TOTAL = (1ull << (PC_AC_BITS - 2)) + 2;
+    long long fr[16];
+    pc_table_row(logits, a.L, a.resolution, fr, nullptr);
+    unsigned long long total = 0;
+    for (int j = 0; j < a.L; ++j) total += (unsigned long long)fr[j];
+    if (total > MAX_TOTAL) s.error = 1;
+    const unsigned long long r = s.high - s.low + 1;
+    const unsigned long long value = ((s.code - s.low + 1) * total - 1) / r;
+    int sym = 0;
+    unsigned long long cum = 0;
+    while (sym + 1 < a.L && cum + (unsigned long long)fr[sym] <= value) { cum += (unsigned long long)fr[sym]; ++sym; }
+    const unsigned long long cum_lo = cum, cum_hi = cum + (unsigned long long)fr[sym];
+    s.high = s.low + cum_hi * r / total - 1;
+    s.low = s.low + cum_lo * r / total;
+    while (((s.low ^ s.high) & TOP) == 0) {
+        s.code = ((s.code << 1) & MASK) | (unsigned)pc_dec_bit(a, s);
+        s.low = (s.low << 1) & MASK;
+        s.high = ((s.high << 1) & MASK) | 1;
+    }
+    while ((s.low & ~s.high & SECOND) != 0) {
+        s.code = (s.code & TOP) | ((s.code << 1) & (MASK >> 1)) | (unsigned)pc_dec_bit(a, s);
+        s.low = (s.low << 1) & (MASK >> 1);
+        s.high = ((s.high << 1) & (MASK >> 1)) | TOP | 1;
+    }
+    return sym;
+}
+
+__device__ __forceinline__ void pc_dec_store(const PcDecArgs& a, long long idx, int sym) {
+    const int HW = a.h * a.w;
+    const int c = (int)(idx / HW), rr = (int)(idx - (long long)c * HW);
+    a.symbols[idx] = sym;
+    a.vol[((size_t)(c + 4) * (a.h + 8) + rr / a.w + 4) * (a.w + 8) + rr % a.w + 4] = a.centers[sym];
+}
+
 __global__ __launch_bounds__(256) void pc_dec_step_kernel(const PcDecArgs a) {
     __shared__ long long sh_next;
     if (threadIdx.x == 0) {
         PcDecState s = *a.st;
-        const unsigned long long MASK = (1ull << PC_AC_BITS) - 1, TOP = 1ull << (PC_AC_BITS - 1), SECOND = TOP >> 1;
-        const unsigned long long MAX_TOTAL = (1ull << (PC_AC_BITS - 2)) + 2;
-        long long fr[16];
-        pc_table_row(a.logits, a.L, a.resolution, fr, nullptr);
-        unsigned long long total = 0;
-        for (int j = 0; j < a.L; ++j) total += (unsigned long long)fr[j];
-        if (total > MAX_TOTAL) s.error = 1;
-        const unsigned long long r = s.high - s.low + 1;
-        const unsigned long long value = ((s.code - s.low + 1) * total - 1) / r;
-        int sym = 0;
-        unsigned long long cum = 0;
-        while (sym + 1 < a.L && cum + (unsigned long long)fr[sym] <= value) { cum += (unsigned long long)fr[sym]; ++sym; }
-        const unsigned long long cum_lo = cum, cum_hi = cum + (unsigned long long)fr[sym];
-        s.high = s.low + cum_hi * r / total - 1;
-        s.low = s.low + cum_lo * r / total;
-        while (((s.low ^ s.high) & TOP) == 0) {
-            s.code = ((s.code << 1) & MASK) | (unsigned)pc_dec_bit(a, s);
-            s.low = (s.low << 1) & MASK;
-            s.high = ((s.high << 1) & MASK) | 1;
-        }
-        while ((s.low & ~s.high & SECOND) != 0) {
-            s.code = (s.code & TOP) | ((s.code << 1) & (MASK >> 1)) | (unsigned)pc_dec_bit(a, s);
-            s.low = (s.low << 1) & (MASK >> 1);
-            s.high = ((s.high << 1) & (MASK >> 1)) | TOP | 1;
-        }
-        const long long idx = s.next;
-        const int HW = a.h * a.w;
-        const int c = (int)(idx / HW), rr = (int)(idx - (long long)c * HW);
-        a.symbols[idx] = sym;
-        a.vol[((size_t)(c + 4) * (a.h + 8) + rr / a.w + 4) * (a.w + 8) + rr % a.w + 4] = a.centers[sym];
-        s.next = idx + 1;
+        const int sym = pc_dec_symbol(a, s, a.logits);
+        pc_dec_store(a, s.next, sym);
+        s.next += 1;
         *a.st = s;
         sh_next = s.next;
         __threadfence_block();
@@ -556,6 +582,226 @@ __global__ __launch_bounds__(256) void pc_dec_step_kernel(const PcDecArgs a) {
     __syncthreads();
     if (sh_next < (long long)a.C * a.h * a.w) pc_dec_gather(a, sh_next);
 }
+
+// ---- the same loop as ONE persistent work-group (k = 24): no launches between symbols -------------------------------------
+// The five launches per symbol above cost ~5 us of launch latency each on top of ~5 us of work.  Here one work-group
+// keeps the coder state in registers and the activations of the current 5x9x9 context in LDS and runs, per symbol:
+// gather -> layer 0 (VALU, one lane per voxel) -> the three matrix-core layers -> table + range-decoder step.
+// Bit-identical to the parallel pass by construction: every output is the same operation sequence -- layer 0 the fmaf
+// chain of pc_conv3d_kernel<.., FIRST> in (kd,kh,kw) order, the other layers the MFMA chain of pc_mfma_kernel in
+// (8-channel chunk, tap, k-step) order with the same packed A fragments, then + bias, ReLU, + residual.  Only the
+// voxel -> lane assignment differs (the 75 / 18 / 1 output voxels of the context are packed densely into 32-voxel
+// accumulator tiles: three waves, one wave, one wave), which no output value depends on.
+struct PcFusedArgs {
+    PcDecArgs d;
+    const float* w0; const float* b0;          // layer 0: TF filter [2,3,3,1,k], bias
+    const float* pk1; const float* b1;         // packed k -> k
+    const float* pk2; const float* b2;
+    const float* pk3; const float* b3;         // packed k -> L
+    int* status;
+};
+
+// One of the PC_NP partial sums (steps [42 PART, 42 PART + 42) of the 168-step K sequence of pc_mfma_kernel<24, ...>) for
+// NTL 32-voxel tiles at once: input volume [24][ID][IH][IW] in LDS, output voxel q = 32 i + (lane & 31) of the
+// (ID-1, IH-2, IW-2) grid.  The tiles share the A fragments and give the wave independent accumulators to interleave.
+template <int ID, int IH, int IW, int NTL, int PART>
+__device__ __forceinline__ void pc_fused_part(const float* __restrict__ sin, const pc_f32x4* __restrict__ wp, int lane,
+                                              pc_f32x16 (&acc)[NTL]) {
+    constexpr int OH = IH - 2, OW = IW - 2, NV = (ID - 1) * OH * OW, IVOL = ID * IH * IW;
+    constexpr int G0 = 42 * PART, G1 = G0 + 42, TS0 = G0 / 4, TS1 = (G1 - 1) / 4;       // tap-steps (c8 * 14 + t) touched
+    static_assert(3 * PC_NT * 4 == 42 * PC_NP, "k = 24: 168 steps in 4 parts");
+    const int kh = lane >> 5;
+    int base[NTL];
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) {
+        const int q = 32 * i + (lane & 31);
+        const int qq = q < NV ? q : 0;
+        const int od = qq / (OH * OW), oy = (qq / OW) % OH, ox = qq % OW;
+        base[i] = (od * IH + oy) * IW + ox + kh * IVOL;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    }
+    pc_f32x4 av[TS1 - TS0 + 1];
+#pragma unroll
+    for (int ts = TS0; ts <= TS1; ++ts) av[ts - TS0] = wp[(size_t)ts * 64];               // all A fragments of the part up front
+#pragma unroll
+    for (int ts = TS0; ts <= TS1; ++ts) {
+        const int c8 = ts / PC_NT, t = ts % PC_NT;
+        const int tapoff = pc_tap_kd(t) * IH * IW + pc_tap_kh(t) * IW + pc_tap_kw(t);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int g = 4 * ts + ks;
+            if (g < G0 || g >= G1) continue;
+#pragma unroll
+            for (int i = 0; i < NTL; ++i) {
+                const float bv = sin[base[i] + (8 * c8 + 2 * ks) * IVOL + tapoff];
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ts - TS0][ks], bv, acc[i], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int ID, int IH, int IW, int NTL>
+__device__ __forceinline__ void pc_fused_layer(const float* __restrict__ sin, const float* __restrict__ pk, int wave, int lane,
+                                               pc_f32x16 (&acc)[NTL]) {
+    const pc_f32x4* wp = reinterpret_cast<const pc_f32x4*>(pk) + lane;
+    if (wave == 0) pc_fused_part<ID, IH, IW, NTL, 0>(sin, wp, lane, acc);
+    else if (wave == 1) pc_fused_part<ID, IH, IW, NTL, 1>(sin, wp, lane, acc);
+    else if (wave == 2) pc_fused_part<ID, IH, IW, NTL, 2>(sin, wp, lane, acc);
+    else pc_fused_part<ID, IH, IW, NTL, 3>(sin, wp, lane, acc);
+}
+
+__global__ __launch_bounds__(256) void pc_dec_fused_kernel(const PcFusedArgs f) {
+    constexpr int K = 24;
+    __shared__ float s_ctx[5 * 9 * 9];
+    __shared__ float s_a0[K * 196];            // layer 0 output  [k][4][7][7]
+    __shared__ float s_a1[K * 75];             // res1/conv1      [k][3][5][5]
+    __shared__ float s_a2[K * 18];             // res1/conv2 + skip [k][2][3][3]
+    __shared__ float s_logits[16];
+    __shared__ float s_red[4 * 16 * 64];       // the four partial accumulators of one tile, [part][register][lane]
+    __shared__ float s_w0[13 * K];             // layer-0 filter rows of the 13 live taps, live-tap order
+    __shared__ float s_bias[3 * K + 16];       // b0 | b1 | b2 | b3
+    __shared__ float s_centers[16];
+    const PcDecArgs& a = f.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, j = lane & 31;
+    for (int e = tid; e < 13 * K; e += 256) {
+        const int lt = e / K;                                   // live tap lt -> (kd,kh,kw): 0..8 = kd 0; 9..11 = (1,0,*); 12 = (1,1,0)
+        const int tap = lt < 9 ? lt : (lt < 12 ? 9 + (lt - 9) : 12);
+        s_w0[e] = f.w0[(size_t)tap * K + e % K];
+    }
+    if (tid < K) { s_bias[tid] = f.b0[tid]; s_bias[K + tid] = f.b1[tid]; s_bias[2 * K + tid] = f.b2[tid]; }
+    if (tid < a.L) { s_bias[3 * K + tid] = f.b3[tid]; s_centers[tid] = a.centers[tid]; }
+    const long long n = (long long)a.C * a.h * a.w;
+    PcDecState s;                               // lives in thread 0's registers for the whole volume
+    if (tid == 0) {
+        s.low = 0; s.high = (1ull << PC_AC_BITS) - 1; s.code = 0;
+        s.byte_pos = -1; s.bit_left = 0; s.cur_byte = 0; s.nxt_byte = a.nbytes > 0 ? a.bits[0] : 0; s.error = 0; s.next = 1;
+        for (int i = 0; i < PC_AC_BITS; ++i) s.code = (s.code << 1) | (unsigned)pc_dec_bit(a, s);
+        pc_dec_store(a, 0, a.first_sym);        // the first symbol is not coded
+    }
+    __syncthreads();
+    const int HW = a.h * a.w, PH = a.h + 8, PW = a.w + 8;
+#ifdef PC_DEC_PROF
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+#define PC_PH(i) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ph[i] += tn_ - tl; tl = tn_; } while (0)
+#else
+#define PC_PH(i) do { } while (0)
+#endif
+    for (long long idx = 1; idx < n; ++idx) {
+        // ---- context of symbol idx: padded block [c, c+5) x [y, y+9) x [x, x+9) ----
+        {
+            const int c = (int)(idx / HW), r = (int)(idx - (long long)c * HW);
+            const int y = r / a.w, x = r - y * a.w;
+            for (int e = tid; e < 405; e += 256) {
+                const int d = e / 81, r2 = e - d * 81;
+                s_ctx[e] = a.vol[((size_t)(c + d) * PH + y + r2 / 9) * PW + x + r2 % 9];
+            }
+        }
+        __syncthreads();
+        PC_PH(0);
+        // ---- layer 0: 1 -> k, first mask (13 live taps), + bias, ReLU; one lane = one of the 196 voxels ----
+        if (tid < 196) {
+            const int od = tid / 49, oy = (tid / 7) % 7, ox = tid % 7;
+            float acc[K];
+#pragma unroll
+            for (int c = 0; c < K; ++c) acc[c] = 0.f;
+#pragma unroll
+            for (int kd = 0; kd < 2; ++kd)
+#pragma unroll
+                for (int kh2 = 0; kh2 < 3; ++kh2)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const bool dead = (kd == 1) && (kh2 == 2 || (kh2 == 1 && kw >= 1));
+                        if (dead) continue;
+                        const float xv = s_ctx[(od + kd) * 81 + (oy + kh2) * 9 + ox + kw];
+                        const int tap = (kd * 3 + kh2) * 3 + kw;           // live taps are 0..12 in this order
+                        const float* wp = s_w0 + tap * K;
+#pragma unroll
+                        for (int c = 0; c < K; ++c) acc[c] = fmaf(xv, wp[c], acc[c]);
+                    }
+#pragma unroll
+            for (int c = 0; c < K; ++c) s_a0[c * 196 + tid] = fmaxf(acc[c] + s_bias[c], 0.f);
+        }
+        __syncthreads();
+        PC_PH(1);
+        // ---- res1/conv1: k -> k, ReLU; 75 voxels = 3 tiles; wave w computes partial sum w of all three ----
+        {
+            pc_f32x16 acc[3];
+            pc_fused_layer<4, 7, 7, 3>(s_a0, f.pk1, wave, lane, acc);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_red[(wave * 16 + r) * 64 + lane] = acc[i][r];
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int o = tid + 256 * e, r = o >> 6, ln = o & 63;
+                    const int co = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), q = 32 * i + (ln & 31);
+                    const float v = (s_red[o] + s_red[1024 + o]) + (s_red[2048 + o] + s_red[3072 + o]);
+                    if (co < K && q < 75) s_a1[co * 75 + q] = fmaxf(v + s_bias[K + co], 0.f);
+                }
+                __syncthreads();
+            }
+        }
+        PC_PH(2);
+        // ---- res1/conv2: k -> k, linear, + layer-0 output cropped [2:, 2:-2, 2:-2]; 18 voxels = 1 tile ----
+        {
+            pc_f32x16 acc[1];
+            pc_fused_layer<3, 5, 5, 1>(s_a1, f.pk2, wave, lane, acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_red[(wave * 16 + r) * 64 + lane] = acc[0][r];
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int o = tid + 256 * e, r = o >> 6, ln = o & 63;
+                const int co = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), q = ln & 31;
+                const float v = (s_red[o] + s_red[1024 + o]) + (s_red[2048 + o] + s_red[3072 + o]);
+                if (co < K && q < 18) {
+                    const int od = q / 9, oy = (q / 3) % 3, ox = q % 3;
+                    float x = v + s_bias[2 * K + co];
+                    x += s_a0[co * 196 + ((od + 2) * 7 + oy + 2) * 7 + ox + 2];
+                    s_a2[co * 18 + q] = x;
+                }
+            }
+            __syncthreads();
+        }
+        PC_PH(3);
+        // ---- conv2 (final): k -> L, ReLU; one voxel ----
+        {
+            pc_f32x16 acc[1];
+            pc_fused_layer<2, 3, 3, 1>(s_a2, f.pk3, wave, lane, acc);
+            if ((lane & 31) == 0) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) s_red[(wave * 16 + r) * 64 + lane] = acc[0][r];
+            }
+            __syncthreads();
+            if (tid < 16) {
+                // channel co lives in register r = (co & 3) + 4 * (co >> 3) of lane 32 * ((co >> 2) & 1)
+                const int co = tid, r = (co & 3) + 4 * (co >> 3), ln = 32 * ((co >> 2) & 1), o = r * 64 + ln;
+                const float v = (s_red[o] + s_red[1024 + o]) + (s_red[2048 + o] + s_red[3072 + o]);
+                if (co < a.L) s_logits[co] = fmaxf(v + s_bias[3 * K + co], 0.f);
+            }
+            __syncthreads();
+        }
+        PC_PH(4);
+        if (tid == 0) {
+            const int sym = pc_dec_symbol(a, s, s_logits);
+            const int c = (int)(idx / HW), rr = (int)(idx - (long long)c * HW);
+            a.symbols[idx] = sym;
+            a.vol[((size_t)(c + 4) * PH + rr / a.w + 4) * PW + rr % a.w + 4] = s_centers[sym];
+            __threadfence_block();
+        }
+        __syncthreads();
+        PC_PH(5);
+    }
+    if (tid == 0) *f.status = s.error;
+#ifdef PC_DEC_PROF
+    if (tid == 0) for (int i = 0; i < 6; ++i) ((unsigned long long*)a.st)[i] = ph[i];
+#endif
+}
+
+static int g_pc_dec_mode = 0;      // 0: automatic, 1: always the launch-per-layer loop (tests)
+extern "C" int ic_pc_decode_set_mode(int mode) { const int prev = g_pc_dec_mode; g_pc_dec_mode = mode; return prev; }
 
 static size_t pc_dec_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
@@ -597,6 +843,19 @@ extern "C" int ic_pc_decode_f32(const uint8_t* bitstream, long long nbytes, int 
         hipLaunchKernelGGL(pc_pack_kernel, dim3(ic_cdiv(t3, 256)), dim3(256), 0, st, wtab_host[6], pk3, k, L, 1, t3);
     }
     hipLaunchKernelGGL(pc_dec_fill_kernel, dim3((unsigned)((nvol + 255) / 256)), dim3(256), 0, st, a.vol, nvol, centers);
+    if (use_mfma && k == 24 && g_pc_dec_mode == 0) {
+        PcFusedArgs f{};
+        f.d = a;
+        float* pk1 = (float*)pcws + (size_t)k * (4 * 7 * 7 + 3 * 5 * 5 + 2 * 3 * 3);
+        f.w0 = wtab_host[0]; f.b0 = wtab_host[1];
+        f.pk1 = pk1; f.b1 = wtab_host[3];
+        f.pk2 = pk1 + pc_packed_floats(k, k); f.b2 = wtab_host[5];
+        f.pk3 = pk1 + 2 * pc_packed_floats(k, k); f.b3 = wtab_host[7];
+        f.status = status;
+        hipLaunchKernelGGL(pc_dec_fused_kernel, dim3(1), dim3(256), 0, st, f);
+        IC_LAUNCH_CHECK();
+        return IC_OK;
+    }
     hipLaunchKernelGGL(pc_dec_init_kernel, dim3(1), dim3(256), 0, st, a);
     IC_LAUNCH_CHECK();
     const long long n = (long long)C * h * w;

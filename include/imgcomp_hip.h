@@ -186,13 +186,16 @@ int ic_pc_logits_to_freqs_f32(const float* logits, long long count, int L, float
  * arithmetic-coded bit stream: per symbol the same context-model kernels as ic_pc_logits_padded_f32 run on the
  * gathered 5x9x9 context (identical tables by construction), and one small kernel builds the integer table, steps the
  * 32-bit range decoder (arithmetic_coding.py restated for the device), stores the symbol and gathers the next
- * context.  Work is enqueued on `stream` (volumes of >= 256 symbols replay a captured hipGraph of 128 symbol steps and
- * wait for it before returning; smaller ones are plain launches).
+ * context.  k = 24 runs the whole volume as ONE persistent work-group (coder state in registers, activations in LDS);
+ * other k enqueue five launches per symbol (volumes of >= 256 symbols replay a captured hipGraph of 128 symbol steps on a
+ * private stream and wait for it before returning).
  *   bitstream: device bytes written by the encoder (symbols 1..n-1 in raster order C,H,W; bit_counter.py:103-131)
  *   first_sym: the uncoded first symbol;  centers: device [L];  resolution: 1e9 (probclass.py:443)
  *   symbols: out, device int64 (C,h,w);  status: out, device int (0 ok, 1 = a table's total exceeded the coder's range)
  *   wtab_host / k / L as ic_pc_logits_f32.  workspace: ic_pc_decode_workspace_bytes(C, h, w, k). */
 size_t ic_pc_decode_workspace_bytes(int C, int h, int w, int k);
+/* tests: 1 forces the launch-per-layer loop, 0 (default) lets k = 24 run as one persistent work-group; returns previous */
+int ic_pc_decode_set_mode(int mode);
 int ic_pc_decode_f32(const uint8_t* bitstream, long long nbytes, int first_sym, const float* const* wtab_host,
                      const float* centers, int k, int L, float resolution, int64_t* symbols, int* status,
                      int C, int h, int w, void* workspace, size_t workspace_bytes, ic_stream_t stream);

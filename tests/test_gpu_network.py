@@ -187,8 +187,15 @@ def test_device_decoder_stream(cuda, configs, syn_weights, nets, tmp_path):
     nbits, first, _ = bit_counter._encode(fd, padded, sym, pred)
     data = open(path, 'rb').read()
     assert len(data) * 8 == nbits
-    out = pred.decode_stream(data, sym.shape, first)
+    out = pred.decode_stream(data, sym.shape, first)                        # k = 24: one persistent work-group
     assert out.dtype == np.int64 and np.array_equal(out, sym)
+    from imgcomp_cvpr_amd import _lib
+    prev = _lib.lib.ic_pc_decode_set_mode(1)                                # the launch-per-layer loop (any k)
+    try:
+        out2 = pred.decode_stream(data, sym.shape, first)
+    finally:
+        _lib.lib.ic_pc_decode_set_mode(prev)
+    assert np.array_equal(out2, sym)
     ref = pred.undo_pad_symbols_volume(bit_counter._decode(path, padded.shape, pred.input_ctx_shape, first, pred.get_freqs))
     assert np.array_equal(ref, sym)
     cut = pred.decode_stream(data[:len(data) // 2], sym.shape, first)

@@ -30,9 +30,14 @@ def main():
     pred.decode_stream(data[:64], (1, 2, 2), first)                # warm-up
     t = time.time(); out = pred.decode_stream(data, sym.shape, first); t_dec = time.time() - t
     ok = bool(np.array_equal(out, sym))
+    from imgcomp_cvpr_amd import _lib
+    prev = _lib.lib.ic_pc_decode_set_mode(1)
+    t = time.time(); out2 = pred.decode_stream(data, sym.shape, first); t_dec2 = time.time() - t
+    _lib.lib.ic_pc_decode_set_mode(prev)
     res = {'symbols': int(sym.size), 'bits': int(nbits), 'bpp_real': nbits / (a.height * a.width), 'bits_theory': theory,
            'encode_s': round(t_enc, 3), 'device_decode_s': round(t_dec, 3), 'device_decode_us_per_symbol': round(t_dec / sym.size * 1e6, 2),
-           'round_trip_ok': ok}
+           'round_trip_ok': ok,
+           'launch_per_layer_decode_s': round(t_dec2, 3), 'launch_per_layer_ok': bool(np.array_equal(out2, sym))}
     if a.host_loop:
         t = time.time()
         ref = pred.undo_pad_symbols_volume(bit_counter._decode(path, padded.shape, pred.input_ctx_shape, first, pred.get_freqs))
