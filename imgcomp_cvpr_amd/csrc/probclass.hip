@@ -163,7 +163,8 @@ __global__ void pc_pack_kernel(const float* __restrict__ w, float* __restrict__ 
 }
 
 template <int CIN, int KC, int WM, int WN, int TR, int TC, bool FINAL>
-__global__ __launch_bounds__(256) void pc_mfma_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void pc_mfma_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
     constexpr int S = TC + 2, DS = (TR + 2) * S, CS = 2 * DS, CHUNK = KC * CS;
     constexpr int NST = (CHUNK + 255) / 256;
     constexpr int NCH = CIN / KC, C8 = KC / 8, RD = 7;
@@ -243,15 +244,20 @@ __global__ __launch_bounds__(256) void pc_mfma_kernel(const PcLayerArgs a, const
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const float bv = lds[boff + (8 * c8 + 2 * ks) * CS + tapoff];
-                    const int part = (c * STEPS_PER_CHUNK + (c8 * PC_NT + t) * 4 + ks) / (STEPS / PC_NP);
+                    const int step = c * STEPS_PER_CHUNK + (c8 * PC_NT + t) * 4 + ks, part = step / (STEPS / PC_NP);
                     accp[part] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[t % RD][ks], bv, accp[part], 0, 0, 0);
+                    // fold finished parts as early as the summation order allows: fewer live accumulators
+                    if (step + 1 == 2 * (STEPS / PC_NP)) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) accp[0][r] = accp[0][r] + accp[1][r];
+                    }
                 }
             }
         }
     }
     pc_f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = (accp[0][r] + accp[1][r]) + (accp[2][r] + accp[3][r]);
+    for (int r = 0; r < 16; ++r) acc[r] = accp[0][r] + (accp[2][r] + accp[3][r]);       // accp[0] already holds p0 + p1
 
     // epilogue: D[i][j], i = (r&3) + 8*(r>>2) + 4*kh output channel of tile `cot`, j = voxel
     const int oy = y0 + q / TC, ox = x0 + q % TC;
