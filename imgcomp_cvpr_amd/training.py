@@ -336,7 +336,7 @@ class TrainGraph(object):
         net = self._cba_fwd(_weights.DEC + '/h12', net, True, tape=dec_tape_b)
         pre = self._cba_fwd(_weights.DEC + '/h13', net, False, tape=dec_tape_b)
         # ===== forward: context model on stop_gradient(qbar) =====
-        pad_value = float(centers[0]) if self.pc_config.use_centers_for_padding else 0.0
+        pad_value = self._pad_value() if self.pc_config.use_centers_for_padding else 0.0
         wtab_t = []
         for s in self.pc_scopes:
             wtab_t += [self.params[s + '/weights'], self.params[s + '/biases']]
@@ -370,13 +370,11 @@ class TrainGraph(object):
         H_mask = (bc * hm).mean() if self.heatmap else H_real
         H_soft = 0.5 * (H_mask + H_real)
         beta, H_t = float(cfg.beta), float(cfg.H_target)
-        active = bool(H_soft > H_t)
-        pc_loss = beta * max(float(H_soft) - H_t, 0.0)
-        if active:
-            d_bc = (hm + 1.0) * (0.5 * beta / count) if self.heatmap else torch.full_like(bc, beta / count)
-            d_hm = bc * (0.5 * beta / count) if self.heatmap else None
-        else:
-            d_bc, d_hm = torch.zeros_like(bc), (torch.zeros_like(bc) if self.heatmap else None)
+        # pc_loss = beta * max(H_soft - H_target, 0): the gate stays on the device (no host round trip mid-step)
+        pc_loss = beta * torch.clamp(H_soft - H_t, min=0.0)
+        gate = (H_soft > H_t).to(torch.float32) * (beta / count)
+        d_bc = (hm + 1.0) * (0.5 * gate) if self.heatmap else torch.ones_like(bc) * gate
+        d_hm = bc * (0.5 * gate) if self.heatmap else None
         # ===== backward: context model (its bucket is complete first) =====
         self._pc_backward(qbar, symbols, logits, d_bc, pc_ws, pad_value, N, C, h, w)
         self._bucket_ready('pc')
@@ -401,12 +399,28 @@ class TrainGraph(object):
         self._cba_bwd(enc_tape_a.pop(), g, need_dx=False)
         self._bucket_ready('enc')
         self._wait_buckets()
-        out = {'d_loss_scaled': float(d_loss.detach()), 'pc_loss': pc_loss, 'H_real': float(H_real), 'H_mask': float(H_mask),
-               'bpp': float(bc.sum()) / (N * H * W)}
-        if msssim is not None:
-            out['ms_ssim'] = float(msssim)
+        # one device -> host transfer for all the scalars of the step
+        stats = [d_loss.detach(), pc_loss, H_real, H_mask, bc.sum() / (N * H * W)] + ([msssim.detach()] if msssim is not None else [])
+        vals = torch.stack([t.to(torch.float32).reshape(()) for t in stats]).tolist()
+        out = dict(zip(['d_loss_scaled', 'pc_loss', 'H_real', 'H_mask', 'bpp', 'ms_ssim'], vals))
         self.last = {'x_out': x_out.detach(), 'symbols': symbols, 'bc': bc, 'heatmap': hm, 'z': z, 'qbar': qbar}
         return out
+
+    # ---- centres[0] on the host (the context model's pad value is a by-value argument of the C ABI) ----
+    def refresh_pad_value(self):
+        """asynchronous copy of centres[0] into pinned memory; call after the variables changed (Trainer.step does)."""
+        if not hasattr(self, '_c0_host'):
+            self._c0_host = torch.empty(1, dtype=torch.float32).pin_memory()
+            self._c0_event = torch.cuda.Event()
+        self._c0_host.copy_(self.params[_weights.ENC + '/centers'][:1], non_blocking=True)
+        self._c0_event.record(torch.cuda.current_stream(self.dev))
+        self._c0_fresh = True
+
+    def _pad_value(self):
+        if getattr(self, '_c0_fresh', False):
+            self._c0_event.synchronize()               # recorded a whole step ago: does not stall
+            return float(self._c0_host[0])
+        return float(self.params[_weights.ENC + '/centers'][0])
 
     def regularization_loss(self):
         """value of the L2 terms (their gradients are already folded into the filter gradients)."""
@@ -525,6 +539,7 @@ class Trainer(object):
         if g.ae_config.train_probclass:
             self.opt_pc.step(learning_rate(g.pc_config, self.global_step, self.num_itr_per_epoch))
         self.global_step += 1
+        g.refresh_pad_value()
         return out
 
     def state_weights(self):
