@@ -5,8 +5,10 @@
     shrunk for small images, 2x2 box down-sampling with 'reflect' at the far edge.
   * PSNR on uint8 images, 10 log10(255^2 / MSE) (reference code/val.py:227-232).
 
-Pure numpy; these run on the host exactly as in the reference (they are not part of the GPU hot path).
-Pinned against outputs of the reference's own implementation: tests/golden/msssim.npz.
+The numpy versions run on the host exactly as in the reference and are pinned against outputs of the reference's
+own implementation (tests/golden/msssim.npz).  val.py spends 0.5 s per Kodak image in them against 3.6 ms on the GPU
+for everything else, so the same float64 computation is also available on the device (`*_device`, torch float64, the
+same operations in the same order; agreement with the numpy path to ~1e-15 is tested).
 """
 import numpy as np
 
@@ -98,3 +100,72 @@ def psnr_uint8(a, b):
     if mse == 0:
         return np.float32(np.inf)
     return np.float32(10.0 * np.log10(255.0 ** 2 / mse))
+
+
+# ---- the same metrics in float64 on the device --------------------------------------------------------------------------
+
+def _blur_valid_t(img, g):
+    """torch twin of _blur_valid: (N,H,W,C) float64 tensor, taps accumulated in the same order."""
+    k = len(g)
+    H, W = img.shape[1], img.shape[2]
+    tmp = g[0] * img[:, 0:H - k + 1, :, :]
+    for i in range(1, k):
+        tmp = tmp + g[i] * img[:, i:i + H - k + 1, :, :]
+    out = g[0] * tmp[:, :, 0:W - k + 1, :]
+    for i in range(1, k):
+        out = out + g[i] * tmp[:, :, i:i + W - k + 1, :]
+    return out
+
+
+def _ssim_and_cs_t(img1, img2, max_val=255.0, filter_size=11, filter_sigma=1.5, k1=0.01, k2=0.03):
+    _, h, w, _ = img1.shape
+    size = min(filter_size, h, w)
+    g = [float(v) for v in _gauss1d(size, size * filter_sigma / filter_size)]
+    mu1, mu2 = _blur_valid_t(img1, g), _blur_valid_t(img2, g)
+    s11 = _blur_valid_t(img1 * img1, g) - mu1 * mu1
+    s22 = _blur_valid_t(img2 * img2, g) - mu2 * mu2
+    s12 = _blur_valid_t(img1 * img2, g) - mu1 * mu2
+    c1, c2 = (k1 * max_val) ** 2, (k2 * max_val) ** 2
+    v1 = 2.0 * s12 + c2
+    v2 = s11 + s22 + c2
+    ssim = (((2.0 * mu1 * mu2 + c1) * v1) / ((mu1 * mu1 + mu2 * mu2 + c1) * v2)).mean()
+    return ssim, (v1 / v2).mean()
+
+
+def _downsample2_t(img):
+    import torch
+    p = torch.cat([img, img[:, -1:, :, :]], dim=1)                     # 'symmetric' pad by one = repeat the edge sample
+    p = torch.cat([p, p[:, :, -1:, :]], dim=2)
+    box = 0.25 * (p[:, :-1, :-1] + p[:, 1:, :-1] + p[:, :-1, 1:] + p[:, 1:, 1:])
+    return box[:, ::2, ::2, :]
+
+
+def msssim_nchw_uint8_device(x, y):
+    """x, y: uint8 NCHW torch tensors on the device -> python float (float32-rounded like msssim_nchw_uint8)."""
+    import torch
+    assert x.dtype == torch.uint8 and y.dtype == torch.uint8, 'Expected uint8 input'
+    if x.shape != y.shape:
+        raise RuntimeError('Input images must have the same shape ({} vs. {}).'.format(tuple(x.shape), tuple(y.shape)))
+    im1 = x.permute(0, 2, 3, 1).to(torch.float64)
+    im2 = y.permute(0, 2, 3, 1).to(torch.float64)
+    w = _MSSSIM_WEIGHTS
+    mssim, mcs = [], []
+    for _ in range(len(w)):
+        s, c = _ssim_and_cs_t(im1, im2)
+        mssim.append(s)
+        mcs.append(c)
+        im1, im2 = _downsample2_t(im1), _downsample2_t(im2)
+    vals = torch.stack(mcs[:-1] + [mssim[-1]]).tolist()                # one device -> host transfer
+    out = 1.0
+    for v, wt in zip(vals[:-1], w[:-1]):
+        out *= v ** wt
+    return float(np.float32(out * vals[-1] ** w[-1]))
+
+
+def psnr_uint8_device(a, b):
+    import torch
+    assert a.dtype == torch.uint8 and b.dtype == torch.uint8, 'Expected uint8 input'
+    mse = float(((a.to(torch.float64) - b.to(torch.float64)) ** 2).mean())
+    if mse == 0:
+        return float('inf')
+    return float(np.float32(10.0 * np.log10(255.0 ** 2 / mse)))

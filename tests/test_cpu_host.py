@@ -486,3 +486,14 @@ def test_datasets_tfrecord_pickle_glob(tmp_path, monkeypatch):
         assert L.get_batch().shape == (4, 3, 64, 64) and L.num_images == 1281167
     finally:
         L.close()
+
+
+def test_device_metric_twins_on_cpu_tensors():
+    """the torch float64 twins of MS-SSIM / PSNR (used on the device by val.py) against the numpy versions."""
+    import torch
+    from imgcomp_cvpr_amd import metrics, weights as W
+    a = W.synthetic_image((1, 3, 192, 224), 'natural', 4)
+    b = np.clip(a.astype(np.float64) + np.random.RandomState(0).normal(0, 5, a.shape), 0, 255).astype(np.uint8)
+    ta, tb = torch.as_tensor(a), torch.as_tensor(b)
+    assert abs(metrics.msssim_nchw_uint8_device(ta, tb) - float(metrics.msssim_nchw_uint8(a, b))) < 1e-7
+    assert abs(metrics.psnr_uint8_device(ta, tb) - float(metrics.psnr_uint8(a, b))) < 1e-5

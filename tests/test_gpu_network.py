@@ -287,3 +287,16 @@ def test_high_rate_config_matches_oracle(cuda):
     assert_close(bc, rb, 'bit cost (hi, k = 64)')
     assert_close(x_out, O.decode(q, wts, ae_cfg.as_dict()), 'x_out (hi)')
     assert abs(float(bits.bitcost_to_bpp(bc, xd)) - O.bitcost_to_bpp(rb, torch.as_tensor(x))) < 1e-4
+
+
+def test_device_metrics_match_numpy(cuda):
+    """val.py's MS-SSIM / PSNR: the float64 device versions against the numpy ones that are pinned to the reference's
+    implementation (tests/golden/msssim.npz), sizes with and without the shrunken-window scales."""
+    from imgcomp_cvpr_amd import metrics, weights as W
+    for shape, seed in (((1, 3, 256, 320), 1), ((1, 3, 181, 177), 2), ((2, 3, 96, 200), 3)):
+        a = W.synthetic_image(shape, 'natural', seed)
+        b = np.clip(a.astype(np.float64) + np.random.RandomState(seed).normal(0, 7, a.shape), 0, 255).astype(np.uint8)
+        ad, bd = torch.as_tensor(a).to(cuda), torch.as_tensor(b).to(cuda)
+        assert abs(metrics.msssim_nchw_uint8_device(ad, bd) - float(metrics.msssim_nchw_uint8(a, b))) < 1e-6
+        assert abs(metrics.psnr_uint8_device(ad, bd) - float(metrics.psnr_uint8(a, b))) < 1e-4
+    assert metrics.psnr_uint8_device(ad, ad) == float('inf') and metrics.msssim_nchw_uint8_device(ad, ad) == 1.0
