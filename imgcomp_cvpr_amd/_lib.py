@@ -34,6 +34,7 @@ PROTOTYPES = {
     'ic_conv3x3_c128_set_debug_buffer': (None, [c_void_p]),
     'ic_wino3x3_c128_packed_floats': (c_size_t, []),
     'ic_pack_wino3x3_c128_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    'ic_pack_wino3x3_c128_batch_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'ic_wino3x3_c128_bn_act_f32': (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_void_p]),
     'ic_wino3x3_c128_set_tuning': (None, [c_int, c_int]),
     'ic_conv3x3_c128_both_packed_floats': (c_size_t, []),

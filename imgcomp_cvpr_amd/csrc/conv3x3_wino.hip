@@ -320,6 +320,47 @@ __global__ __launch_bounds__(256) void wino3x3_c128_kernel(const WnArgs a) {
     wino_body<VEC>(a, t / a.grows, t % a.grows, gx);
 }
 
+// all the 3x3 filters of a network in one launch (training re-packs every filter every step; 128 five-microsecond
+// launches per step otherwise): layer l reads w_tab[l], writes out + l * WN_PACKED_FLOATS
+__global__ __launch_bounds__(256) void wino_pack_batch_kernel(const float* const* __restrict__ w_tab, float* __restrict__ out,
+                                                              int backward) {
+    const float* __restrict__ w_tf = w_tab[blockIdx.y];
+    float* __restrict__ o_l = out + (size_t)blockIdx.y * WN_PACKED_FLOATS;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= WN_C * WN_C) return;
+    const int cin = idx / WN_C, cout = idx % WN_C;
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            g[a][b] = backward ? w_tf[(((2 - a) * 3 + (2 - b)) * WN_C + cout) * WN_C + cin]
+                               : w_tf[((a * 3 + b) * WN_C + cin) * WN_C + cout];
+    float t[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+        t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+        t[3][b] = g[2][b];
+    }
+    float* o = o_l + (((size_t)(cout >> 5) * 64 + (cin >> 1)) * 4 * 64 + ((cin & 1) * 32 + (cout & 31))) * 4;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        f32x4 q = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
+        *(f32x4*)(o + a * 256) = q;
+    }
+}
+
+extern "C" int ic_pack_wino3x3_c128_batch_f32(const float* const* w_tf_table_dev, float* w_packed, int layers, int backward,
+                                              ic_stream_t stream) {
+    IC_CHECK_ARG(w_tf_table_dev && w_packed && layers > 0);
+    hipLaunchKernelGGL(wino_pack_batch_kernel, dim3(WN_C * WN_C / 256, layers), dim3(256), 0, (hipStream_t)stream,
+                       w_tf_table_dev, w_packed, backward);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
 extern "C" size_t ic_wino3x3_c128_packed_floats(void) { return WN_PACKED_FLOATS; }
 
 extern "C" int ic_pack_wino3x3_c128_f32(const float* w_tf, float* w_packed, int backward, ic_stream_t stream) {

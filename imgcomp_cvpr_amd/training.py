@@ -146,15 +146,37 @@ class TrainGraph(object):
         return torch.empty(shape, dtype=torch.float32, device=self.dev)
 
     # ---- raw convolution (no BN, no activation): forward and data-gradient use ----
-    def _conv3x3(self, x, w_tf, backward=False):
-        """raw 3x3 128->128 conv (backward: its adjoint = the data gradient).  The filter is re-packed every call (it
-        changes every step) -- only in the form the launch will use."""
+    def _pack_all_3x3(self, N, H, W):
+        """Winograd fragments of every 3x3 filter, forward and adjoint, in two launches (the filters change every step).
+        No-op when the shape runs the direct form."""
+        self._wino_pk = None
+        if lib.ic_conv3x3_c128_pick_algo(N, H, W) != 1:
+            return
+        if not hasattr(self, '_w3_names'):
+            self._w3_names = [l.scope + '/weights' for l in self.layers.values()
+                              if l.kind == 'conv' and l.kh == 3 and l.cin == 128 and l.cout == 128]
+            self._w3_index = {n: i for i, n in enumerate(self._w3_names)}
+            self._w3_table = torch.tensor([self.params[n].data_ptr() for n in self._w3_names], dtype=torch.int64,
+                                          device=self.dev)
+            self._w3_buf = self._new(2, len(self._w3_names), lib.ic_wino3x3_c128_packed_floats())
+        for b in (0, 1):
+            check(lib.ic_pack_wino3x3_c128_batch_f32(ptr(self._w3_table), ptr(self._w3_buf[b]), len(self._w3_names), b,
+                                                     self._st()), 'batched winograd pack')
+        self._wino_pk = self._w3_buf
+
+    def _conv3x3(self, x, name, backward=False):
+        """raw 3x3 128->128 conv (backward: its adjoint = the data gradient).  name: a parameter name -- its fragments
+        come from this step's batched packing when there is one -- or a filter tensor in the TF layout."""
         N, _, H, W = x.shape
         y = self._new(N, 128, H, W)
         st = self._st()
+        w_tf = self.params[name] if isinstance(name, str) else name
         if lib.ic_conv3x3_c128_pick_algo(N, H, W) == 1:
-            wp = self._new(lib.ic_wino3x3_c128_packed_floats())
-            check(lib.ic_pack_wino3x3_c128_f32(ptr(w_tf), ptr(wp), int(backward), st))
+            if isinstance(name, str) and getattr(self, '_wino_pk', None) is not None:
+                wp = self._wino_pk[int(backward), self._w3_index[name]]
+            else:
+                wp = self._new(lib.ic_wino3x3_c128_packed_floats())
+                check(lib.ic_pack_wino3x3_c128_f32(ptr(w_tf), ptr(wp), int(backward), st))
             check(lib.ic_wino3x3_c128_bn_act_f32(ptr(x), ptr(wp), ptr(self.ones), ptr(self.zeros), None, None, ptr(y),
                                                  N, H, W, 0, st), 'conv3x3 (winograd)')
         else:
@@ -198,7 +220,7 @@ class TrainGraph(object):
     def _raw_forward(self, l, x):
         w = self.params[l.scope + '/weights']
         if l.kind == 'conv' and l.kh == 3 and l.cin == 128 and l.cout == 128:
-            return self._conv3x3(x, w)
+            return self._conv3x3(x, l.scope + '/weights')
         if l.kind == 'conv':
             return self._conv_s(x, w, l.kh, l.kw, l.cin, l.cout, l.stride)
         return self._deconv_s(x, w, l.kh, l.kw, l.cin, l.cout)
@@ -207,7 +229,7 @@ class TrainGraph(object):
         """gradient wrt the layer input of the raw conv (g = gradient wrt its output)."""
         w = self.params[l.scope + '/weights']
         if l.kind == 'conv' and l.kh == 3 and l.cin == 128 and l.cout == 128:
-            return self._conv3x3(g, w, backward=True)
+            return self._conv3x3(g, l.scope + '/weights', backward=True)
         if l.kind == 'conv':      # adjoint of a strided conv = transposed conv with the SAME array read as [kh,kw,out=cin,in=cout]
             return self._deconv_s(g, w, l.kh, l.kw, l.cout, l.cin)
         # adjoint of a transposed conv = strided conv with the same array read as [kh,kw,cin=cout_l,cout=cin_l]
@@ -310,6 +332,7 @@ class TrainGraph(object):
         assert H % 8 == 0 and W % 8 == 0
         C, L, k = self.C, self.L, self.k
         h, w = H // 8, W // 8
+        self._pack_all_3x3(N, H // 4, W // 4)
         # ===== forward: encoder =====
         enc_tape_a, enc_tape_s, enc_tape_b = [], [], []
         # _normalize (autoencoder.py:136-144): kept as its own tensor, h1's filter gradient needs the normalised input

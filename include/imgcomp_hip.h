@@ -99,6 +99,10 @@ void ic_conv3x3_c128_set_debug_buffer(void* dev_u64);
  * Results differ from the direct form by fp32 rounding only (both within 1e-4 of the float64 oracle). */
 size_t ic_wino3x3_c128_packed_floats(void);
 int ic_pack_wino3x3_c128_f32(const float* w_tf, float* w_packed, int backward, ic_stream_t stream);
+/* the same for `layers` filters in one launch: w_tf_table_dev is a DEVICE array of `layers` device pointers, layer l is
+ * packed to w_packed + l * ic_wino3x3_c128_packed_floats() (the training step re-packs all 64 filters twice per step) */
+int ic_pack_wino3x3_c128_batch_f32(const float* const* w_tf_table_dev, float* w_packed, int layers, int backward,
+                                   ic_stream_t stream);
 int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale,
                                const float* shift, const float* res1, const float* res2, float* y,
                                int N, int H, int W, int relu, ic_stream_t stream);
