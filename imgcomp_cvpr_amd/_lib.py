@@ -79,7 +79,8 @@ PROTOTYPES = {
     'ic_heatmap_quantize_bwd_f32': (c_int, [c_void_p, c_void_p, c_int, c_float] + [c_void_p] * 4 + [c_int] * 5 +
                                     [c_void_p, c_void_p]),
     'ic_pc_dlogits_f32': (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),
-    'ic_pc_bwd_data_f32': (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
+    'ic_pc_bwd_data_workspace_bytes': (c_size_t, [c_int] * 6),
+    'ic_pc_bwd_data_f32': (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]),
     'ic_pc_wgrad_workspace_bytes': (c_size_t, [c_int] * 6),
     'ic_pc_wgrad_f32': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p] + [c_int] * 7 +
                         [c_void_p, c_size_t, c_void_p]),

@@ -18,3 +18,8 @@ int icx_conv2d(ConvArgs a, bool transposed, hipStream_t st);
 // 5x5 / stride-2 transposed conv with <= 4 output channels (h13); `a` already completed by icx_conv2d's
 // transposed branch.  IC_ERR_UNSUPPORTED when the shape does not fit.
 int icx_deconv5_small_cout(const ConvArgs& a, hipStream_t st);
+
+// probclass.hip: data gradient of a masked conv3d layer on the matrix cores (train_pc.hip); workspace 0 = shape not covered
+size_t icx_pc_bwd_data_mfma_workspace(int N, int CinF, int CoutF, int OD, int OH, int OW);
+int icx_pc_bwd_data_mfma(const float* g, const float* w, float* dx_raw, int N, int CinF, int CoutF, int OD, int OH, int OW,
+                         const float* zero_bias, void* workspace, size_t workspace_bytes, hipStream_t st);

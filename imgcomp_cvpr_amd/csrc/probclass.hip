@@ -162,7 +162,25 @@ __global__ void pc_pack_kernel(const float* __restrict__ w, float* __restrict__ 
     out[idx] = co < Cout ? w[((size_t)tap * Cin + ci) * Cout + co] : 0.f;
 }
 
-template <int CIN, int KC, int WM, int WN, int TR, int TC, bool FINAL>
+// the same fragments for the ADJOINT layer (data gradient): the GEMM's k axis runs over the forward layer's OUTPUT
+// channels (padded with zeros up to KPAD), its rows over the forward layer's input channels:
+//   packed[...] = w[tap][ci_fwd = 32 n + (l & 31)][co_fwd = 8 c8 + 2 j + (l >> 5)]
+__global__ void pc_pack_adjoint_kernel(const float* __restrict__ w, float* __restrict__ out, int CinF, int CoutF, int NCOT,
+                                       int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int j = idx & 3, l = (idx >> 2) & 63;
+    int r = idx >> 8;
+    const int n = r % NCOT; r /= NCOT;
+    const int t = r % PC_NT, c8 = r / PC_NT;
+    const int tap = (pc_tap_kd(t) * 3 + pc_tap_kh(t)) * 3 + pc_tap_kw(t);
+    const int kq = 8 * c8 + 2 * j + (l >> 5), row = 32 * n + (l & 31);
+    out[idx] = (row < CinF && kq < CoutF) ? w[((size_t)tap * CinF + row) * CoutF + kq] : 0.f;
+}
+
+// FLIP: the adjoint layer -- tap t reads the brick at the mirrored offset (1 - kd, 2 - kh, 2 - kw); with the input
+// zero-padded by (1, 2, 2) on every side this is the data gradient of the forward layer (pc_bwd_data below).
+template <int CIN, int KC, int WM, int WN, int TR, int TC, bool FINAL, bool FLIP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void pc_mfma_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
     constexpr int S = TC + 2, DS = (TR + 2) * S, CS = 2 * DS, CHUNK = KC * CS;
@@ -240,7 +258,8 @@ void pc_mfma_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
             for (int t = 0; t < PC_NT; ++t) {
                 const int tn = t + RD - 2;
                 if (tn < PC_NT || more) ring[tn % RD] = wc[(size_t)tn * wstep];
-                const int tapoff = pc_tap_kd(t) * DS + pc_tap_kh(t) * S + pc_tap_kw(t);
+                const int tapoff = FLIP ? (1 - pc_tap_kd(t)) * DS + (2 - pc_tap_kh(t)) * S + (2 - pc_tap_kw(t))
+                                        : pc_tap_kd(t) * DS + pc_tap_kh(t) * S + pc_tap_kw(t);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const float bv = lds[boff + (8 * c8 + 2 * ks) * CS + tapoff];
@@ -461,6 +480,60 @@ extern "C" int ic_pc_logits_to_freqs_f32(const float* logits, long long count, i
                        logits, count, L, resolution, (long long*)freqs, pr);
     IC_LAUNCH_CHECK();
     return IC_OK;
+}
+
+// ---- data gradient of a k -> Cout_f layer on the matrix cores (training; train_pc.hip calls this) --------------------------
+// dx[n][ci][u] = sum_{live taps t, co} g[n][co][u - off(t)] * w[t][ci][co]: a VALID conv of the (1,2,2)-zero-padded gradient
+// with the mirrored taps and the transposed filter.  gpad: (N, KP, OD+2, OH+4, OW+4) with KP = 24 or 64 channels (channels
+// >= Cout_f zero), dx_raw: (N, Cin_f, OD+1, OH+2, OW+2).  pk: pc_packed_floats(KP, Cin_f) floats of scratch.
+__global__ __launch_bounds__(256) void pc_pad_grad_kernel(const float* __restrict__ g, float* __restrict__ gp, int N, int Cg, int KP,
+                                                          int OD, int OH, int OW) {
+    const int PD = OD + 2, PH = OH + 4, PW = OW + 4;
+    const long long total = (long long)N * KP * PD * PH * PW;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % PW);
+    long long r = i / PW;
+    const int y = (int)(r % PH); r /= PH;
+    const int d = (int)(r % PD); r /= PD;
+    const int c = (int)(r % KP), n = (int)(r / KP);
+    const int od = d - 1, oy = y - 2, ox = x - 2;
+    const bool in = c < Cg && od >= 0 && od < OD && oy >= 0 && oy < OH && ox >= 0 && ox < OW;
+    gp[i] = in ? g[(((size_t)n * Cg + c) * OD + od) * OH * OW + (size_t)oy * OW + ox] : 0.f;
+}
+
+int icx_pc_bwd_data_mfma(const float* g, const float* w, float* dx_raw, int N, int CinF, int CoutF, int OD, int OH, int OW,
+                         const float* zero_bias, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    const int KP = CoutF <= 24 ? 24 : 64;
+    if (CoutF > 64 || CinF > 64 || (CinF != 24 && CinF != 64)) return IC_ERR_UNSUPPORTED;
+    const size_t gp_floats = (size_t)N * KP * (OD + 2) * (OH + 4) * (OW + 4);
+    const size_t pk_floats = pc_packed_floats(KP, CinF);
+    if (workspace_bytes < (gp_floats + pk_floats) * sizeof(float)) return IC_ERR_WORKSPACE;
+    float* gp = (float*)workspace;
+    float* pk = gp + gp_floats;
+    hipLaunchKernelGGL(pc_pad_grad_kernel, dim3((unsigned)((gp_floats + 255) / 256)), dim3(256), 0, st, g, gp, N, CoutF, KP,
+                       OD, OH, OW);
+    hipLaunchKernelGGL(pc_pack_adjoint_kernel, dim3(ic_cdiv((int)pk_floats, 256)), dim3(256), 0, st, w, pk, CinF, CoutF,
+                       ic_cdiv(CinF, 32), (int)pk_floats);
+    PcLayerArgs a{};
+    a.in = gp; a.bias = zero_bias; a.res = nullptr; a.out = dx_raw;
+    a.N = N; a.Cin = KP; a.Cout = CinF;
+    a.D = OD + 2; a.H = OH + 4; a.W = OW + 4; a.OD = OD + 1; a.OH = OH + 2; a.OW = OW + 2; a.relu = 0;
+    if (KP == 24) {
+        dim3 grid(a.OD * ic_cdiv(a.OH, 8) * ic_cdiv(a.OW, 16), ic_cdiv(CinF, 32), N);
+        hipLaunchKernelGGL((pc_mfma_kernel<24, 24, 1, 4, 8, 16, false, true>), grid, dim3(256), 0, st, a, pk);
+    } else {
+        dim3 grid(a.OD * ic_cdiv(a.OH, 4) * ic_cdiv(a.OW, 16), ic_cdiv(CinF, 64), N);
+        hipLaunchKernelGGL((pc_mfma_kernel<64, 16, 2, 2, 4, 16, false, true>), grid, dim3(256), 0, st, a, pk);
+    }
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
+size_t icx_pc_bwd_data_mfma_workspace(int N, int CinF, int CoutF, int OD, int OH, int OW) {
+    if (CoutF > 64 || (CinF != 24 && CinF != 64)) return 0;
+    const int KP = CoutF <= 24 ? 24 : 64;
+    return ((size_t)N * KP * (OD + 2) * (OH + 4) * (OW + 4) + pc_packed_floats(KP, CinF)) * sizeof(float);
 }
 
 // ---- sequential decoder (row N3: bit_counter.py:137-164 without the host in the loop) ----------------------------------

@@ -3,6 +3,7 @@
 // here: the cross-entropy/ReLU gradient of the logits, the data gradient of a masked VALID conv3d, channel sums.
 // The context model is ~2 % of a training step's FLOPs: these are plain one-lane-per-output kernels.
 #include "common.h"
+#include "internal.h"
 
 // g[n][l][v] = (softmax(logits[n][v])[l] - [l == sym]) * log2(e) * d_bits[n][v] * [logits[n][v][l] > 0]
 // logits: (N, vol, L) channels-last, post-ReLU (probclass.py:220,233); g: (N, L, vol) planar.
@@ -96,16 +97,58 @@ extern "C" int ic_pc_dlogits_f32(const float* logits, const int64_t* symbols, co
     return IC_OK;
 }
 
+// epilogue of the matrix-core path: dx = (raw (+ res inside)) * [act > 0], in place
+__global__ __launch_bounds__(256) void pc_bwd_fix_kernel(const PcBwdArgs a, long long total) {
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= total) return;
+    const int D = a.OD + 1, H = a.OH + 2, W = a.OW + 2;
+    const int x = (int)(o % W);
+    long long r = o / W;
+    const int y = (int)(r % H); r /= H;
+    const int d = (int)(r % D); r /= D;           // r = n * Cin + ci
+    float v = a.dx[o];
+    if (a.res) {
+        const int rd = d - 2, ry = y - 2, rx = x - 2;
+        const int RD = a.OD - 1, RH = a.OH - 2, RW = a.OW - 2;
+        if (rd >= 0 && rd < RD && ry >= 0 && ry < RH && rx >= 0 && rx < RW)
+            v += a.res[((size_t)r * RD + rd) * RH * RW + (size_t)ry * RW + rx];
+    }
+    if (a.relu_mask && !(a.act[o] > 0.f)) v = 0.f;
+    a.dx[o] = v;
+}
+
+extern "C" size_t ic_pc_bwd_data_workspace_bytes(int N, int Cin, int Cout, int OD, int OH, int OW) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || OD <= 0 || OH <= 0 || OW <= 0) return 0;
+    const size_t b = icx_pc_bwd_data_mfma_workspace(N, Cin, Cout, OD, OH, OW);
+    return b ? b + 64 * sizeof(float) : 0;
+}
+
+// workspace: ic_pc_bwd_data_workspace_bytes(...) bytes select the matrix-core path ("other" mask, Cin = 24 or 64); NULL or
+// 0 bytes (or a shape it does not cover) run the any-shape VALU kernel.
 extern "C" int ic_pc_bwd_data_f32(const float* g, const float* w, const float* res, const float* act, float* dx,
                                   int N, int Cin, int Cout, int OD, int OH, int OW, int first_mask, int relu_mask,
-                                  ic_stream_t stream) {
+                                  void* workspace, size_t workspace_bytes, ic_stream_t stream) {
     IC_CHECK_ARG(g && w && dx && N > 0 && Cin > 0 && Cout > 0 && OD > 0 && OH > 0 && OW > 0);
     IC_CHECK_ARG(!relu_mask || act);
     PcBwdArgs a{};
     a.g = g; a.w = w; a.res = res; a.act = act; a.dx = dx;
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.OD = OD; a.OH = OH; a.OW = OW; a.first_mask = first_mask; a.relu_mask = relu_mask;
     const int ivol = (OD + 1) * (OH + 2) * (OW + 2);
-    hipLaunchKernelGGL((pc_bwd_data_kernel<8>), dim3(ic_cdiv(ivol, 256), ic_cdiv(Cin, 8), N), dim3(256), 0, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t need = first_mask ? 0 : ic_pc_bwd_data_workspace_bytes(N, Cin, Cout, OD, OH, OW);
+    if (workspace && need && workspace_bytes >= need) {
+        float* zero = (float*)((char*)workspace + need - 64 * sizeof(float));
+        if (hipMemsetAsync(zero, 0, 64 * sizeof(float), st) != hipSuccess) return IC_ERR_ARG;
+        int rc = icx_pc_bwd_data_mfma(g, w, dx, N, Cin, Cout, OD, OH, OW, zero, workspace, need - 64 * sizeof(float), st);
+        if (rc) return rc;
+        if (res || relu_mask) {
+            const long long total = (long long)N * Cin * ivol;
+            hipLaunchKernelGGL(pc_bwd_fix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, total);
+        }
+        IC_LAUNCH_CHECK();
+        return IC_OK;
+    }
+    hipLaunchKernelGGL((pc_bwd_data_kernel<8>), dim3(ic_cdiv(ivol, 256), ic_cdiv(Cin, 8), N), dim3(256), 0, st, a);
     IC_LAUNCH_CHECK();
     return IC_OK;
 }

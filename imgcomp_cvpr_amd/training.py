@@ -481,8 +481,10 @@ class TrainGraph(object):
 
         def bwd_data(g, scope, res, act, Cin, Cout, OD, OH, OW, relu_mask):
             dx = self._new(N, Cin, OD + 1, OH + 2, OW + 2)
+            need = lib.ic_pc_bwd_data_workspace_bytes(N, Cin, Cout, OD, OH, OW)      # 0: the VALU kernel serves the shape
+            ws = self._scratch('pcbwd', need) if need else None
             check(lib.ic_pc_bwd_data_f32(ptr(g), ptr(P[scope + '/weights']), ptr(res), ptr(act), ptr(dx), N, Cin, Cout,
-                                         OD, OH, OW, 0, int(relu_mask), st), 'pc bwd data ' + scope)
+                                         OD, OH, OW, 0, int(relu_mask), ptr(ws), need, st), 'pc bwd data ' + scope)
             return dx
         # logits (post-ReLU) -> g3 planar (N, L, C*h*w)
         g3 = self._new(N, L, C, h, w)

@@ -275,9 +275,13 @@ int ic_heatmap_quantize_bwd_f32(const float* bottleneck, const float* centers, i
 /* context model backward pieces (probclass.py:63-106,185-261) */
 int ic_pc_dlogits_f32(const float* logits, const int64_t* symbols, const float* d_bits, float* g,
                       int N, int vol, int L, ic_stream_t stream);
+/* data gradient of one masked conv3d layer: dx = (sum_taps w^T g (+ res embedded at (2,2,2))) * [act > 0].
+ * workspace = ic_pc_bwd_data_workspace_bytes(...) bytes runs it on the matrix cores (the layer's adjoint: mirrored taps,
+ * transposed filter, zero-padded gradient); NULL / 0 or an uncovered shape (size query returns 0) runs the VALU kernel. */
+size_t ic_pc_bwd_data_workspace_bytes(int N, int Cin, int Cout, int OD, int OH, int OW);
 int ic_pc_bwd_data_f32(const float* g, const float* w, const float* res, const float* act, float* dx,
                        int N, int Cin, int Cout, int OD, int OH, int OW, int first_mask, int relu_mask,
-                       ic_stream_t stream);
+                       void* workspace, size_t workspace_bytes, ic_stream_t stream);
 size_t ic_pc_wgrad_workspace_bytes(int N, int A, int B, int VD, int VH, int VW);
 int ic_pc_wgrad_f32(const float* U, const float* q, float pad_value, const float* V, float* dw,
                     int N, int A, int B, int VD, int VH, int VW, int first_mask,

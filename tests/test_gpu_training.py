@@ -279,3 +279,44 @@ def test_gradient_buckets_over_rccl_single_rank(cuda, configs, syn_weights):
             assert torch.equal(g1.flat_grads[k], ref[k]), k
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('Cin,Cout,relu_mask,with_res', [(24, 24, True, True), (24, 6, False, False), (24, 24, True, False),
+                                                         (64, 64, True, True), (64, 6, False, False)])
+def test_pc_data_gradient_matrix_core_path(cuda, Cin, Cout, relu_mask, with_res):
+    """data gradient of a masked conv3d layer: the matrix-core path (adjoint layer: mirrored taps, transposed filter,
+    zero-padded gradient) against torch autograd in float64 and against the any-shape VALU kernel."""
+    import torch.nn.functional as F
+    from oracle import oracle as O
+    L = _L()
+    rs = np.random.RandomState(Cin + Cout)
+    N, OD, OH, OW = 2, 3, 9, 21
+    g = rs.normal(0, 1, (N, Cout, OD, OH, OW)).astype(np.float32)
+    w = rs.normal(0, 0.1, (2, 3, 3, Cin, Cout)).astype(np.float32)
+    act = rs.normal(0, 1, (N, Cin, OD + 1, OH + 2, OW + 2)).astype(np.float32)
+    res = rs.normal(0, 1, (N, Cin, OD - 1, OH - 2, OW - 2)).astype(np.float32)
+    _, other = O.pc_masks(3)
+    xt = torch.zeros((N, Cin, OD + 1, OH + 2, OW + 2), dtype=torch.float64, requires_grad=True)
+    wm = (torch.as_tensor(w).double() * torch.as_tensor(other, dtype=torch.float64)[..., None, None]).permute(4, 3, 0, 1, 2)
+    F.conv3d(xt, wm).backward(torch.as_tensor(g).double())
+    ref = xt.grad.clone()
+    if with_res:
+        ref[:, :, 2:2 + OD - 1, 2:2 + OH - 2, 2:2 + OW - 2] += torch.as_tensor(res).double()
+    if relu_mask:
+        ref = ref * (torch.as_tensor(act) > 0)
+    d = lambda a: dev(a, cuda)
+    gd, wd_, actd, resd = d(g), d(w), d(act), d(res)
+    outs = []
+    need = L.lib.ic_pc_bwd_data_workspace_bytes(N, Cin, Cout, OD, OH, OW)
+    assert need > 0
+    for use_ws in (True, False):
+        dx = torch.full((N, Cin, OD + 1, OH + 2, OW + 2), float('nan'), device=cuda)
+        ws = torch.empty(need, dtype=torch.uint8, device=cuda) if use_ws else None
+        L.check(L.lib.ic_pc_bwd_data_f32(L.ptr(gd), L.ptr(wd_), L.ptr(resd) if with_res else None,
+                                         L.ptr(actd) if relu_mask else None, L.ptr(dx), N, Cin, Cout, OD, OH, OW, 0,
+                                         int(relu_mask), L.ptr(ws), need if use_ws else 0, L.current_stream()))
+        torch.cuda.synchronize()
+        assert_close(dx, ref, 'pc data gradient, matrix cores {}'.format(use_ws), 1e-5)
+        outs.append(dx)
+    assert not torch.equal(outs[0], outs[1])          # really two different kernels
+    assert L.lib.ic_pc_bwd_data_workspace_bytes(N, 8, 24, OD, OH, OW) == 0      # uncovered shape -> VALU kernel only
