@@ -22,6 +22,7 @@ struct BnArgs {
     double* partial;          // [C][BN_CHUNKS][2]
     float* out0; float* out1; // stats: mean, var ; bwd_apply: dx
     int N, C, HW, relu;
+    int nchunks;              // stage-1 slices actually used (<= BN_CHUNKS): each covers >= ~8k elements
 };
 
 __device__ __forceinline__ void block_reduce2(double& a, double& b) {
@@ -38,24 +39,29 @@ __device__ __forceinline__ void block_reduce2(double& a, double& b) {
 // MODE 0: (sum x, sum x^2)   MODE 1: (sum g, sum g * xhat)
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_stage1(const BnArgs a) {
-    // block (c, chunk): the channel's N planes are cut into tiles of 1024 positions, dealt round-robin to the chunks
-    // (one division per tile, none per element)
+    // block (c, chunk): the channel's N * HW elements (N separate planes) are cut into nchunks contiguous runs of whole
+    // 256-element groups; divisions only per block and per plane, none per element
     const int c = blockIdx.x, chunk = blockIdx.y;
-    const int tpp = (a.HW + 1023) / 1024, tiles = a.N * tpp;
+    const long long E = (long long)a.N * a.HW;
+    const long long per = ((E + a.nchunks - 1) / a.nchunks + 255) / 256 * 256;
+    const long long lo = per * chunk, hi = lo + per < E ? lo + per : E;
     float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
     if (MODE == 1) { sc = a.scale[c]; sh = a.shift[c]; mu = a.mean[c]; is = a.invstd[c]; }
     double s0 = 0.0, s1 = 0.0;
-    for (int t = chunk; t < tiles; t += BN_CHUNKS) {
-        const int n = t / tpp, p0 = (t - n * tpp) * 1024;
-        const size_t base = ((size_t)n * a.C + c) * a.HW;
-        const int hi = min(p0 + 1024, a.HW);
-        for (int p = p0 + threadIdx.x; p < hi; p += 256) {
-            const float xv = a.x[base + p];
-            if (MODE == 0) { s0 += xv; s1 += (double)xv * xv; }
-            else {
-                float g = a.dy[base + p];
-                if (a.relu && !(fmaf(xv, sc, sh) > 0.f)) g = 0.f;
-                s0 += g; s1 += (double)g * ((xv - mu) * is);
+    if (lo < hi) {
+        const int n_lo = (int)(lo / a.HW), n_hi = (int)((hi - 1) / a.HW);
+        for (int n = n_lo; n <= n_hi; ++n) {
+            const size_t base = ((size_t)n * a.C + c) * a.HW;
+            const int p0 = n == n_lo ? (int)(lo - (long long)n * a.HW) : 0;
+            const int p1 = n == n_hi ? (int)(hi - (long long)n * a.HW) : a.HW;
+            for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+                const float xv = a.x[base + p];
+                if (MODE == 0) { s0 += xv; s1 += (double)xv * xv; }
+                else {
+                    float g = a.dy[base + p];
+                    if (a.relu && !(fmaf(xv, sc, sh) > 0.f)) g = 0.f;
+                    s0 += g; s1 += (double)g * ((xv - mu) * is);
+                }
             }
         }
     }
@@ -65,11 +71,11 @@ __global__ __launch_bounds__(256) void bn_reduce_stage1(const BnArgs a) {
 
 template <int MODE>
 __global__ void bn_reduce_stage2(const double* __restrict__ partial, int C, long long M, float* __restrict__ o0,
-                                 float* __restrict__ o1, double* __restrict__ sums) {
+                                 float* __restrict__ o1, double* __restrict__ sums, int nchunks) {
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= C) return;
     double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < BN_CHUNKS; ++k) { s0 += partial[((size_t)c * BN_CHUNKS + k) * 2]; s1 += partial[((size_t)c * BN_CHUNKS + k) * 2 + 1]; }
+    for (int k = 0; k < nchunks; ++k) { s0 += partial[((size_t)c * BN_CHUNKS + k) * 2]; s1 += partial[((size_t)c * BN_CHUNKS + k) * 2 + 1]; }
     if (MODE == 0) {
         const double m = s0 / (double)M;
         double v = s1 / (double)M - m * m;        // biased variance (what BN normalises with)
@@ -113,6 +119,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs a, long 
     }
 }
 
+static int g_bn_per_chunk = 8192;
+extern "C" int ic_bn_set_tuning(int elems_per_chunk) { const int p = g_bn_per_chunk; if (elems_per_chunk > 0) g_bn_per_chunk = elems_per_chunk; return p; }
+static int bn_nchunks(int N, int HW) {
+    long long n = ((long long)N * HW) / g_bn_per_chunk;
+    return (int)(n < 1 ? 1 : (n > BN_CHUNKS ? BN_CHUNKS : n));
+}
+
 static int ew_grid(long long total) {
     long long g = (total + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -126,9 +139,10 @@ extern "C" int ic_bn_stats_f32(const float* x, float* mean, float* var, int N, i
     BnArgs a{};
     a.x = x; a.N = N; a.C = C; a.HW = HW; a.partial = (double*)workspace;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_reduce_stage1<0>, dim3(C, BN_CHUNKS), dim3(256), 0, st, a);
+    a.nchunks = bn_nchunks(N, HW);
+    hipLaunchKernelGGL(bn_reduce_stage1<0>, dim3(C, a.nchunks), dim3(256), 0, st, a);
     hipLaunchKernelGGL(bn_reduce_stage2<0>, dim3(ic_cdiv(C, 64)), dim3(64), 0, st, a.partial, C, (long long)N * HW, mean, var,
-                       (double*)nullptr);
+                       (double*)nullptr, a.nchunks);
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
@@ -139,11 +153,12 @@ extern "C" int ic_bn_stats_f32(const float* x, float* mean, float* var, int N, i
 __global__ void bn_train_fold_kernel(const double* __restrict__ partial, int C, long long M, const float* __restrict__ gamma,
                                      const float* __restrict__ beta, float* __restrict__ moving_mean,
                                      float* __restrict__ moving_var, float decay, float eps, float* __restrict__ mean,
-                                     float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
+                                     float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
+                                     int nchunks) {
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= C) return;
     double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < BN_CHUNKS; ++k) { s0 += partial[((size_t)c * BN_CHUNKS + k) * 2]; s1 += partial[((size_t)c * BN_CHUNKS + k) * 2 + 1]; }
+    for (int k = 0; k < nchunks; ++k) { s0 += partial[((size_t)c * BN_CHUNKS + k) * 2]; s1 += partial[((size_t)c * BN_CHUNKS + k) * 2 + 1]; }
     const double m = s0 / (double)M;
     double v = s1 / (double)M - m * m;
     if (v < 0.0) v = 0.0;
@@ -165,9 +180,10 @@ extern "C" int ic_bn_train_stats_f32(const float* x, const float* gamma, const f
     BnArgs a{};
     a.x = x; a.N = N; a.C = C; a.HW = HW; a.partial = (double*)workspace;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_reduce_stage1<0>, dim3(C, BN_CHUNKS), dim3(256), 0, st, a);
+    a.nchunks = bn_nchunks(N, HW);
+    hipLaunchKernelGGL(bn_reduce_stage1<0>, dim3(C, a.nchunks), dim3(256), 0, st, a);
     hipLaunchKernelGGL(bn_train_fold_kernel, dim3(ic_cdiv(C, 64)), dim3(64), 0, st, a.partial, C, (long long)N * HW, gamma,
-                       beta, moving_mean, moving_var, decay, eps, mean, invstd, scale, shift);
+                       beta, moving_mean, moving_var, decay, eps, mean, invstd, scale, shift, a.nchunks);
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
@@ -194,9 +210,10 @@ extern "C" int ic_bn_backward_f32(const float* dy, const float* x, const float* 
     double* sums = a.partial + (size_t)C * BN_CHUNKS * 2;
     a.sums = sums; a.out0 = dx;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_reduce_stage1<1>, dim3(C, BN_CHUNKS), dim3(256), 0, st, a);
+    a.nchunks = bn_nchunks(N, HW);
+    hipLaunchKernelGGL(bn_reduce_stage1<1>, dim3(C, a.nchunks), dim3(256), 0, st, a);
     hipLaunchKernelGGL(bn_reduce_stage2<1>, dim3(ic_cdiv(C, 64)), dim3(64), 0, st, a.partial, C, (long long)N * HW, dbeta,
-                       dgamma, sums);
+                       dgamma, sums, a.nchunks);
     const long long total = (long long)N * C * HW;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ic_cdiv(HW, 1024) < 1 ? 1 : ic_cdiv(HW, 1024), N * C), dim3(256), 0, st, a, total);
     IC_LAUNCH_CHECK();

@@ -16,7 +16,11 @@ def main():
     p.add_argument('--steps', type=int, default=10)
     p.add_argument('--warmup', type=int, default=2)
     p.add_argument('--distortion', default='ms_ssim')
+    p.add_argument('--bn_chunk', type=int, default=0)
     a = p.parse_args()
+    if a.bn_chunk:
+        from imgcomp_cvpr_amd import _lib as _l
+        _l.lib.ic_bn_set_tuning(a.bn_chunk)
     rank = int(os.environ.get('RANK', '0')); world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
