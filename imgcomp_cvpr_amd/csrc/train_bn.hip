@@ -22,7 +22,7 @@ struct BnArgs {
     double* partial;          // [C][BN_CHUNKS][2]
     float* out0; float* out1; // stats: mean, var ; bwd_apply: dx
     int N, C, HW, relu;
-    int nchunks;              // stage-1 slices actually used (<= BN_CHUNKS): each covers >= ~8k elements
+    int nchunks;              // stage-1 slices actually used (<= BN_CHUNKS): each covers >= ~1k elements
 };
 
 __device__ __forceinline__ void block_reduce2(double& a, double& b) {
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs a, long 
     }
 }
 
-static int g_bn_per_chunk = 8192;
+static int g_bn_per_chunk = 1024;
 extern "C" int ic_bn_set_tuning(int elems_per_chunk) { const int p = g_bn_per_chunk; if (elems_per_chunk > 0) g_bn_per_chunk = elems_per_chunk; return p; }
 static int bn_nchunks(int N, int HW) {
     long long n = ((long long)N * HW) / g_bn_per_chunk;

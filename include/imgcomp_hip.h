@@ -250,7 +250,7 @@ size_t ic_bn_workspace_bytes(int C);
 /* batch mean and BIASED variance per channel of x (N,C,HW) (autoencoder.py:114-125, is_training=True) */
 int ic_bn_stats_f32(const float* x, float* mean, float* var, int N, int C, int HW, void* workspace, ic_stream_t stream);
 /* y = act(x * scale[c] + shift[c]) + res1 + res2 */
-/* tuning only: elements of a channel each stage-1 reduction block covers (default 8192); returns the previous value */
+/* tuning only: elements of a channel each stage-1 reduction block covers (default 1024); returns the previous value */
 int ic_bn_set_tuning(int elems_per_chunk);
 int ic_bn_apply_f32(const float* x, const float* scale, const float* shift, const float* res1, const float* res2,
                     float* y, int N, int C, int HW, int relu, ic_stream_t stream);
