@@ -62,61 +62,53 @@ __global__ __launch_bounds__(64 * WA * WB) void conv_wgrad_kernel(const WgArgs a
     constexpr int RA = AT / TROWS, RB = BT / TROWS;            // U rows and V rows staged by each thread
     static_assert(RA + RB == RPT, "row split");
     float st[RPT];
-    // channel validity and channel strides of this thread's rows do not depend on the chunk
+    // Staging loads are raw buffer loads: per-lane byte offset of the position (row 0 of this thread) + a SCALAR offset
+    // per staged row (k * TROWS channels further) -- no vector address arithmetic per row; padded positions, dead lanes and
+    // channels past A / B get an out-of-range lane offset and the hardware returns 0.  (The first version spent 3.7 vector
+    // instructions per MFMA on addresses and selects; vector instructions cost matrix-pipe issue time.)
+    const int uvol = MODE3D ? a.UD * UHW : UHW, vvol = MODE3D ? a.VD * VHW : VHW;
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)a.U, 0, MODE3D && a.q ? 0 : (int)((long long)a.N * a.A * uvol * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void*)a.V, 0, (int)((long long)a.N * a.B * vvol * 4), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const bool a_full = a0 + AT <= a.A, b_full = b0 + BT <= a.B;           // work-group uniform
     auto fetch = [&](int q0) {
         const int q = q0 + px;
         const bool live = q < q_end;
         const int qc = live ? q : q_begin;
-        size_t ubase, vbase;
-        unsigned ustride, vstride;
-        bool uok;
+        unsigned uoff, voff;
         float qv = 0.f;
         if (!MODE3D) {
             const int n = qc / VHW, rem = qc - n * VHW;
             const int qy = rem / a.VW, qx = rem - qy * a.VW;
             const int iy = a.stride * qy + ty + a.oy0, ix = a.stride * qx + tx + a.ox0;
-            uok = live && iy >= 0 && iy < a.UH && ix >= 0 && ix < a.UW;
-            ubase = (size_t)n * a.A * UHW + (uok ? iy * a.UW + ix : 0);
-            vbase = (size_t)n * a.B * VHW + rem;
-            ustride = UHW; vstride = VHW;
+            const bool uok = live && iy >= 0 && iy < a.UH && ix >= 0 && ix < a.UW;
+            uoff = uok ? (unsigned)(((n * a.A + a0 + trow) * UHW + iy * a.UW + ix) * 4) : OOB;
+            voff = live ? (unsigned)(((n * a.B + b0 + trow) * VHW + rem) * 4) : OOB;
         } else {
             // position = (n, d, y, x) of the conv3d OUTPUT volume; the tap offset is never out of range (VALID)
-            const int vvol = a.VD * VHW, uvol = a.UD * UHW;
             const int n = qc / vvol, rem = qc - n * vvol;
             const int d = rem / VHW, r2 = rem - d * VHW;
             const int y = r2 / a.VW, x = r2 - y * a.VW;
             const int t3 = a.taps[tap];
             const int ud = d + t3 / 9, uy = y + (t3 % 9) / 3, ux = x + t3 % 3;
-            uok = live;
-            ubase = (size_t)n * a.A * uvol + (size_t)ud * UHW + uy * a.UW + ux;
-            vbase = (size_t)n * a.B * vvol + rem;
-            ustride = uvol; vstride = vvol;
+            uoff = live ? (unsigned)(((n * a.A + a0 + trow) * uvol + ud * UHW + uy * a.UW + ux) * 4) : OOB;
+            voff = live ? (unsigned)(((n * a.B + b0 + trow) * vvol + rem) * 4) : OOB;
             if (a.q) {                                 // U = symbol volume padded on load (depth front 4, H/W 4 each side)
                 const int c = ud - 4, yy = uy - 4, xx = ux - 4;
                 const bool in = c >= 0 && yy >= 0 && yy < a.qh && xx >= 0 && xx < a.qw;
-                qv = in ? a.q[(((size_t)n * a.qC + c) * a.qh + yy) * a.qw + xx] : a.pad_value;
+                qv = !live ? 0.f : (in ? a.q[(((size_t)n * a.qC + c) * a.qh + yy) * a.qw + xx] : a.pad_value);
             }
         }
-        // one 64-bit address per operand, then a constant step per staged row; rows of padded channels and padded
-        // positions are skipped (exec-masked), not loaded
-        const float* up = a.U + ubase + (size_t)(a0 + trow) * ustride;
-        const float* vp = a.V + vbase + (size_t)(b0 + trow) * vstride;
-        const size_t ustep = (size_t)TROWS * ustride, vstep = (size_t)TROWS * vstride;
 #pragma unroll
         for (int k = 0; k < RA; ++k) {
-            const bool ok = uok && a0 + trow + k * TROWS < a.A;
-            float v = 0.f;
-            if (MODE3D && a.q) v = ok ? qv : 0.f;
-            else if (ok) v = *up;
-            up += ustep;
-            st[k] = v;
+            if (MODE3D && a.q) { st[k] = (a0 + trow + k * TROWS < a.A) ? qv : 0.f; continue; }
+            const unsigned vo = (a_full || a0 + trow + k * TROWS < a.A) ? uoff : OOB;
+            st[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ur, vo, k * TROWS * uvol * 4, 0));
         }
 #pragma unroll
         for (int k = 0; k < RB; ++k) {
-            float v = 0.f;
-            if (live && b0 + trow + k * TROWS < a.B) v = *vp;
-            vp += vstep;
-            st[RA + k] = v;
+            const unsigned vo = (b_full || b0 + trow + k * TROWS < a.B) ? voff : OOB;
+            st[RA + k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vr, vo, k * TROWS * vvol * 4, 0));
         }
     };
     auto stash = [&](int buf) {
@@ -227,7 +219,9 @@ extern "C" int ic_conv2d_wgrad_f32(const float* U, const float* V, float* dw, in
     if (stride != 1 && stride != 2) return IC_ERR_UNSUPPORTED;
     const int VH = ic_cdiv(UH, stride), VW = ic_cdiv(UW, stride);
     const long long P = (long long)N * VH * VW;
-    if (P >= (1ll << 31) || (long long)N * A * UH * UW >= (1ll << 31)) return IC_ERR_UNSUPPORTED;
+    // byte offsets into U and V are 31-bit (buffer loads; 2^31 is the out-of-range marker)
+    if (P >= (1ll << 31) || (long long)N * A * UH * UW * 4 >= (1ll << 31) || (long long)N * B * VH * VW * 4 >= (1ll << 31))
+        return IC_ERR_UNSUPPORTED;
     if (workspace_bytes < ic_conv2d_wgrad_workspace_bytes(N, A, B, VH, VW, KH, KW)) return IC_ERR_WORKSPACE;
     int TA, WA, TB, WB, S, PS;
     wg_plan(A, B, P, KH, KW, &TA, &WA, &TB, &WB, &S, &PS);
@@ -291,7 +285,8 @@ extern "C" int ic_pc_wgrad_f32(const float* U, const float* q, float pad_value, 
     IC_CHECK_ARG((U || q) && V && dw && workspace && N > 0 && A > 0 && B > 0 && VD > 0 && VH > 0 && VW > 0);
     if (q && A != 1) return IC_ERR_ARG;
     const long long P = (long long)N * VD * VH * VW;
-    if (P >= (1ll << 31)) return IC_ERR_UNSUPPORTED;
+    if (P >= (1ll << 31) || P * B * 4 >= (1ll << 31) ||
+        (long long)N * A * (VD + 1) * (VH + 2) * (VW + 2) * 4 >= (1ll << 31)) return IC_ERR_UNSUPPORTED;
     if (workspace_bytes < ic_pc_wgrad_workspace_bytes(N, A, B, VD, VH, VW)) return IC_ERR_WORKSPACE;
     int TA, WA, TB, WB, S, PS;
     wg_plan(A, B, P, 2, 7, &TA, &WA, &TB, &WB, &S, &PS);
