@@ -188,6 +188,7 @@ void pc_mfma_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
     constexpr int NCH = CIN / KC, C8 = KC / 8, RD = 7;
     static_assert(WM * WN == 4 && TR * TC == 32 * WN, "one 32-voxel accumulator tile per wave");
     static_assert(CIN % KC == 0 && KC % 8 == 0, "channel chunking");
+    static_assert(DS <= 256 && NST * 256 >= CHUNK + 64, "one brick plane per pass of the work-group, 64 spare floats behind the brick");
     __shared__ float lds[NST * 256];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -202,20 +203,17 @@ void pc_mfma_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
     const size_t cstride = (size_t)a.D * HW;
     const float* __restrict__ xin = a.in + (size_t)n * CIN * cstride + (size_t)od * HW;
 
-    // staging plan: e -> (ci, kd, row, col) of the brick [KC][2][TR+2][TC+2]; VALID conv: clip to the volume
-    int goff[NST];
-    static_assert(NST <= 64, "in-bounds mask is 64 bits");
-    unsigned long long inb = 0;
-#pragma unroll
-    for (int i = 0; i < NST; ++i) {
-        const int e = tid + 256 * i;
-        const int ci = e / CS, r1 = e - ci * CS;
-        const int kd = r1 / DS, r2 = r1 - kd * DS;
-        const int rr = r2 / S, cc = r2 - rr * S;
+    // staging plan: the brick [KC][2][TR+2][TC+2] is loaded plane by plane ((ci, kd) = 2 KC planes of DS elements): lane
+    // tid < DS owns position (tid / S, tid % S) of every plane, so a load is descriptor + one loop-invariant lane offset
+    // + a scalar plane offset, and the LDS address is plane * DS + tid.  (The first version derived (ci, kd, row, col)
+    // from a flat element index per load: 10 vector instructions per MFMA, mostly that index arithmetic.)  VALID conv:
+    // positions past the volume get an out-of-range offset -> the buffer load returns 0.
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xin, 0, (int)(((size_t)CIN * cstride - (size_t)od * HW) * 4), 0x00020000);
+    unsigned loff;
+    {
+        const int rr = tid / S, cc = tid - rr * S;
         const int iy = y0 + rr, ix = x0 + cc;
-        const bool ok = (e < CHUNK) && iy < a.H && ix < a.W;            // od + kd < D always
-        goff[i] = ok ? (int)(ci * cstride) + kd * HW + iy * a.W + ix : 0;
-        inb |= (ok ? 1ull : 0ull) << i;
+        loff = (tid < DS && iy < a.H && ix < a.W) ? (unsigned)((iy * a.W + ix) * 4) : 0x80000000u;   // od + kd < D always
     }
     const int j = lane & 31, kh = lane >> 5;
     const int q = 32 * wn + j;
@@ -242,12 +240,19 @@ void pc_mfma_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         if (c > 0) __syncthreads();                       // everyone done reading the previous brick
-        const float* xc = xin + (size_t)c * KC * cstride;
+        float stv[2 * KC];                                 // all loads first, then the writes under ONE predicate
 #pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            const float v = xc[goff[i]];
-            lds[tid + 256 * i] = ((inb >> i) & 1) ? v : 0.f;
+        for (int p = 0; p < 2 * KC; ++p) {
+            const int so = (int)((((size_t)(c * KC + p / 2)) * cstride + (size_t)(p & 1) * HW) * 4);      // scalar: plane (ci, kd)
+            stv[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, loff, so, 0));
         }
+        // unpredicated writes (a predicate per write makes the compiler pair every load with its own wait + branch): the
+        // lanes past the plane write their zeros into the spare floats behind the brick
+        // unpredicated writes (a predicate per write makes the compiler pair every load with its own wait + exec-mask
+        // branch): the lanes past the plane put their zeros into the spare floats behind the brick
+        const int lw = tid < DS ? tid : CHUNK + (tid & 63), lstep = tid < DS ? DS : 0;
+#pragma unroll
+        for (int p = 0; p < 2 * KC; ++p) lds[lw + p * lstep] = stv[p];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -284,16 +289,22 @@ void pc_mfma_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
     const int ovol = a.OD * a.OH * a.OW;
     const int v = (od * a.OH + (live ? oy : 0)) * a.OW + (live ? ox : 0);
     float val[16];
+    // one 64-bit base per tensor, then 32-bit channel steps (a channel plane is far below 2^31 elements)
+    const int co0 = 32 * cot + 4 * kh;
+    float* __restrict__ outp = FINAL ? nullptr : a.out + ((size_t)n * a.Cout + co0) * ovol + v;
+    const int rvol = a.RD * a.RH * a.RW;
+    const float* __restrict__ resp = a.res ? a.res + ((size_t)n * a.Cout + co0) * rvol + (size_t)(od + 2) * a.RH * a.RW
+                                                 + (size_t)((live ? oy : 0) + 2) * a.RW + (live ? ox : 0) + 2 : nullptr;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int co = 32 * cot + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int cr = (r & 3) + 8 * (r >> 2);           // channel = co0 + cr
+        const int co = co0 + cr;
         const bool cok = co < a.Cout;
         float x = acc[r] + (cok ? a.bias[co] : 0.f);
         if (a.relu) x = fmaxf(x, 0.f);
-        if (a.res && cok) x += a.res[(((size_t)n * a.Cout + co) * a.RD + od + 2) * a.RH * a.RW
-                                     + (size_t)((live ? oy : 0) + 2) * a.RW + (live ? ox : 0) + 2];
+        if (a.res && cok) x += resp[(unsigned)(cr * rvol)];
         val[r] = x;
-        if (!FINAL && cok && live) a.out[((size_t)n * a.Cout + co) * ovol + v] = x;
+        if (!FINAL && cok && live) outp[(unsigned)(cr * ovol)] = x;
     }
     if (FINAL) {
         // logits of one voxel are split over the two half-waves (kh = 0: channels 0-3, 8-11, ...; kh = 1: 4-7, ...)
@@ -391,8 +402,10 @@ static int pc_forward(const float* q, int prepadded, const int64_t* symbols, con
     a.in = q; a.w = wt[0]; a.bias = wt[1]; a.res = nullptr; a.out = b0;
     a.Cin = 1; a.Cout = k; a.D = C + 4; a.H = h + 8; a.W = w + 8; a.OD = C + 3; a.OH = h + 6; a.OW = w + 6;
     a.qC = C; a.qh = h; a.qw = w; a.relu = 1;
-    if ((rc = launch_pc<8, true, false>(a, st))) return rc;
-    const bool use_mfma = pc_mfma_supported(k, L);
+    // all k output channels of a voxel in one lane when k = 24: the input brick is read once instead of three times
+    if ((rc = (k == 24 ? launch_pc<24, true, false>(a, st) : launch_pc<8, true, false>(a, st)))) return rc;
+    // (the matrix-core kernels address one image's feature volume with 31-bit byte offsets)
+    const bool use_mfma = pc_mfma_supported(k, L) && (size_t)k * (C + 3) * (h + 6) * (w + 6) * 4 < (1ull << 31);
     float* pk1 = b2 + (size_t)N * k * (C + 1) * (h + 2) * (w + 2);
     float* pk2 = pk1 + pc_packed_floats(k, k);
     float* pk3 = pk2 + pc_packed_floats(k, k);
@@ -506,6 +519,7 @@ int icx_pc_bwd_data_mfma(const float* g, const float* w, float* dx_raw, int N, i
                          const float* zero_bias, void* workspace, size_t workspace_bytes, hipStream_t st) {
     const int KP = CoutF <= 24 ? 24 : 64;
     if (CoutF > 64 || CinF > 64 || (CinF != 24 && CinF != 64)) return IC_ERR_UNSUPPORTED;
+    if ((size_t)KP * (OD + 2) * (OH + 4) * (OW + 4) * 4 >= (1ull << 31)) return IC_ERR_UNSUPPORTED;
     const size_t gp_floats = (size_t)N * KP * (OD + 2) * (OH + 4) * (OW + 4);
     const size_t pk_floats = pc_packed_floats(KP, CinF);
     if (workspace_bytes < (gp_floats + pk_floats) * sizeof(float)) return IC_ERR_WORKSPACE;
@@ -533,6 +547,7 @@ int icx_pc_bwd_data_mfma(const float* g, const float* w, float* dx_raw, int N, i
 size_t icx_pc_bwd_data_mfma_workspace(int N, int CinF, int CoutF, int OD, int OH, int OW) {
     if (CoutF > 64 || (CinF != 24 && CinF != 64)) return 0;
     const int KP = CoutF <= 24 ? 24 : 64;
+    if ((size_t)KP * (OD + 2) * (OH + 4) * (OW + 4) * 4 >= (1ull << 31)) return 0;
     return ((size_t)N * KP * (OD + 2) * (OH + 4) * (OW + 4) + pc_packed_floats(KP, CinF)) * sizeof(float);
 }
 
