@@ -17,8 +17,10 @@
 typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-#define WG_KP 32            // positions per LDS chunk
-#define WG_LS 36            // LDS row stride (floats): 16-byte aligned rows, 36 * row mod 64 spreads 16 rows over all banks
+#ifndef WG_KP
+#define WG_KP 32            // positions per LDS chunk (16 was tried: 4 resident groups per CU but twice the slices to reduce -- slower)
+#endif
+#define WG_LS (WG_KP + 4)    // LDS row stride (floats): 16-byte aligned rows; 20 or 36 * row mod 64 spreads 16 rows over all banks
 
 struct WgArgs {
     const float* U; const float* V; float* partial;
@@ -36,8 +38,8 @@ __global__ __launch_bounds__(64 * WA * WB) void conv_wgrad_kernel(const WgArgs a
     constexpr int NTH = 64 * WA * WB;
     constexpr int AT = 32 * TA * WA, BT = 32 * TB * WB;       // channel rows staged per chunk
     constexpr int ROWS = AT + BT;
-    constexpr int RPT = ROWS / (NTH / 32);                     // rows each thread stages (its pixel column is fixed)
-    static_assert(ROWS % (NTH / 32) == 0, "rows divide evenly over the thread rows");
+    constexpr int RPT = ROWS / (NTH / WG_KP);                  // rows each thread stages (its pixel column is fixed)
+    static_assert(ROWS % (NTH / WG_KP) == 0, "rows divide evenly over the thread rows");
     __shared__ __attribute__((aligned(16))) float lds[2][ROWS * WG_LS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(64 * WA * WB) void conv_wgrad_kernel(const WgArgs a
     const int ty = MODE3D ? 0 : tap / a.KW, tx = MODE3D ? 0 : tap % a.KW;
     const int q_begin = split * a.PS, q_end = min(q_begin + a.PS, a.P);
     const int VHW = a.VH * a.VW, UHW = a.UH * a.UW;
-    const int px = tid & 31, trow = tid >> 5;                  // this thread's pixel column and first row
+    const int px = tid % WG_KP, trow = tid / WG_KP;            // this thread's pixel column and first row
 
     wg_f32x16 acc[TA][TB];
 #pragma unroll
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(64 * WA * WB) void conv_wgrad_kernel(const WgArgs a
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    constexpr int TROWS = NTH / 32;                            // thread rows; AT and BT are multiples of 32 >= TROWS
+    constexpr int TROWS = NTH / WG_KP;                         // thread rows; AT and BT are multiples of 32 >= TROWS
     constexpr int RA = AT / TROWS, RB = BT / TROWS;            // U rows and V rows staged by each thread
     static_assert(RA + RB == RPT, "row split");
     float st[RPT];
@@ -133,10 +135,10 @@ __global__ __launch_bounds__(64 * WA * WB) void conv_wgrad_kernel(const WgArgs a
             f32x4 av[TA], bv[TB];
 #pragma unroll
             for (int i = 0; i < TA; ++i)
-                av[i] = *(const f32x4*)(L + (32 * (TA * wa + i) + li) * WG_LS + 16 * kh + 4 * j4);
+                av[i] = *(const f32x4*)(L + (32 * (TA * wa + i) + li) * WG_LS + (WG_KP / 2) * kh + 4 * j4);
 #pragma unroll
             for (int j = 0; j < TB; ++j)
-                bv[j] = *(const f32x4*)(L + (AT + 32 * (TB * wb + j) + li) * WG_LS + 16 * kh + 4 * j4);
+                bv[j] = *(const f32x4*)(L + (AT + 32 * (TB * wb + j) + li) * WG_LS + (WG_KP / 2) * kh + 4 * j4);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
