@@ -142,3 +142,17 @@ def test_fp32_oracle_close_to_fp64_shadow(configs, syn_weights):
     a = O.encode(torch.as_tensor(x).float(), syn_weights, ae_cfg.as_dict())
     b = O.encode(torch.as_tensor(x).double(), syn_weights, ae_cfg.as_dict())
     assert float((a.z.double() - b.z).abs().max()) < 1e-4 * max(1.0, float(b.z.abs().max()))
+
+
+def test_oracle_matches_frozen_end_to_end_fixture():
+    """regression pin: today's oracle reproduces the end-to-end numbers frozen in tests/golden/oracle_e2e.npz
+    (make_oracle_e2e.py) -- a change of the oracle cannot silently move the target of the GPU parity tests."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_oracle_e2e', os.path.join(GOLD, 'make_oracle_e2e.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    got = mod.compute()
+    g = np.load(os.path.join(GOLD, 'oracle_e2e.npz'))
+    assert np.array_equal(got['symbols'], g['symbols'])
+    for k in ('z', 'heatmap', 'bitcost', 'x_out', 'bpp'):
+        assert np.max(np.abs(got[k] - g[k])) <= 1e-9 * max(1.0, float(np.abs(g[k]).max())), k

@@ -300,3 +300,24 @@ def test_device_metrics_match_numpy(cuda):
         assert abs(metrics.msssim_nchw_uint8_device(ad, bd) - float(metrics.msssim_nchw_uint8(a, b))) < 1e-6
         assert abs(metrics.psnr_uint8_device(ad, bd) - float(metrics.psnr_uint8(a, b))) < 1e-4
     assert metrics.psnr_uint8_device(ad, ad) == float('inf') and metrics.msssim_nchw_uint8_device(ad, ad) == 1.0
+
+
+def test_against_frozen_oracle_fixture(cuda, configs, syn_weights, nets):
+    """the HIP path against the committed end-to-end fixture (tests/golden/oracle_e2e.npz: float64 oracle outputs frozen
+    by make_oracle_e2e.py), independent of the oracle code that is imported at test time."""
+    import os
+    from imgcomp_cvpr_amd import bits, weights as W
+    ae, pc = nets
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'oracle_e2e.npz'))
+    x = W.synthetic_image((1, 3, 64, 96), 'natural', seed=3)
+    xd = dev(x, cuda)
+    enc = ae.encode(xd, False)
+    assert_close(enc.z, torch.as_tensor(g['z']), 'z vs fixture')
+    assert_close(enc.heatmap, torch.as_tensor(g['heatmap']), 'heatmap vs fixture')
+    flips = enc.symbols.cpu().numpy() != g['symbols']
+    assert flips.mean() < 5e-3
+    if not flips.any():                                   # same symbols -> the rest is comparable element-wise
+        bc = pc.bitcost(enc.qbar, enc.symbols, False, pad_value=pc.auto_pad_value(ae))
+        assert_close(bc, torch.as_tensor(g['bitcost']), 'bit cost vs fixture')
+        assert abs(float(bits.bitcost_to_bpp(bc, xd)) - float(g['bpp'])) < 1e-4
+        assert_close(ae.decode(enc.qhard, False), torch.as_tensor(g['x_out']), 'x_out vs fixture')
