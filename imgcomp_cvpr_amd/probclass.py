@@ -173,7 +173,8 @@ class _ResShallow(_Network3D):
 
     def bitcost(self, q, target_symbols, is_training, pad_value=0, return_logits=False):
         if is_training:
-            raise NotImplementedError('backward kernels of the context model are not built yet (DESIGN.md)')
+            raise NotImplementedError('is_training=True: the context model trains inside imgcomp_cvpr_amd.training.TrainGraph '
+                                      '(forward with tape + hand-written backward); this plugin method is inference only')
         self._require_weights()
         assert q.dim() == 4, 'Expected NCHW'
         _lib.require_cuda(q, 'q')
@@ -206,7 +207,8 @@ class _ResShallow(_Network3D):
 
     def logits(self, q, is_training):
         if is_training:
-            raise NotImplementedError('backward kernels of the context model are not built yet (DESIGN.md)')
+            raise NotImplementedError('is_training=True: the context model trains inside imgcomp_cvpr_amd.training.TrainGraph '
+                                      '(forward with tape + hand-written backward); this plugin method is inference only')
         self._require_weights()
         _lib.require_cuda(q, 'q')
         if q.dim() == 5:
