@@ -25,6 +25,7 @@
 // Rounding differs from the direct form (different summation tree); measured against the float64 oracle both stay
 // inside the 1e-4 parity bound (tests/test_gpu_ops.py).
 #include "common.h"
+#include <type_traits>
 #include "internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -103,9 +104,16 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
     return r;
 }
 
-template <bool VEC>
-__device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx) {
+// KS = 1: the four waves of a work-group are the four output-channel tiles of one tile group (64 k-steps each).
+// KS = 4: small maps that cannot fill the chip with 4 x groups waves -- a work-group is ONE channel tile (cot) of a
+//         group, its four waves take a quarter of the input channels each (16 k-steps) and the partial accumulators are
+//         summed through LDS in the fixed order (w0 + w1) + (w2 + w3); wave w then finishes output registers 4w..4w+3.
+template <bool VEC, int KS>
+__device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx, int cot_in) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform (scalar) on purpose
+    const int cot = KS == 1 ? wave : cot_in;                                // this wave's output-channel tile
+    constexpr int NKS = 64 / KS;                                            // k-steps per wave
+    const int ks0 = KS == 1 ? 0 : wave * NKS;
     const int lane = threadIdx.x & 63, li = lane & 31, kh = lane >> 5;
     const int txl = li & 15;
     const int ty = gy * 2 + (li >> 4), tx = gx * 16 + txl;
@@ -165,7 +173,7 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
         }
     };
     auto load_filter = [&](int s, int ks) {
-        const int so = (wave * 64 + ks) * 4096;             // scalar: 4 KB per (channel tile, k-step)
+        const int so = (cot * 64 + ks) * 4096;              // scalar: 4 KB per (channel tile, k-step)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             fl[s][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(fr, fo + q * 1024u, so, 0));
@@ -175,9 +183,9 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
     // prologue load scheduled late would make every iteration wait for almost everything in flight)
 #pragma unroll
     for (int s = 0; s < WN_STAGES - 1; ++s) {
-        load_patch(s, s);
+        load_patch(s, ks0 + s);
         __builtin_amdgcn_sched_barrier(0);
-        load_filter(s, s);
+        load_filter(s, ks0 + s);
         __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -216,16 +224,16 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
 #ifdef WN_PROF
     unsigned long long pd1 = 0, pd2 = 0, pd3 = 0, pt0 = __builtin_amdgcn_s_memtime();
 #endif
-    for (int k0 = 0; k0 < 64; k0 += WN_STAGES) {
+    for (int k0 = 0; k0 < NKS; k0 += WN_STAGES) {
 #pragma unroll
         for (int s = 0; s < WN_STAGES; ++s) {
-            const int ks = k0 + s;
+            const int ks = ks0 + k0 + s;
             const int cur = s & 1, nxt = cur ^ 1;
             // Request k-step ks + 3 into the ring slot whose filter was consumed one k-step ago and whose patch was
             // transformed two k-steps ago.  Always issued (past the end it re-reads the last k-step) so the loop body
             // is ONE basic block and outstanding loads are counted exactly.
             const int sn = (s + WN_STAGES - 1) % WN_STAGES;
-            const int kn = ks + WN_STAGES - 1 < 64 ? ks + WN_STAGES - 1 : 63;
+            const int kn = ks + WN_STAGES - 1 < ks0 + NKS ? ks + WN_STAGES - 1 : ks0 + NKS - 1;
             if (!(WN_ABL & 1)) load_patch(sn, kn);
             if (!(WN_ABL & 2)) load_filter(sn, kn);
             // the input transform of the NEXT k-step
@@ -260,19 +268,17 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
 
     // ---- At M A, BN fold, activation, residuals, store ----
     const int oy = 2 * ty, ox = 2 * tx;
-    if (oy >= H || ox >= W) return;
+    const bool inside = oy < H && ox < W;
     const bool row1 = oy + 1 < H, col1 = ox + 1 < W;
     const bool vec = col1 && ((W & 1) == 0);
     const long long obase = (long long)n * WN_C * HW + (long long)oy * W + ox;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = 32 * wave + 8 * (r >> 2) + 4 * kh + (r & 3);
+    // one output channel of this lane's tile from its 16 position sums
+    auto emit = [&](int co, const float (&m)[16]) __attribute__((always_inline)) {
         float t0[4], t1[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float m0 = acc[j][r], m1 = acc[4 + j][r], m2 = acc[8 + j][r], m3 = acc[12 + j][r];
-            t0[j] = m0 + m1 + m2;
-            t1[j] = m1 - m2 - m3;
+            t0[j] = m[j] + m[4 + j] + m[8 + j];
+            t1[j] = m[4 + j] - m[8 + j] - m[12 + j];
         }
         float o00 = t0[0] + t0[1] + t0[2], o01 = t0[1] - t0[2] - t0[3];
         float o10 = t1[0] + t1[1] + t1[2], o11 = t1[1] - t1[2] - t1[3];
@@ -309,6 +315,48 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
             if (col1) a.y[o + 1] = o01;
             if (row1) { a.y[o + W] = o10; if (col1) a.y[o + W + 1] = o11; }
         }
+    };
+    if (KS == 1) {
+        if (!inside) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float m[16];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) m[p] = acc[p][r];
+            emit(32 * cot + 8 * (r >> 2) + 4 * kh + (r & 3), m);
+        }
+    } else {
+        // cross-wave sum: wave w finishes output registers 4w..4w+3 of every position.  Eight phases of two positions: every
+        // wave stores its 2 x 16 partial values (compile-time register indices, the stored accumulators are dead afterwards)
+        // and reads back its own quarter from all four waves (run-time LDS address, compile-time destination):
+        // red[wave][pos in phase][reg][lane], 32 KB.  Sum order (w0 + w1) + (w2 + w3).
+        __shared__ float red[4 * 2 * 16 * 64];
+        float mine[16][4];
+#pragma unroll
+        for (int ph = 0; ph < 8; ++ph) {
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((wave * 2 + pp) * 16 + r) * 64 + lane] = acc[2 * ph + pp][r];
+            __syncthreads();
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float* q = red + ((pp * 16) + 4 * wave + i) * 64 + lane;
+                    mine[2 * ph + pp][i] = (q[0] + q[2 * 16 * 64]) + (q[2 * 2 * 16 * 64] + q[3 * 2 * 16 * 64]);
+                }
+            __syncthreads();
+        }
+        if (!inside) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float m[16];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) m[p] = mine[p][i];
+            const int r = 4 * wave + i;
+            emit(32 * cot + 8 * (r >> 2) + 4 * kh + (r & 3), m);
+        }
     }
 }
 
@@ -317,7 +365,17 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void wino3x3_c128_kernel(const WnArgs a) {
     const int gx = blockIdx.x % a.gcols;
     const int t = blockIdx.x / a.gcols;
-    wino_body<VEC>(a, t / a.grows, t % a.grows, gx);
+    wino_body<VEC, 1>(a, t / a.grows, t % a.grows, gx, 0);
+}
+
+// K-split form for maps that do not fill the chip: one work-group per (tile group, channel tile)
+template <bool VEC>
+__global__ __launch_bounds__(256) void wino3x3_c128_ksplit_kernel(const WnArgs a) {
+    const int cot = blockIdx.x & 3;
+    const int g = blockIdx.x >> 2;
+    const int gx = g % a.gcols;
+    const int t = g / a.gcols;
+    wino_body<VEC, 4>(a, t / a.grows, t % a.grows, gx, cot);
 }
 
 // all the 3x3 filters of a network in one launch (training re-packs every filter every step; 128 five-microsecond
@@ -371,11 +429,13 @@ extern "C" int ic_pack_wino3x3_c128_f32(const float* w_tf, float* w_packed, int 
 }
 
 static unsigned long long* g_wino_prof = nullptr;
+static int g_wino_ksplit = -1;      // -1 automatic, 0 never, 1 always (tuning key 2)
 // tuning only: key 0 = device buffer (as two 32-bit halves: key 0 low, key 1 high) for WN_PROF builds
 extern "C" void ic_wino3x3_c128_set_tuning(int key, int value) {
     static unsigned long long bits = 0;
     if (key == 0) bits = (bits & 0xffffffff00000000ull) | (unsigned)value;
     if (key == 1) { bits = (bits & 0xffffffffull) | ((unsigned long long)(unsigned)value << 32); g_wino_prof = (unsigned long long*)bits; }
+    if (key == 2) g_wino_ksplit = value;
 }
 
 extern "C" int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
@@ -388,17 +448,26 @@ extern "C" int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed,
     a.x = x; a.wp = w_packed; a.scale = scale; a.shift = shift; a.res1 = res1; a.res2 = res2; a.y = y;
     a.N = N; a.H = H; a.W = W; a.relu = relu;
     a.grows = ic_cdiv(H, 4); a.gcols = ic_cdiv(W, 32); a.prof = g_wino_prof;
-    const dim3 grid((unsigned)((long long)N * a.grows * a.gcols));
-    if ((W & 1) == 0) hipLaunchKernelGGL(wino3x3_c128_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(wino3x3_c128_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    const long long groups = (long long)N * a.grows * a.gcols;
+    // K-split when whole-K waves (4 per group) would leave most of the 1024 SIMDs idle
+    const bool ksplit = g_wino_ksplit < 0 ? groups <= 128 : g_wino_ksplit != 0;      // measured cross-over, see pick_algo
+    if (ksplit) {
+        const dim3 grid((unsigned)(groups * 4));
+        if ((W & 1) == 0) hipLaunchKernelGGL(wino3x3_c128_ksplit_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(wino3x3_c128_ksplit_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        const dim3 grid((unsigned)groups);
+        if ((W & 1) == 0) hipLaunchKernelGGL(wino3x3_c128_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(wino3x3_c128_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    }
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
 
 // ---- both forms behind one packed filter: what the network / training entry points use ---------------------------------
 // blob = [direct-form fragments (ic_conv3x3_c128_packed_floats) | Winograd fragments (16 x 128 x 128)].
-// The form is picked per launch from the shape: the Winograd kernel runs one wave per SIMD and needs ~43 us whatever
-// the map size (64 k-steps x ~1230 clocks), so small maps stay on the direct kernel.
+// The form is picked per launch: Winograd whenever the shape is addressable with 31-bit offsets (whole-K waves for maps
+// that fill the chip, K-split work-groups for small ones), the direct kernel otherwise or on request.
 static int g_algo = -1;   // -1 automatic, 0 direct, 1 Winograd
 extern "C" int ic_conv3x3_c128_set_algo(int algo) { const int prev = g_algo; g_algo = algo; return prev; }
 
@@ -415,11 +484,11 @@ extern "C" int ic_conv3x3_c128_pick_algo(int N, int H, int W) {
     if (N <= 0 || H <= 0 || W <= 0) return 0;
     if ((long long)WN_C * H * W * 4 >= (1ll << 31)) return 0;
     if (g_algo >= 0) return g_algo;
-    const long long groups = (long long)N * ic_cdiv(H, 4) * ic_cdiv(W, 32);
-    const double rounds = (double)((groups + 255) / 256);
-    const double wino_us = rounds * (groups > 128 ? 52.0 : 43.0);           // full chip: lower clocks
-    const double direct_us = 2.0 * 9 * WN_C * WN_C * (double)N * H * W / 1.05e8 + 8.0;
-    return wino_us < direct_us ? 1 : 0;
+    // Measured on the MI355X (tools/bench_wino.py): the direct kernel has a ~27 us floor (16 sequential channel chunks per
+    // work-group) and 95-105 TFLOP/s at best; the Winograd kernel takes ~18 us per round of K-split work-groups (<= 128
+    // tile groups: 16.6 us for a 16x16 map, 37 us for 128x128) and 43-55 us per round of whole-K waves (Kodak 48-55 us,
+    // batch-32 training maps 55 us vs 93 us direct).  It wins at every shape it supports.
+    return 1;
 }
 
 extern "C" int ic_conv3x3_c128_auto_f32(const float* x, const float* w_both, const float* scale, const float* shift,

@@ -178,7 +178,8 @@ def test_conv3x3_c128_winograd(cuda, shape, N, H, W):
     xd, wd, sd, hd, r1d, r2d = d(x), d(w), d(scale), d(shift), d(r1), d(r2)
     wp = torch.empty(L.lib.ic_wino3x3_c128_packed_floats(), device=cuda)
     L.check(L.lib.ic_pack_wino3x3_c128_f32(L.ptr(wd), L.ptr(wp), 0, L.current_stream()))
-    L.lib.ic_wino3x3_c128_set_tuning(0, shape)
+    # `shape` doubles as the K-split switch: -1 automatic, 0 whole-K waves, 1 four K-quarters per work-group
+    L.lib.ic_wino3x3_c128_set_tuning(2, shape)
     try:
         for relu, res in ((1, ()), (0, (r1d,)), (0, (r1d, r2d))):
             y = torch.full((N, 128, H, W), float('nan'), device=cuda)
@@ -199,17 +200,18 @@ def test_conv3x3_c128_winograd(cuda, shape, N, H, W):
         ref = _ref_conv(x, w_adj, np.ones(128, np.float32), np.zeros(128, np.float32), 1, 0)
         assert_close(y, ref, 'winograd adjoint shape {}'.format(shape))
     finally:
-        L.lib.ic_wino3x3_c128_set_tuning(0, -1)
+        L.lib.ic_wino3x3_c128_set_tuning(2, -1)
 
 
 def test_conv3x3_c128_auto_selection(cuda):
-    """one packed blob, both forms: the shape rule keeps small maps on the direct kernel, sends chip-filling ones to
-    Winograd, the override works, and both give the oracle's result through the same entry point."""
+    """one packed blob, both forms: Winograd wherever its 31-bit addressing reaches, the direct form beyond; the
+    override works, and both give the oracle's result through the same entry point."""
     L = _lib()
     assert L.lib.ic_conv3x3_c128_both_packed_floats() == 9 * 128 * 128 + 16 * 128 * 128
-    assert L.lib.ic_conv3x3_c128_pick_algo(1, 16, 16) == 0
+    assert L.lib.ic_conv3x3_c128_pick_algo(1, 16, 16) == 1              # K-split work-groups serve small maps
     assert L.lib.ic_conv3x3_c128_pick_algo(1, 128, 192) == 1
     assert L.lib.ic_conv3x3_c128_pick_algo(32, 32, 32) == 1
+    assert L.lib.ic_conv3x3_c128_pick_algo(1, 4096, 2048) == 0          # beyond 31-bit offsets: direct form
     N, H, W = 1, 24, 40
     rs = np.random.RandomState(7)
     x = rs.normal(0, 1, (N, 128, H, W)).astype(np.float32)

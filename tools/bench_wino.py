@@ -54,10 +54,11 @@ def main():
     print('shape N={} {}x{}  direct-form flop/launch {:.3e}'.format(a.n, a.h, a.w, flop))
     us = timeit(direct)
     print('direct  : {:8.2f} us  {:6.1f} TFLOP/s'.format(us, flop / us / 1e6))
-    for shape in (0, 1):
-        lib.ic_wino3x3_c128_set_tuning(0, shape)
+    for ksplit in (0, 1):
+        lib.ic_wino3x3_c128_set_tuning(2, ksplit)
         us = timeit(wino)
-        print('winograd shape {}: {:8.2f} us  {:6.1f} direct-equivalent TFLOP/s'.format(shape, us, flop / us / 1e6))
+        print('winograd {}: {:8.2f} us  {:6.1f} direct-equivalent TFLOP/s'.format('K-split (4 quarters per group)' if ksplit else 'whole-K waves', us, flop / us / 1e6))
+    lib.ic_wino3x3_c128_set_tuning(2, -1)
     print('max |direct - winograd| = {:.3e}  (max |y| {:.3e})'.format(float((y - y2).abs().max()), float(y.abs().max())))
 
 
