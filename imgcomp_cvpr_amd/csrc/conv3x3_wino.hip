@@ -328,24 +328,26 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
     } else {
         // cross-wave sum: wave w finishes output registers 4w..4w+3 of every position.  Eight phases of two positions: every
         // wave stores its 2 x 16 partial values (compile-time register indices, the stored accumulators are dead afterwards)
-        // and reads back its own quarter from all four waves (run-time LDS address, compile-time destination):
-        // red[wave][pos in phase][reg][lane], 32 KB.  Sum order (w0 + w1) + (w2 + w3).
-        __shared__ float red[4 * 2 * 16 * 64];
-        float mine[16][4];
+        // and reads back its own quarter from all four waves (run-time LDS address, compile-time destination), 32 KB of
+        // LDS.  Sum order (w0 + w1) + (w2 + w3).
+        __shared__ f32x4 red[4 * 2 * 4 * 64];                 // [wave][pos in phase][register quad][lane], 16-byte accesses
+        f32x4 mine[16];
 #pragma unroll
         for (int ph = 0; ph < 8; ++ph) {
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) red[((wave * 2 + pp) * 16 + r) * 64 + lane] = acc[2 * ph + pp][r];
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const f32x16 v = acc[2 * ph + pp];
+                    const f32x4 q = {v[4 * r4], v[4 * r4 + 1], v[4 * r4 + 2], v[4 * r4 + 3]};
+                    red[((wave * 2 + pp) * 4 + r4) * 64 + lane] = q;
+                }
             __syncthreads();
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float* q = red + ((pp * 16) + 4 * wave + i) * 64 + lane;
-                    mine[2 * ph + pp][i] = (q[0] + q[2 * 16 * 64]) + (q[2 * 2 * 16 * 64] + q[3 * 2 * 16 * 64]);
-                }
+            for (int pp = 0; pp < 2; ++pp) {
+                const f32x4* q = red + (pp * 4 + wave) * 64 + lane;
+                mine[2 * ph + pp] = (q[0] + q[2 * 4 * 64]) + (q[2 * 2 * 4 * 64] + q[3 * 2 * 4 * 64]);
+            }
             __syncthreads();
         }
         if (!inside) return;
@@ -450,7 +452,9 @@ extern "C" int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed,
     a.grows = ic_cdiv(H, 4); a.gcols = ic_cdiv(W, 32); a.prof = g_wino_prof;
     const long long groups = (long long)N * a.grows * a.gcols;
     // K-split when whole-K waves (4 per group) would leave most of the 1024 SIMDs idle
-    const bool ksplit = g_wino_ksplit < 0 ? groups <= 128 : g_wino_ksplit != 0;      // measured cross-over, see pick_algo
+    // measured cross-over: up to 128 tile groups (<= 2 rounds of 256 K-split work-groups at ~18 us) the K-split form wins
+    // (37 us vs 43-50 us); at Kodak's 192 groups the micro-benchmark is a tie and the whole step is 6 % slower with K-split
+    const bool ksplit = g_wino_ksplit < 0 ? groups <= 128 : g_wino_ksplit != 0;
     if (ksplit) {
         const dim3 grid((unsigned)(groups * 4));
         if ((W & 1) == 0) hipLaunchKernelGGL(wino3x3_c128_ksplit_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
