@@ -396,3 +396,38 @@ def test_error_codes(cuda):
     with pytest.raises(L.HipLibraryError):
         from imgcomp_cvpr_amd import quantizer
         quantizer.quantize(torch.zeros(1, 1, 2, 2), torch.zeros(6), 1.0)     # CPU tensors: no fallback
+
+
+def test_conv3x3_c128_forms_agree_on_random_shapes(cuda):
+    """fuzz: direct form, Winograd whole-K and Winograd K-split on 24 random (N, H, W) incl. odd and tiny maps, with ReLU and
+    one residual -- all three within fp32 rounding of each other (the oracle comparison of each form is done above)."""
+    L = _lib()
+    rs = np.random.RandomState(2024)
+    w = rs.normal(0, 0.05, (3, 3, 128, 128)).astype(np.float32)
+    scale, shift = _bn(rs, 128)
+    wd, sd, hd = dev(w, cuda), dev(scale, cuda), dev(shift, cuda)
+    wp = torch.empty(L.lib.ic_conv3x3_c128_both_packed_floats(), device=cuda)
+    L.check(L.lib.ic_pack_conv3x3_c128_both_f32(L.ptr(wd), L.ptr(wp), 0, L.current_stream()))
+    shapes = [(1, 1, 1), (1, 2, 3), (3, 5, 33), (1, 31, 65), (2, 4, 32)] + \
+             [(int(rs.randint(1, 4)), int(rs.randint(1, 70)), int(rs.randint(1, 100))) for _ in range(19)]
+    try:
+        for N, H, W in shapes:
+            x = torch.randn((N, 128, H, W), device=cuda)
+            r = torch.randn((N, 128, H, W), device=cuda)
+            outs = []
+            for algo, ks in ((0, -1), (1, 0), (1, 1)):
+                L.lib.ic_conv3x3_c128_set_algo(algo)
+                L.lib.ic_wino3x3_c128_set_tuning(2, ks)
+                y = torch.full((N, 128, H, W), float('nan'), device=cuda)
+                L.check(L.lib.ic_conv3x3_c128_auto_f32(L.ptr(x), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(r), None, L.ptr(y),
+                                                       N, H, W, 1, L.current_stream()))
+                outs.append(y)
+            torch.cuda.synchronize()
+            scale_ = max(1.0, float(outs[0].abs().max()))
+            for k in (1, 2):
+                err = float((outs[k] - outs[0]).abs().max()) / scale_
+                assert err < 2e-5, 'shape {} form {}: {}'.format((N, H, W), k, err)
+            assert bool(torch.isfinite(outs[2]).all())
+    finally:
+        L.lib.ic_conv3x3_c128_set_algo(-1)
+        L.lib.ic_wino3x3_c128_set_tuning(2, -1)
