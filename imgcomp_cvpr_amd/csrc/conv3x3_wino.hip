@@ -110,6 +110,9 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
 //         summed through LDS in the fixed order (w0 + w1) + (w2 + w3); wave w then finishes output registers 4w..4w+3.
 template <bool VEC, int KS>
 __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx, int cot_in) {
+#ifdef WN_PROF
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform (scalar) on purpose
     const int cot = KS == 1 ? wave : cot_in;                                // this wave's output-channel tile
     constexpr int NKS = 64 / KS;                                            // k-steps per wave
@@ -260,10 +263,8 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
         }
     }
 #ifdef WN_PROF
-    if (a.prof && lane == 0) {
-        unsigned long long* d = a.prof + 4 * ((size_t)blockIdx.x * 4 + wave);
-        d[0] = pd1; d[1] = pd2; d[2] = pd3; d[3] = __builtin_amdgcn_s_memtime();
-    }
+    // stamps: entry -> loop start (prologue), loop, loop end -> last store issued (epilogue); written at the very end
+    const unsigned long long t_loop0 = pt0 - pd1, t_loop1 = pt0;
 #endif
 
     // ---- At M A, BN fold, activation, residuals, store ----
@@ -318,13 +319,70 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
     };
     if (KS == 1) {
         if (!inside) return;
+        if constexpr (VEC) {                               // even W: every inside tile has both columns, pairs are aligned
+            // The operands of channel r + 3 (BN scale/shift, residual rows) are requested while channel r is finished:
+            // fetched inside each iteration, every one of the 16 waited out its own L2 round trip (10.6k of a wave's 93k
+            // clocks); all 16 at once would need 160 registers next to the 256 accumulators and spill into the main loop.
+            constexpr int EPD = 3;
+            float sc[EPD], sh[EPD];
+            f32x2 ra0[EPD], ra1[EPD], rb0[EPD], rb1[EPD];
+            const float* __restrict__ scp = a.scale + 32 * cot + 4 * kh;
+            const float* __restrict__ shp = a.shift + 32 * cot + 4 * kh;
+            const long long o0 = obase + (long long)(32 * cot + 4 * kh) * HW;
+            auto fetch = [&](int r) __attribute__((always_inline)) {
+                const int cr = (r & 3) + 8 * (r >> 2), sl = r % EPD;              // channel = 32 cot + 4 kh + cr
+                sc[sl] = scp[cr]; sh[sl] = shp[cr];
+                const long long o = o0 + (long long)cr * HW;
+                if (a.res1) {
+                    ra0[sl] = *(const f32x2*)(a.res1 + o);
+                    ra1[sl] = row1 ? *(const f32x2*)(a.res1 + o + W) : f32x2{0.f, 0.f};
+                }
+                if (a.res2) {
+                    rb0[sl] = *(const f32x2*)(a.res2 + o);
+                    rb1[sl] = row1 ? *(const f32x2*)(a.res2 + o + W) : f32x2{0.f, 0.f};
+                }
+            };
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float m[16];
+            for (int r = 0; r < EPD - 1; ++r) fetch(r);
 #pragma unroll
-            for (int p = 0; p < 16; ++p) m[p] = acc[p][r];
-            emit(32 * cot + 8 * (r >> 2) + 4 * kh + (r & 3), m);
+            for (int r = 0; r < 16; ++r) {
+                if (r + EPD - 1 < 16) fetch(r + EPD - 1);
+                const int cr = (r & 3) + 8 * (r >> 2), sl = r % EPD;
+                float t0[4], t1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float m0 = acc[j][r], m1 = acc[4 + j][r], m2 = acc[8 + j][r], m3 = acc[12 + j][r];
+                    t0[j] = m0 + m1 + m2;
+                    t1[j] = m1 - m2 - m3;
+                }
+                float o00 = t0[0] + t0[1] + t0[2], o01 = t0[1] - t0[2] - t0[3];
+                float o10 = t1[0] + t1[1] + t1[2], o11 = t1[1] - t1[2] - t1[3];
+                o00 = fmaf(o00, sc[sl], sh[sl]); o01 = fmaf(o01, sc[sl], sh[sl]);
+                o10 = fmaf(o10, sc[sl], sh[sl]); o11 = fmaf(o11, sc[sl], sh[sl]);
+                if (a.relu) { o00 = fmaxf(o00, 0.f); o01 = fmaxf(o01, 0.f); o10 = fmaxf(o10, 0.f); o11 = fmaxf(o11, 0.f); }
+                f32x2 q0 = {o00, o01}, q1 = {o10, o11};
+                if (a.res1) { q0 += ra0[sl]; q1 += ra1[sl]; }
+                if (a.res2) { q0 += rb0[sl]; q1 += rb1[sl]; }
+                const long long o = o0 + (long long)cr * HW;
+                *(f32x2*)(a.y + o) = q0;
+                if (row1) *(f32x2*)(a.y + o + W) = q1;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float m[16];
+#pragma unroll
+                for (int p = 0; p < 16; ++p) m[p] = acc[p][r];
+                emit(32 * cot + 8 * (r >> 2) + 4 * kh + (r & 3), m);
+            }
         }
+#ifdef WN_PROF
+        if (a.prof && lane == 0) {
+            unsigned long long* d = a.prof + 4 * ((size_t)blockIdx.x * 4 + wave);
+            d[0] = t_loop0 - t_entry; d[1] = t_loop1 - t_loop0; d[2] = __builtin_amdgcn_s_memtime() - t_loop1; d[3] = t_entry;
+        }
+#endif
     } else {
         // cross-wave sum: wave w finishes output registers 4w..4w+3 of every position.  Eight phases of two positions: every
         // wave stores its 2 x 16 partial values (compile-time register indices, the stored accumulators are dead afterwards)

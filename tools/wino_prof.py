@@ -23,4 +23,8 @@ lib.ic_wino3x3_c128_set_tuning(0, a & 0xffffffff if (a & 0xffffffff) < 2**31 els
 lib.ic_wino3x3_c128_set_tuning(1, (a >> 32))
 run(); torch.cuda.synchronize()
 d = prof.cpu().view(nwg * 4, 4).double()
-print('waves', nwg * 4, 'clocks per k-step %.0f' % (d[:, 0].mean() / 64))
+live = d[:, 1] > 0
+d = d[live]
+span = (d[:, 3] + d[:, :3].sum(1)).max() - d[:, 3].min()
+print('waves %d  clocks: prologue %.0f  loop %.0f (%.0f per k-step)  epilogue %.0f  | wave total %.0f  kernel span %.0f  start skew max %.0f'
+      % (d.shape[0], d[:, 0].mean(), d[:, 1].mean(), d[:, 1].mean() / 64, d[:, 2].mean(), d[:, :3].sum(1).mean(), span, (d[:, 3] - d[:, 3].min()).max()))
