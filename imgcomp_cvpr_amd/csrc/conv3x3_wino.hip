@@ -320,10 +320,10 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
     if (KS == 1) {
         if (!inside) return;
         if constexpr (VEC) {                               // even W: every inside tile has both columns, pairs are aligned
-            // The operands of channel r + 3 (BN scale/shift, residual rows) are requested while channel r is finished:
+            // The operands of channel r + 5 (BN scale/shift, residual rows) are requested while channel r is finished:
             // fetched inside each iteration, every one of the 16 waited out its own L2 round trip (10.6k of a wave's 93k
             // clocks); all 16 at once would need 160 registers next to the 256 accumulators and spill into the main loop.
-            constexpr int EPD = 3;
+            constexpr int EPD = 6;
             float sc[EPD], sh[EPD];
             f32x2 ra0[EPD], ra1[EPD], rb0[EPD], rb1[EPD];
             const float* __restrict__ scp = a.scale + 32 * cot + 4 * kh;
