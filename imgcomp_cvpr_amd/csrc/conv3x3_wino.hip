@@ -408,14 +408,49 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
             }
             __syncthreads();
         }
+        // all epilogue operands of this wave's four channels in one batch (requested any earlier they would sit on top of
+        // the 256 live accumulators and spill)
+        float esc[4], esh[4];
+        f32x2 ea0[4], ea1[4], eb0[4], eb1[4];
+        const long long eo0 = obase + (long long)(32 * cot + 8 * wave + 4 * kh) * HW;     // channel = 32 cot + 8 wave + 4 kh + i
+        if (VEC && inside) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = 32 * cot + 8 * wave + 4 * kh + i;
+                esc[i] = a.scale[co]; esh[i] = a.shift[co];
+                const long long o = eo0 + (long long)i * HW;
+                if (a.res1) { ea0[i] = *(const f32x2*)(a.res1 + o); ea1[i] = row1 ? *(const f32x2*)(a.res1 + o + W) : f32x2{0.f, 0.f}; }
+                if (a.res2) { eb0[i] = *(const f32x2*)(a.res2 + o); eb1[i] = row1 ? *(const f32x2*)(a.res2 + o + W) : f32x2{0.f, 0.f}; }
+            }
+        }
         if (!inside) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float m[16];
 #pragma unroll
             for (int p = 0; p < 16; ++p) m[p] = mine[p][i];
-            const int r = 4 * wave + i;
-            emit(32 * cot + 8 * (r >> 2) + 4 * kh + (r & 3), m);
+            if constexpr (VEC) {
+                float t0[4], t1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    t0[j] = m[j] + m[4 + j] + m[8 + j];
+                    t1[j] = m[4 + j] - m[8 + j] - m[12 + j];
+                }
+                float o00 = t0[0] + t0[1] + t0[2], o01 = t0[1] - t0[2] - t0[3];
+                float o10 = t1[0] + t1[1] + t1[2], o11 = t1[1] - t1[2] - t1[3];
+                o00 = fmaf(o00, esc[i], esh[i]); o01 = fmaf(o01, esc[i], esh[i]);
+                o10 = fmaf(o10, esc[i], esh[i]); o11 = fmaf(o11, esc[i], esh[i]);
+                if (a.relu) { o00 = fmaxf(o00, 0.f); o01 = fmaxf(o01, 0.f); o10 = fmaxf(o10, 0.f); o11 = fmaxf(o11, 0.f); }
+                f32x2 q0 = {o00, o01}, q1 = {o10, o11};
+                if (a.res1) { q0 += ea0[i]; q1 += ea1[i]; }
+                if (a.res2) { q0 += eb0[i]; q1 += eb1[i]; }
+                const long long o = eo0 + (long long)i * HW;
+                *(f32x2*)(a.y + o) = q0;
+                if (row1) *(f32x2*)(a.y + o + W) = q1;
+            } else {
+                const int r = 4 * wave + i;                // register r of the tile: channel 8 (r >> 2) + 4 kh + (r & 3)
+                emit(32 * cot + 8 * (r >> 2) + 4 * kh + (r & 3), m);
+            }
         }
     }
 }
