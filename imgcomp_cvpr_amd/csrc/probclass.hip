@@ -295,14 +295,24 @@ void pc_mfma_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
     const int rvol = a.RD * a.RH * a.RW;
     const float* __restrict__ resp = a.res ? a.res + ((size_t)n * a.Cout + co0) * rvol + (size_t)(od + 2) * a.RH * a.RW
                                                  + (size_t)((live ? oy : 0) + 2) * a.RW + (live ? ox : 0) + 2 : nullptr;
+    // all bias / residual operands first, then the arithmetic and the stores: fetched inside the loop, each of the 16
+    // channels waits out its own L2 round trip (same finding as in the Winograd epilogue)
+    float bia[16], rsd[16];
+    const float* __restrict__ biasp = a.bias + co0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int cr = (r & 3) + 8 * (r >> 2);           // channel = co0 + cr
-        const int co = co0 + cr;
-        const bool cok = co < a.Cout;
-        float x = acc[r] + (cok ? a.bias[co] : 0.f);
+        const bool cok = co0 + cr < a.Cout;
+        bia[r] = cok ? biasp[cr] : 0.f;
+        rsd[r] = (a.res && cok) ? resp[(unsigned)(cr * rvol)] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int cr = (r & 3) + 8 * (r >> 2);
+        const bool cok = co0 + cr < a.Cout;
+        float x = acc[r] + bia[r];
         if (a.relu) x = fmaxf(x, 0.f);
-        if (a.res && cok) x += resp[(unsigned)(cr * rvol)];
+        if (a.res && cok) x += rsd[r];
         val[r] = x;
         if (!FINAL && cok && live) outp[(unsigned)(cr * ovol)] = x;
     }
