@@ -767,7 +767,7 @@ __global__ __launch_bounds__(256) void pc_dec_fused_kernel(const PcFusedArgs f) 
     __shared__ float s_bias[3 * K + 16];       // b0 | b1 | b2 | b3
     __shared__ float s_centers[16];
     const PcDecArgs& a = f.d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, j = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int e = tid; e < 13 * K; e += 256) {
         const int lt = e / K;                                   // live tap lt -> (kd,kh,kw): 0..8 = kd 0; 9..11 = (1,0,*); 12 = (1,1,0)
         const int tap = lt < 9 ? lt : (lt < 12 ? 9 + (lt - 9) : 12);
