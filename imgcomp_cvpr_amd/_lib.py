@@ -37,6 +37,7 @@ PROTOTYPES = {
     'ic_pack_wino3x3_c128_batch_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'ic_wino3x3_c128_bn_act_f32': (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_void_p]),
     'ic_wino3x3_c128_set_tuning': (None, [c_int, c_int]),
+    'ic_edge_set_tuning': (None, [c_int, c_int]),
     'ic_conv3x3_c128_both_packed_floats': (c_size_t, []),
     'ic_pack_conv3x3_c128_both_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     'ic_conv3x3_c128_pick_algo': (c_int, [c_int, c_int, c_int]),

@@ -107,6 +107,10 @@ int icx_conv2d(ConvArgs a, bool transposed, hipStream_t st) {
         a.OH = ic_cdiv(a.H, a.stride); a.OW = ic_cdiv(a.W, a.stride);
         a.pt = ic_same_pad_before(a.H, a.KH, a.stride); a.pl = ic_same_pad_before(a.W, a.KW, a.stride);
         a.w_sci = a.Cout; a.w_sco = 1;                 // TF conv2d filter [kh,kw,cin,cout]
+        if (a.Cin == 3 && a.Cout == 64 && a.KH == 5 && a.KW == 5 && a.stride == 2) {   // h1 on the matrix cores
+            const int rc = icx_conv5s2_cin3_mfma(a, st);
+            if (rc != IC_ERR_UNSUPPORTED) return rc;
+        }
         return launch_direct<false>(a, st);
     }
     a.stride = 2; a.OH = 2 * a.H; a.OW = 2 * a.W;
@@ -114,7 +118,13 @@ int icx_conv2d(ConvArgs a, bool transposed, hipStream_t st) {
     a.pt = ic_same_pad_before(2 * a.H, a.KH, 2); a.pl = ic_same_pad_before(2 * a.W, a.KW, 2);
     a.w_sci = 1; a.w_sco = a.Cin;                      // TF conv2d_transpose filter [kh,kw,cout,cin]
     if (a.Cout <= 4 && a.KH == 5 && a.KW == 5) {
-        const int rc = icx_deconv5_small_cout(a, st);
+        int rc = icx_deconv5_cout3_mfma(a, st);          // h13: 64 input channels, matrix cores
+        if (rc != IC_ERR_UNSUPPORTED) return rc;
+        rc = icx_deconv5_small_cout(a, st);
+        if (rc != IC_ERR_UNSUPPORTED) return rc;
+    }
+    if (a.KH == 3 && a.KW == 3 && a.Cout == 128) {     // from_bn on the matrix cores
+        const int rc = icx_deconv3_mfma(a, st);
         if (rc != IC_ERR_UNSUPPORTED) return rc;
     }
     return launch_direct<true>(a, st);

@@ -19,6 +19,15 @@ int icx_conv2d(ConvArgs a, bool transposed, hipStream_t st);
 // transposed branch.  IC_ERR_UNSUPPORTED when the shape does not fit.
 int icx_deconv5_small_cout(const ConvArgs& a, hipStream_t st);
 
+// the same layer for Cin = 64 on the matrix cores
+int icx_deconv5_cout3_mfma(const ConvArgs& a, hipStream_t st);
+
+// 3x3 / stride-2 transposed conv Cin (32 | 64) -> 128 on the matrix cores (from_bn); same contract
+int icx_deconv3_mfma(const ConvArgs& a, hipStream_t st);
+
+// 5x5 / stride-2 conv 3 -> 64 with optional input normalisation on the matrix cores (h1); same contract
+int icx_conv5s2_cin3_mfma(const ConvArgs& a, hipStream_t st);
+
 // probclass.hip: data gradient of a masked conv3d layer on the matrix cores (train_pc.hip); workspace 0 = shape not covered
 size_t icx_pc_bwd_data_mfma_workspace(int N, int CinF, int CoutF, int OD, int OH, int OW);
 int icx_pc_bwd_data_mfma(const float* g, const float* w, float* dx_raw, int N, int CinF, int CoutF, int OD, int OH, int OW,

@@ -69,6 +69,11 @@ int ic_conv2d_bn_act_f32(const float* x, const float* w, const float* scale, con
 int ic_deconv2d_bn_act_f32(const float* x, const float* w, const float* scale, const float* shift,
                            float* y, int N, int Cin, int H, int W, int Cout, int KH, int KW, int relu,
                            const float* out_mean, const float* out_std, ic_stream_t stream);
+/* The three edge layers of the autoencoder run on the matrix cores inside the two entry points above, straight
+ * from the TF filter layouts: h1 (conv 5x5/2, 3 -> 64, :222), from_bn (deconv 3x3/2, C = 32|64 -> 128, :251) and
+ * h13 (deconv 5x5/2, 64 -> <= 4, :265).  Every other shape takes the generic direct kernels.
+ * tuning only: key 0 = tiles per work-group of the h13 kernel (0 = automatic, the default) */
+void ic_edge_set_tuning(int key, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * MFMA fast path for the 64 residual 3x3 convs (128 -> 128 channels, stride 1):

@@ -39,6 +39,8 @@ def _ref_conv(x, w, scale, shift, stride, relu, transposed=False, res=(), norm=F
 
 @pytest.mark.parametrize('name,N,Cin,H,W,Cout,K,stride,relu,norm', [
     ('h1', 1, 3, 40, 56, 64, 5, 2, 1, True),
+    ('h1_odd', 2, 3, 37, 71, 64, 5, 2, 1, True),
+    ('h1_wide', 1, 3, 18, 150, 64, 5, 2, 0, False),
     ('h2', 2, 64, 20, 28, 128, 5, 2, 1, False),
     ('to_bn', 1, 128, 10, 14, 33, 5, 2, 0, False),
     ('odd_sizes', 1, 5, 13, 9, 7, 3, 1, 1, False),
@@ -68,8 +70,13 @@ def test_conv2d_direct(cuda, name, N, Cin, H, W, Cout, K, stride, relu, norm):
 
 @pytest.mark.parametrize('name,N,Cin,H,W,Cout,K,relu,denorm', [
     ('from_bn', 1, 32, 6, 9, 128, 3, 1, False),
+    ('from_bn_tiles', 2, 32, 7, 37, 128, 3, 1, False),
+    ('from_bn_hi', 1, 64, 5, 18, 128, 3, 0, False),
     ('h12', 1, 128, 10, 12, 64, 5, 1, False),
     ('h13', 2, 64, 12, 20, 3, 5, 0, True),
+    ('h13_tiles', 1, 64, 19, 35, 3, 5, 1, False),
+    ('h13_cout4', 1, 64, 8, 16, 4, 5, 0, False),
+    ('h13_cin32', 1, 32, 8, 16, 3, 5, 0, True),
     ('odd', 1, 3, 5, 7, 5, 5, 0, False),
 ])
 def test_deconv2d(cuda, name, N, Cin, H, W, Cout, K, relu, denorm):
