@@ -273,16 +273,8 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
     const bool row1 = oy + 1 < H, col1 = ox + 1 < W;
     const bool vec = col1 && ((W & 1) == 0);
     const long long obase = (long long)n * WN_C * HW + (long long)oy * W + ox;
-    // one output channel of this lane's tile from its 16 position sums
-    auto emit = [&](int co, const float (&m)[16]) __attribute__((always_inline)) {
-        float t0[4], t1[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            t0[j] = m[j] + m[4 + j] + m[8 + j];
-            t1[j] = m[4 + j] - m[8 + j] - m[12 + j];
-        }
-        float o00 = t0[0] + t0[1] + t0[2], o01 = t0[1] - t0[2] - t0[3];
-        float o10 = t1[0] + t1[1] + t1[2], o11 = t1[1] - t1[2] - t1[3];
+    // BN fold, activation, residuals and store of one output channel of this lane's tile (any width)
+    auto finish = [&](int co, float o00, float o01, float o10, float o11) __attribute__((always_inline)) {
         const float sc = a.scale[co], sh = a.shift[co];
         o00 = fmaf(o00, sc, sh); o01 = fmaf(o01, sc, sh); o10 = fmaf(o10, sc, sh); o11 = fmaf(o11, sc, sh);
         if (a.relu) { o00 = fmaxf(o00, 0.f); o01 = fmaxf(o01, 0.f); o10 = fmaxf(o10, 0.f); o11 = fmaxf(o11, 0.f); }
@@ -316,6 +308,16 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
             if (col1) a.y[o + 1] = o01;
             if (row1) { a.y[o + W] = o10; if (col1) a.y[o + W + 1] = o11; }
         }
+    };
+    // one output channel of this lane's tile from its 16 position sums
+    auto emit = [&](int co, const float (&m)[16]) __attribute__((always_inline)) {
+        float t0[4], t1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t0[j] = m[j] + m[4 + j] + m[8 + j];
+            t1[j] = m[4 + j] - m[8 + j] - m[12 + j];
+        }
+        finish(co, t0[0] + t0[1] + t0[2], t0[1] - t0[2] - t0[3], t1[0] + t1[1] + t1[2], t1[1] - t1[2] - t1[3]);
     };
     if (KS == 1) {
         if (!inside) return;
@@ -384,32 +386,25 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
         }
 #endif
     } else {
-        // cross-wave sum: wave w finishes output registers 4w..4w+3 of every position.  Eight phases of two positions: every
-        // wave stores its 2 x 16 partial values (compile-time register indices, the stored accumulators are dead afterwards)
-        // and reads back its own quarter from all four waves (run-time LDS address, compile-time destination), 32 KB of
-        // LDS.  Sum order (w0 + w1) + (w2 + w3).
-        __shared__ f32x4 red[4 * 2 * 4 * 64];                 // [wave][pos in phase][register quad][lane], 16-byte accesses
-        f32x4 mine[16];
+        // cross-wave sum AFTER the output transform: At M A is linear, so every wave first reduces its 16 partial position
+        // sums to the 4 outputs of each (channel, tile) and the waves exchange a quarter of the accumulator volume -- one
+        // phase and one barrier through 64 KB of LDS instead of eight phases in the Winograd domain.  Wave w then finishes
+        // output registers 4w..4w+3 (channels 32 cot + 8w + 4kh + i); sum order (w0 + w1) + (w2 + w3).
+        __shared__ f32x4 red[4 * 4 * 4 * 64];                 // [source wave][output][register quad][lane]
+        f32x16 out[4];
 #pragma unroll
-        for (int ph = 0; ph < 8; ++ph) {
+        for (int r = 0; r < 16; ++r) {
+            float t0[4], t1[4];
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const f32x16 v = acc[2 * ph + pp];
-                    const f32x4 q = {v[4 * r4], v[4 * r4 + 1], v[4 * r4 + 2], v[4 * r4 + 3]};
-                    red[((wave * 2 + pp) * 4 + r4) * 64 + lane] = q;
-                }
-            __syncthreads();
-#pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {
-                const f32x4* q = red + (pp * 4 + wave) * 64 + lane;
-                mine[2 * ph + pp] = (q[0] + q[2 * 4 * 64]) + (q[2 * 2 * 4 * 64] + q[3 * 2 * 4 * 64]);
+            for (int j = 0; j < 4; ++j) {
+                const float m0 = acc[j][r], m1 = acc[4 + j][r], m2 = acc[8 + j][r], m3 = acc[12 + j][r];
+                t0[j] = m0 + m1 + m2;
+                t1[j] = m1 - m2 - m3;
             }
-            __syncthreads();
+            out[0][r] = t0[0] + t0[1] + t0[2]; out[1][r] = t0[1] - t0[2] - t0[3];
+            out[2][r] = t1[0] + t1[1] + t1[2]; out[3][r] = t1[1] - t1[2] - t1[3];
         }
-        // all epilogue operands of this wave's four channels in one batch (requested any earlier they would sit on top of
-        // the 256 live accumulators and spill)
+        // epilogue operands of this wave's four channels, requested before the exchange (the accumulators are dead now)
         float esc[4], esh[4];
         f32x2 ea0[4], ea1[4], eb0[4], eb1[4];
         const long long eo0 = obase + (long long)(32 * cot + 8 * wave + 4 * kh) * HW;     // channel = 32 cot + 8 wave + 4 kh + i
@@ -423,21 +418,25 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
                 if (a.res2) { eb0[i] = *(const f32x2*)(a.res2 + o); eb1[i] = row1 ? *(const f32x2*)(a.res2 + o + W) : f32x2{0.f, 0.f}; }
             }
         }
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 q = {out[o][4 * r4], out[o][4 * r4 + 1], out[o][4 * r4 + 2], out[o][4 * r4 + 3]};
+                red[((wave * 4 + o) * 4 + r4) * 64 + lane] = q;
+            }
+        __syncthreads();
+        f32x4 mine[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const f32x4* q = red + (o * 4 + wave) * 64 + lane;
+            mine[o] = (q[0] + q[16 * 64]) + (q[2 * 16 * 64] + q[3 * 16 * 64]);
+        }
         if (!inside) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float m[16];
-#pragma unroll
-            for (int p = 0; p < 16; ++p) m[p] = mine[p][i];
+            float o00 = mine[0][i], o01 = mine[1][i], o10 = mine[2][i], o11 = mine[3][i];
             if constexpr (VEC) {
-                float t0[4], t1[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    t0[j] = m[j] + m[4 + j] + m[8 + j];
-                    t1[j] = m[4 + j] - m[8 + j] - m[12 + j];
-                }
-                float o00 = t0[0] + t0[1] + t0[2], o01 = t0[1] - t0[2] - t0[3];
-                float o10 = t1[0] + t1[1] + t1[2], o11 = t1[1] - t1[2] - t1[3];
                 o00 = fmaf(o00, esc[i], esh[i]); o01 = fmaf(o01, esc[i], esh[i]);
                 o10 = fmaf(o10, esc[i], esh[i]); o11 = fmaf(o11, esc[i], esh[i]);
                 if (a.relu) { o00 = fmaxf(o00, 0.f); o01 = fmaxf(o01, 0.f); o10 = fmaxf(o10, 0.f); o11 = fmaxf(o11, 0.f); }
@@ -449,7 +448,7 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
                 if (row1) *(f32x2*)(a.y + o + W) = q1;
             } else {
                 const int r = 4 * wave + i;                // register r of the tile: channel 8 (r >> 2) + 4 kh + (r & 3)
-                emit(32 * cot + 8 * (r >> 2) + 4 * kh + (r & 3), m);
+                finish(32 * cot + 8 * (r >> 2) + 4 * kh + (r & 3), o00, o01, o10, o11);
             }
         }
     }
@@ -525,12 +524,14 @@ extern "C" int ic_pack_wino3x3_c128_f32(const float* w_tf, float* w_packed, int 
 
 static unsigned long long* g_wino_prof = nullptr;
 static int g_wino_ksplit = -1;      // -1 automatic, 0 never, 1 always (tuning key 2)
+static int g_wino_ratio = 290;      // cost of a whole-K round in K-split rounds, x100 (tuning key 3)
 // tuning only: key 0 = device buffer (as two 32-bit halves: key 0 low, key 1 high) for WN_PROF builds
 extern "C" void ic_wino3x3_c128_set_tuning(int key, int value) {
     static unsigned long long bits = 0;
     if (key == 0) bits = (bits & 0xffffffff00000000ull) | (unsigned)value;
     if (key == 1) { bits = (bits & 0xffffffffull) | ((unsigned long long)(unsigned)value << 32); g_wino_prof = (unsigned long long*)bits; }
     if (key == 2) g_wino_ksplit = value;
+    if (key == 3) g_wino_ratio = value;
 }
 
 extern "C" int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
@@ -547,7 +548,13 @@ extern "C" int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed,
     // K-split when whole-K waves (4 per group) would leave most of the 1024 SIMDs idle
     // measured cross-over: up to 128 tile groups (<= 2 rounds of 256 K-split work-groups at ~18 us) the K-split form wins
     // (37 us vs 43-50 us); at Kodak's 192 groups the micro-benchmark is a tie and the whole step is 6 % slower with K-split
-    const bool ksplit = g_wino_ksplit < 0 ? groups <= 128 : g_wino_ksplit != 0;
+    // One work-group per CU at a time (512 registers per lane), so a launch runs in rounds of 256 work-groups, and K-split
+    // issues four times as many.  A full round of whole-K work-groups costs ~2.9 K-split rounds in a sustained run (Kodak
+    // map, 192 groups, inside bench.py: one 75 % full whole-K round 41.5 us, three full K-split rounds 43.1 us -- with
+    // every SIMD busy the clock drops, a short burst in tools/bench_wino.py shows 50 against 46 us); K-split wins where the
+    // whole-K launch would leave most of a round empty (<= 128 groups; 272 groups: 72 against 88 us).
+    const long long rounds_w = (groups + 255) / 256, rounds_k = (4 * groups + 255) / 256;
+    const bool ksplit = g_wino_ksplit < 0 ? 100 * rounds_k < g_wino_ratio * rounds_w : g_wino_ksplit != 0;
     if (ksplit) {
         const dim3 grid((unsigned)(groups * 4));
         if ((W & 1) == 0) hipLaunchKernelGGL(wino3x3_c128_ksplit_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);

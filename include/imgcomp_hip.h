@@ -112,8 +112,10 @@ int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed, const floa
                                const float* shift, const float* res1, const float* res2, float* y,
                                int N, int H, int W, int relu, ic_stream_t stream);
 /* tuning / tests: key 2 = work decomposition (-1 automatic, 0 whole-K waves: 4 output-channel tiles per work-group,
- * 1 K-split: one channel tile per work-group, 4 quarters of the input channels summed through LDS -- the form small
- * maps run); keys 0, 1: profiling builds. */
+ * 1 K-split: one channel tile per work-group, 4 quarters of the input channels summed through LDS after the output
+ * transform -- the form every map runs whose whole-K launch would leave a round of 256 work-groups partly empty);
+ * key 3 = cost of a whole-K round in K-split rounds x 100 (default 290) for the automatic choice; keys 0, 1: profiling
+ * builds. */
 void ic_wino3x3_c128_set_tuning(int key, int value);
 
 /* Both forms behind ONE packed filter [direct fragments | Winograd fragments]; this is what ic_ae_encode_f32 /
