@@ -74,8 +74,13 @@ def main():
     pad_value = float(wts['autoencoder/encoder/centers'][0])
 
     # The context model and the decoder both hang off the encoder output and do not depend on each other (val.py:85-89):
-    # the bitcost goes on a second HIP stream and fills the CUs the decoder's one-wave-per-SIMD convs leave idle.
-    side = torch.cuda.Stream(device=dev)
+    # the bitcost goes on a second HIP stream restricted to the CUs the decoder's one-work-group-per-CU 3x3 launches
+    # leave idle (imgcomp_cvpr_amd/streams.py; a Kodak map: 64 of 256 CUs), the same arrangement val.py runs.
+    from imgcomp_cvpr_amd import streams
+    branch = streams.BranchStreams(dev)
+    side = branch.context_model_stream(N, H, Wd)
+    torch.cuda.synchronize(dev)
+    torch.cuda.set_stream(branch.main)      # CU-range streams are blocking with respect to the legacy default stream
 
     def step():
         cur = torch.cuda.current_stream(dev)
@@ -109,7 +114,7 @@ def main():
     value = pixels_per_step * a.steps / elapsed / 1e6
 
     # ---- stage split and the dominant kernel, HIP events on the launch stream (rank 0) ----
-    extra = {}
+    extra = {'context_model_stream_cus': branch.idle_cus(N, H, Wd) if side is not branch._plain else 0}
     roofline = None
     if rank == 0:
         st = _lib.current_stream(dev)
@@ -132,8 +137,8 @@ def main():
         ms_enc = timed(lambda: ae.encode(x, False), 5)
         ms_pc = timed(lambda: pc.bitcost(enc.qbar, enc.symbols, False, pad_value=pad_value), 5)
         ms_dec = timed(lambda: ae.decode(enc.qhard, False), 5)
-        extra = {'ms_encode': round(ms_enc, 4), 'ms_pc_bitcost': round(ms_pc, 4), 'ms_decode': round(ms_dec, 4),
-                 'bpp_synthetic': round(float(bpp), 5)}
+        extra.update({'ms_encode': round(ms_enc, 4), 'ms_pc_bitcost': round(ms_pc, 4), 'ms_decode': round(ms_dec, 4),
+                      'bpp_synthetic': round(float(bpp), 5)})
         # dominant kernel: the shape the residual stacks run at, (N,128,H/4,W/4)
         h4, w4 = H // 4, Wd // 4
         xin = torch.randn((N, 128, h4, w4), device=dev)

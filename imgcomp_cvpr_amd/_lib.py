@@ -38,6 +38,7 @@ PROTOTYPES = {
     'ic_wino3x3_c128_bn_act_f32': (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_void_p]),
     'ic_wino3x3_c128_set_tuning': (None, [c_int, c_int]),
     'ic_edge_set_tuning': (None, [c_int, c_int]),
+    'ic_wino3x3_c128_workgroups': (c_longlong, [c_int, c_int, c_int]),
     'ic_conv3x3_c128_both_packed_floats': (c_size_t, []),
     'ic_pack_conv3x3_c128_both_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     'ic_conv3x3_c128_pick_algo': (c_int, [c_int, c_int, c_int]),
@@ -88,6 +89,8 @@ PROTOTYPES = {
                         [c_void_p, c_size_t, c_void_p]),
     'ic_channel_sum_workspace_bytes': (c_size_t, [c_int]),
     'ic_channel_sum_f32': (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p, c_void_p]),
+    'ic_stream_create_cu_range': (c_int, [c_int, c_int, POINTER(c_void_p)]),
+    'ic_stream_destroy': (c_int, [c_void_p]),
     'ic_event_create': (c_int, [POINTER(c_void_p)]),
     'ic_event_destroy': (c_int, [c_void_p]),
     'ic_event_record': (c_int, [c_void_p, c_void_p]),

@@ -534,6 +534,18 @@ extern "C" void ic_wino3x3_c128_set_tuning(int key, int value) {
     if (key == 3) g_wino_ratio = value;
 }
 
+static bool wino_use_ksplit(long long groups) {
+    const long long rounds_w = (groups + 255) / 256, rounds_k = (4 * groups + 255) / 256;
+    return g_wino_ksplit < 0 ? 100 * rounds_k < g_wino_ratio * rounds_w : g_wino_ksplit != 0;
+}
+
+// work-groups (= CUs kept busy, one each) of the launch ic_wino3x3_c128_bn_act_f32 would make for this shape
+extern "C" long long ic_wino3x3_c128_workgroups(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    const long long groups = (long long)N * ic_cdiv(H, 4) * ic_cdiv(W, 32);
+    return wino_use_ksplit(groups) ? 4 * groups : groups;
+}
+
 extern "C" int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
                                           const float* res1, const float* res2, float* y, int N, int H, int W, int relu,
                                           ic_stream_t stream) {
@@ -553,8 +565,7 @@ extern "C" int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed,
     // map, 192 groups, inside bench.py: one 75 % full whole-K round 41.5 us, three full K-split rounds 43.1 us -- with
     // every SIMD busy the clock drops, a short burst in tools/bench_wino.py shows 50 against 46 us); K-split wins where the
     // whole-K launch would leave most of a round empty (<= 128 groups; 272 groups: 72 against 88 us).
-    const long long rounds_w = (groups + 255) / 256, rounds_k = (4 * groups + 255) / 256;
-    const bool ksplit = g_wino_ksplit < 0 ? 100 * rounds_k < g_wino_ratio * rounds_w : g_wino_ksplit != 0;
+    const bool ksplit = wino_use_ksplit(groups);
     if (ksplit) {
         const dim3 grid((unsigned)(groups * 4));
         if ((W & 1) == 0) hipLaunchKernelGGL(wino3x3_c128_ksplit_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);

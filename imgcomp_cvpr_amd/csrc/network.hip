@@ -183,6 +183,33 @@ extern "C" uint32_t ic_crc32c(const void* data, size_t n, uint32_t crc) {
     return c ^ 0xFFFFFFFFu;
 }
 
+// ---- branch streams --------------------------------------------------------------------------------------------------
+// The context model and the decoder both hang off the encoder output (val.py:85-89).  The decoder's 3x3 launches keep
+// one 512-register work-group per CU and, for a Kodak-sized map, occupy 192 of the 256 CUs; a context-model work-group
+// that lands on one of those CUs takes registers the next 3x3 work-group needs, and that one then waits for the whole
+// SIMD.  A stream restricted to the CUs the decoder leaves idle removes the interference: the two branches overlap
+// completely (tools/bench_cumask.py: 3.15 -> 2.98 ms per Kodak image).  Mask bit i is CU (i / 8) of XCD (i % 8)
+// (tools/cumask_probe.hip), so a run of 8 m consecutive bits takes m CUs from every XCD.
+// The stream is created BLOCKING (the only flavour the runtime offers with a mask): it orders itself against the legacy
+// default stream, so the other branch must run on a non-blocking stream for the two to overlap.
+extern "C" int ic_stream_create_cu_range(int first_cu, int n_cus, ic_stream_t* stream) {
+    IC_CHECK_ARG(stream && first_cu >= 0 && n_cus > 0);
+    int dev = 0, ncu = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return (int)e;
+    if (first_cu + n_cus > ncu || ncu > 1024) return IC_ERR_UNSUPPORTED;
+    uint32_t words[32] = {0};
+    for (int b = first_cu; b < first_cu + n_cus; ++b) words[b / 32] |= 1u << (b % 32);
+    hipStream_t s;
+    e = hipExtStreamCreateWithCUMask(&s, (uint32_t)ic_cdiv(ncu, 32), words);
+    if (e != hipSuccess) return (int)e;
+    *stream = (ic_stream_t)s;
+    return IC_OK;
+}
+extern "C" int ic_stream_destroy(ic_stream_t stream) { return stream ? (int)hipStreamDestroy((hipStream_t)stream) : IC_ERR_ARG; }
+
 extern "C" int ic_event_create(void** ev) {
     IC_CHECK_ARG(ev);
     hipEvent_t e;

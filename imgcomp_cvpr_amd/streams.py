@@ -1,0 +1,62 @@
+"""HIP streams for the two branches that hang off the encoder output.
+
+The reference evaluates bitcost and reconstruction in one session.run (val.py:85-89); they share nothing but the encoder
+output.  On the MI355X the decoder is a chain of 3x3 launches that keep ONE 512-register work-group per CU and -- for a
+Kodak-sized feature map -- occupy 192 of the 256 CUs.  A context-model work-group that lands on one of those CUs takes
+registers the next 3x3 work-group needs, which then waits for the whole SIMD: a plain second stream buys ~1 %.  A stream
+restricted to the CUs the decoder leaves idle (ic_stream_create_cu_range) removes the interference and hides the
+context model completely (tools/bench_cumask.py: 3.15 -> 2.98 ms per Kodak image).
+
+    bs = BranchStreams(device)
+    with torch.cuda.stream(bs.main):                 # CU-range streams are blocking w.r.t. the legacy default stream
+        enc = ae.encode(x)
+        side = bs.context_model_stream(N, H, W)
+        side.wait_stream(bs.main)
+        with torch.cuda.stream(side): ... pc.bitcost(...)
+        x_out = ae.decode(enc.qhard)
+        bs.main.wait_stream(side)
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class BranchStreams(object):
+    MIN_CUS = 32          # fewer than this and the context model becomes the critical path of a Kodak-sized image
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.main = torch.cuda.Stream(device=self.device)
+        self._plain = torch.cuda.Stream(device=self.device)
+        self._ranged = {}
+        self._handles = []
+        self.n_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+
+    def idle_cus(self, N, H, W):
+        """CUs the decoder's 3x3 launches leave idle for an (N, 3, H, W) image, rounded down to whole CUs per XCD."""
+        wgs = int(_lib.lib.ic_wino3x3_c128_workgroups(N, H // 4, W // 4))
+        if wgs <= 0 or wgs >= self.n_cus:
+            return 0
+        return min((self.n_cus - wgs) // 8 * 8, self.n_cus // 2)
+
+    def context_model_stream(self, N, H, W):
+        n = self.idle_cus(N, H, W)
+        if n < self.MIN_CUS:
+            return self._plain           # the decoder fills the chip in rounds: nothing to partition
+        if n not in self._ranged:
+            h = ctypes.c_void_p()
+            with torch.cuda.device(self.device):
+                rc = _lib.lib.ic_stream_create_cu_range(self.n_cus - n, n, ctypes.byref(h))
+            if rc != 0:                  # runtime without CU masks: fall back to the plain side stream
+                self._ranged[n] = self._plain
+            else:
+                self._handles.append(h)
+                self._ranged[n] = torch.cuda.ExternalStream(h.value, device=self.device)
+        return self._ranged[n]
+
+    def close(self):
+        for h in self._handles:
+            _lib.lib.ic_stream_destroy(h)
+        self._handles, self._ranged = [], {}

@@ -31,7 +31,7 @@ from os import path
 import numpy as np
 import torch
 
-from . import autoencoder, bits, bpp_helpers, config_parser, metrics, probclass, sharding
+from . import autoencoder, bits, bpp_helpers, config_parser, metrics, probclass, sharding, streams
 from . import weights as _weights
 
 OutputFlags = namedtuple('OutputFlags', ['save_ours', 'ckpt_step', 'real_bpp'])
@@ -169,21 +169,31 @@ class Fetcher(object):
             weights, self.device)
         self.pc_config = pc_config
         self._bpp_fetcher = None
-        self._side = torch.cuda.Stream(device=self.device)
+        self._streams = streams.BranchStreams(self.device)
 
     def __call__(self, img_chw_uint8, want_symbols=False, want_image=False):
         x_uint8 = torch.as_tensor(img_chw_uint8)[None]
+        outer, main = torch.cuda.current_stream(self.device), self._streams.main
+        main.wait_stream(outer)
+        with torch.cuda.stream(main):
+            otp = self._measure(x_uint8, want_symbols, want_image)
+        outer.wait_stream(main)
+        return otp
+
+    def _measure(self, x_uint8, want_symbols, want_image):
         x_uint8_dev = x_uint8.to(self.device)
         x = x_uint8_dev.float()
         enc = self.ae.encode(x, is_training=False)
-        # decoder and context model are independent consumers of the encoder output: run them on two streams
+        # decoder and context model are independent consumers of the encoder output: two streams, the context model on
+        # the CUs the decoder's 3x3 launches leave idle (streams.py)
         cur = torch.cuda.current_stream(self.device)
-        self._side.wait_stream(cur)
-        with torch.cuda.stream(self._side):
+        side = self._streams.context_model_stream(x.shape[0], x.shape[2], x.shape[3])
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
             bc = self.pc.bitcost(enc.qbar, enc.symbols, is_training=False, pad_value=self.pc.auto_pad_value(self.ae))
             bpp = bits.bitcost_to_bpp(bc, x)
         x_out = self.ae.decode(enc.qhard, is_training=False)
-        cur.wait_stream(self._side)
+        cur.wait_stream(side)
         x_out_uint8_dev = x_out.to(torch.uint8)                    # tf.cast truncates (val.py:91)
         if self.host_metrics:
             x_out_uint8 = x_out_uint8_dev.cpu().numpy()

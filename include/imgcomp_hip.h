@@ -117,6 +117,9 @@ int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed, const floa
  * key 3 = cost of a whole-K round in K-split rounds x 100 (default 290) for the automatic choice; keys 0, 1: profiling
  * builds. */
 void ic_wino3x3_c128_set_tuning(int key, int value);
+/* work-groups of the launch above for this shape; each occupies one whole CU (what a caller sizing a CU-range stream
+ * for an independent branch needs to know, see ic_stream_create_cu_range) */
+long long ic_wino3x3_c128_workgroups(int N, int H, int W);
 
 /* Both forms behind ONE packed filter [direct fragments | Winograd fragments]; this is what ic_ae_encode_f32 /
  * ic_ae_decode_f32 expect in their tables for the 3x3 layers and what the training step uses (backward != 0: adjoint).
@@ -302,6 +305,15 @@ int ic_channel_sum_f32(const float* x, float* out, int N, int C, int M, void* wo
 /* The context-model backward reads the three feature volumes ic_pc_bitcost_f32 left in its workspace
  * (layout: conv0 out (N,k,C+3,h+6,w+6) | res1/conv1 out (N,k,C+2,h+4,w+4) | res1 out (N,k,C+1,h+2,w+2) | packed
  * filters): keep that workspace untouched between the forward call and the ic_pc_* backward calls. */
+
+/* Branch streams.  The context model and the decoder are independent consumers of the encoder output (val.py:85-89);
+ * ic_stream_create_cu_range makes a stream whose kernels only run on CU mask bits [first_cu, first_cu + n_cus) -- bit i
+ * is CU i/8 of XCD i%8 on the MI355X, so a multiple of 8 takes the same number of CUs from every XCD.  Giving the
+ * context model the CUs the decoder's one-work-group-per-CU 3x3 launches leave idle (a Kodak map: 64 of 256) lets the
+ * branches overlap fully.  The stream is blocking with respect to the legacy default stream: run the other branch on a
+ * non-blocking stream.  IC_ERR_UNSUPPORTED if the range exceeds the device. */
+int ic_stream_create_cu_range(int first_cu, int n_cus, ic_stream_t* stream);
+int ic_stream_destroy(ic_stream_t stream);
 
 /* device timing helper for bench.py: wall time between two points on `stream` measured with
  * hipEvents created on that stream's device (torch.cuda.Event only sees torch's own streams). */

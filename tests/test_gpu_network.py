@@ -321,3 +321,46 @@ def test_against_frozen_oracle_fixture(cuda, configs, syn_weights, nets):
         assert_close(bc, torch.as_tensor(g['bitcost']), 'bit cost vs fixture')
         assert abs(float(bits.bitcost_to_bpp(bc, xd)) - float(g['bpp'])) < 1e-4
         assert_close(ae.decode(enc.qhard, False), torch.as_tensor(g['x_out']), 'x_out vs fixture')
+
+
+def test_branch_streams_cu_range(cuda, configs, syn_weights, nets):
+    """The context model on its own CUs next to the decoder (streams.py) gives the same numbers as the serial schedule; the
+    CU-range stream really is a separate, usable stream; shapes that fill the chip fall back to the plain side stream."""
+    import ctypes
+    from imgcomp_cvpr_amd import bits, streams, weights as W, _lib
+    ae, pc = nets
+    bs = streams.BranchStreams(cuda)
+    try:
+        assert bs.n_cus >= 64
+        # Kodak: 192 whole-K work-groups -> a quarter of the chip is idle; 4K: the decoder fills every round
+        assert bs.idle_cus(1, 512, 768) == (bs.n_cus - 192) // 8 * 8
+        assert bs.idle_cus(1, 2160, 3840) == 0
+        assert bs.context_model_stream(1, 2160, 3840) is bs._plain
+        side = bs.context_model_stream(1, 512, 768)
+        assert side is not bs._plain and side.cuda_stream != bs.main.cuda_stream
+        assert bs.context_model_stream(1, 512, 768) is side                    # cached
+        x = dev(W.synthetic_image((1, 3, 128, 192), 'natural', seed=5), cuda)
+        pad = pc.auto_pad_value(ae)
+        enc = ae.encode(x, False)
+        ref_out = ae.decode(enc.qhard, False)
+        ref_bpp = float(bits.bitcost_to_bpp(pc.bitcost(enc.qbar, enc.symbols, False, pad_value=pad), x))
+        torch.cuda.synchronize()
+        outer = torch.cuda.current_stream(cuda)
+        bs.main.wait_stream(outer)
+        with torch.cuda.stream(bs.main):
+            for _ in range(3):
+                enc = ae.encode(x, False)
+                side.wait_stream(bs.main)
+                with torch.cuda.stream(side):
+                    bpp = bits.bitcost_to_bpp(pc.bitcost(enc.qbar, enc.symbols, False, pad_value=pad), x)
+                out = ae.decode(enc.qhard, False)
+                bs.main.wait_stream(side)
+        outer.wait_stream(bs.main)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref_out)
+        assert float(bpp) == ref_bpp
+        # out-of-range requests are refused, not clamped
+        h = ctypes.c_void_p()
+        assert _lib.lib.ic_stream_create_cu_range(bs.n_cus - 8, 16, ctypes.byref(h)) != 0
+    finally:
+        bs.close()
