@@ -108,7 +108,7 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
 // KS = 4: small maps that cannot fill the chip with 4 x groups waves -- a work-group is ONE channel tile (cot) of a
 //         group, its four waves take a quarter of the input channels each (16 k-steps) and the partial accumulators are
 //         summed through LDS in the fixed order (w0 + w1) + (w2 + w3); wave w then finishes output registers 4w..4w+3.
-template <bool VEC, int KS>
+template <bool VEC, int KS, bool SHARE = false>
 __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx, int cot_in) {
 #ifdef WN_PROF
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
@@ -182,15 +182,18 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
             fl[s][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(fr, fo + q * 1024u, so, 0));
     };
 
+    if constexpr (!SHARE) {
     // (pinned in ring order: the wait counts at the loop head are the merge of this entry state and the back edge; a
-    // prologue load scheduled late would make every iteration wait for almost everything in flight)
-#pragma unroll
-    for (int s = 0; s < WN_STAGES - 1; ++s) {
-        load_patch(s, ks0 + s);
-        __builtin_amdgcn_sched_barrier(0);
-        load_filter(s, ks0 + s);
-        __builtin_amdgcn_sched_barrier(0);
-    }
+        // prologue load scheduled late would make every iteration wait for almost everything in flight)
+    #pragma unroll
+        for (int s = 0; s < WN_STAGES - 1; ++s) {
+            load_patch(s, ks0 + s);
+            __builtin_amdgcn_sched_barrier(0);
+            load_filter(s, ks0 + s);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    
+}
 
     // Bt d B of one lane's patch -> the 16 B operands of a k-step.  Written on (x0, x1) / (left, right) pairs so that
     // it maps onto packed fp32 adds: every vector instruction costs matrix-pipe time when there is one wave per SIMD.
@@ -222,10 +225,95 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
         }
     };
 
+#ifdef WN_PROF
+    unsigned long long pd1 = 0, pd2 = 0, pd3 = 0, pt0 = 0;
+#endif
+    if constexpr (SHARE) {
+        // The four waves of a whole-K work-group multiply the SAME transformed input (B operand) with four different
+        // channel tiles of the filter.  Instead of every wave loading and transforming every k-step, wave w produces
+        // k-steps 4j + w and the B operands travel through a ring in LDS: a quarter of the patch loads and transform
+        // instructions per wave -- vector instructions that, with one wave per SIMD, come straight out of the matrix
+        // pipe's issue time.  One iteration = 4 k-steps: ring half (j & 1) is read while half ((j+1) & 1) is written,
+        // one barrier per iteration.
+        static_assert(KS == 1, "shared input transform is the whole-K form");
+        __shared__ f32x4 ring[2 * 4 * 4 * 64];                // [half][k-step of the iteration][position quad][lane]
+        auto put = [&](int half, const float (&vv)[16]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 t = {vv[4 * q], vv[4 * q + 1], vv[4 * q + 2], vv[4 * q + 3]};
+                ring[((half * 4 + wave) * 4 + q) * 64 + lane] = t;
+            }
+        };
+        auto get = [&](int half, int st, f32x4 (&b)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b[q] = ring[((half * 4 + st) * 4 + q) * 64 + lane];
+        };
+        load_patch(0, wave);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int st = 0; st < WN_STAGES - 1; ++st) {
+            load_filter(st, st);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        load_patch(1, 4 + wave);
+        __builtin_amdgcn_sched_barrier(0);
+        float vt[16];
+        transform(0, vt);
+        put(0, vt);
+        __syncthreads();
+        f32x4 bq[2][4];
+        get(0, 0, bq[0]);
+#ifdef WN_PROF
+        pt0 = __builtin_amdgcn_s_memtime();
+#endif
+        for (int jj = 0; jj < 16; jj += 2) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {                     // iteration j = jj + u reads ring half u
+                const int j = jj + u;
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int ks = 4 * j + st;
+                    load_filter((st + WN_STAGES - 1) % WN_STAGES, ks + WN_STAGES - 1 < 64 ? ks + WN_STAGES - 1 : 63);
+                    if (st == 0) {
+                        // own k-step of iteration j + 2 into the patch slot transformed one iteration ago; own k-step of
+                        // iteration j + 1 (loaded one iteration ago) through the transform.  Past the end both repeat the
+                        // last own k-step: same instruction stream, the extra ring entries are never read.
+                        const int kp = 4 * (j + 2) + wave < 64 ? 4 * (j + 2) + wave : 60 + wave;
+                        load_patch(u, kp);
+                        transform(u ^ 1, vt);
+                    }
+                    if (st == 1) put(u ^ 1, vt);
+                    if (st < 3) get(u, st + 1, bq[(st + 1) & 1]);
+                    else get(u ^ 1, 0, bq[0]);
+#pragma unroll
+                    for (int p = 0; p < 16; ++p)
+                        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fl[st][p >> 2][p & 3], bq[st & 1][p >> 2][p & 3], acc[p], 0, 0, 0);
+#pragma unroll
+                    for (int p = 0; p < 16; ++p) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             // 1 MFMA
+                        if (p < (st == 0 ? 12 : 4)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+                        if (p >= 4 && p < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // 1 LDS read
+                        if (st == 1 && p >= 8 && p < 12) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 LDS write
+                        if (st == 0) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                // the transform
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (st == 2) {
+                        // every wave has written its k-step of the next half and read all of this one
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+#ifdef WN_PROF
+        pd1 = __builtin_amdgcn_s_memtime() - pt0; pt0 += pd1;
+#endif
+    } else {
     float v[2][16];
     transform(0, v[0]);
 #ifdef WN_PROF
-    unsigned long long pd1 = 0, pd2 = 0, pd3 = 0, pt0 = __builtin_amdgcn_s_memtime();
+    pt0 = __builtin_amdgcn_s_memtime();
 #endif
     for (int k0 = 0; k0 < NKS; k0 += WN_STAGES) {
 #pragma unroll
@@ -261,6 +349,7 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
             pd1 += q3 - pt0; pt0 = q3;
 #endif
         }
+    }
     }
 #ifdef WN_PROF
     // stamps: entry -> loop start (prologue), loop, loop end -> last store issued (epilogue); written at the very end
@@ -320,29 +409,36 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
         finish(co, t0[0] + t0[1] + t0[2], t0[1] - t0[2] - t0[3], t1[0] + t1[1] + t1[2], t1[1] - t1[2] - t1[3]);
     };
     if (KS == 1) {
-        if (!inside) return;
+        if (!VEC && !inside) return;
         if constexpr (VEC) {                               // even W: every inside tile has both columns, pairs are aligned
+            // Branch-free: residuals and the output go through buffer descriptors.  An absent residual is a descriptor
+            // of zero records (every load returns 0), a tile row below the map or a tile outside it an out-of-range lane
+            // offset (loads return 0, stores are dropped): no per-channel control flow for the register allocator to
+            // fight, border work-groups run the interior instruction stream.
             // The operands of channel r + 5 (BN scale/shift, residual rows) are requested while channel r is finished:
             // fetched inside each iteration, every one of the 16 waited out its own L2 round trip (10.6k of a wave's 93k
             // clocks); all 16 at once would need 160 registers next to the 256 accumulators and spill into the main loop.
+            const int img_bytes = WN_C * HW * 4;
+            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (size_t)n * WN_C * HW), 0, img_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r1r = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(a.res1 ? a.res1 + (size_t)n * WN_C * HW : a.x), 0, a.res1 ? img_bytes : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r2r = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(a.res2 ? a.res2 + (size_t)n * WN_C * HW : a.x), 0, a.res2 ? img_bytes : 0, 0x00020000);
+            const unsigned lo0 = inside ? (unsigned)((4 * kh * HW + oy * W + ox) * 4) : WN_OOB;
+            const unsigned lo1 = inside && row1 ? lo0 + 4u * W : WN_OOB;
             constexpr int EPD = 6;
             float sc[EPD], sh[EPD];
             f32x2 ra0[EPD], ra1[EPD], rb0[EPD], rb1[EPD];
             const float* __restrict__ scp = a.scale + 32 * cot + 4 * kh;
             const float* __restrict__ shp = a.shift + 32 * cot + 4 * kh;
-            const long long o0 = obase + (long long)(32 * cot + 4 * kh) * HW;
             auto fetch = [&](int r) __attribute__((always_inline)) {
                 const int cr = (r & 3) + 8 * (r >> 2), sl = r % EPD;              // channel = 32 cot + 4 kh + cr
                 sc[sl] = scp[cr]; sh[sl] = shp[cr];
-                const long long o = o0 + (long long)cr * HW;
-                if (a.res1) {
-                    ra0[sl] = *(const f32x2*)(a.res1 + o);
-                    ra1[sl] = row1 ? *(const f32x2*)(a.res1 + o + W) : f32x2{0.f, 0.f};
-                }
-                if (a.res2) {
-                    rb0[sl] = *(const f32x2*)(a.res2 + o);
-                    rb1[sl] = row1 ? *(const f32x2*)(a.res2 + o + W) : f32x2{0.f, 0.f};
-                }
+                const int so = (32 * cot + cr) * HW * 4;                          // scalar part of the channel offset
+                ra0[sl] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r1r, lo0, so, 0));
+                ra1[sl] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r1r, lo1, so, 0));
+                rb0[sl] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r2r, lo0, so, 0));
+                rb1[sl] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r2r, lo1, so, 0));
             };
 #pragma unroll
             for (int r = 0; r < EPD - 1; ++r) fetch(r);
@@ -363,11 +459,11 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
                 o10 = fmaf(o10, sc[sl], sh[sl]); o11 = fmaf(o11, sc[sl], sh[sl]);
                 if (a.relu) { o00 = fmaxf(o00, 0.f); o01 = fmaxf(o01, 0.f); o10 = fmaxf(o10, 0.f); o11 = fmaxf(o11, 0.f); }
                 f32x2 q0 = {o00, o01}, q1 = {o10, o11};
-                if (a.res1) { q0 += ra0[sl]; q1 += ra1[sl]; }
-                if (a.res2) { q0 += rb0[sl]; q1 += rb1[sl]; }
-                const long long o = o0 + (long long)cr * HW;
-                *(f32x2*)(a.y + o) = q0;
-                if (row1) *(f32x2*)(a.y + o + W) = q1;
+                q0 += ra0[sl]; q1 += ra1[sl];
+                q0 += rb0[sl]; q1 += rb1[sl];
+                const int so = (32 * cot + cr) * HW * 4;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q0), yr, lo0, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q1), yr, lo1, so, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
@@ -462,6 +558,13 @@ __global__ __launch_bounds__(256) void wino3x3_c128_kernel(const WnArgs a) {
     wino_body<VEC, 1>(a, t / a.grows, t % a.grows, gx, 0);
 }
 
+// whole-K with the input transform shared between the four waves through LDS (even widths)
+__global__ __launch_bounds__(256) void wino3x3_c128_shared_kernel(const WnArgs a) {
+    const int gx = blockIdx.x % a.gcols;
+    const int t = blockIdx.x / a.gcols;
+    wino_body<true, 1, true>(a, t / a.grows, t % a.grows, gx, 0);
+}
+
 // K-split form for maps that do not fill the chip: one work-group per (tile group, channel tile)
 template <bool VEC>
 __global__ __launch_bounds__(256) void wino3x3_c128_ksplit_kernel(const WnArgs a) {
@@ -524,6 +627,7 @@ extern "C" int ic_pack_wino3x3_c128_f32(const float* w_tf, float* w_packed, int 
 
 static unsigned long long* g_wino_prof = nullptr;
 static int g_wino_ksplit = -1;      // -1 automatic, 0 never, 1 always (tuning key 2)
+static int g_wino_share = 1;        // whole-K form: 1 = input transform shared between the waves through LDS (tuning key 4)
 static int g_wino_ratio = 290;      // cost of a whole-K round in K-split rounds, x100 (tuning key 3)
 // tuning only: key 0 = device buffer (as two 32-bit halves: key 0 low, key 1 high) for WN_PROF builds
 extern "C" void ic_wino3x3_c128_set_tuning(int key, int value) {
@@ -532,6 +636,7 @@ extern "C" void ic_wino3x3_c128_set_tuning(int key, int value) {
     if (key == 1) { bits = (bits & 0xffffffffull) | ((unsigned long long)(unsigned)value << 32); g_wino_prof = (unsigned long long*)bits; }
     if (key == 2) g_wino_ksplit = value;
     if (key == 3) g_wino_ratio = value;
+    if (key == 4) g_wino_share = value;
 }
 
 static bool wino_use_ksplit(long long groups) {
@@ -572,7 +677,8 @@ extern "C" int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed,
         else hipLaunchKernelGGL(wino3x3_c128_ksplit_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
     } else {
         const dim3 grid((unsigned)groups);
-        if ((W & 1) == 0) hipLaunchKernelGGL(wino3x3_c128_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        if ((W & 1) == 0 && g_wino_share != 0) hipLaunchKernelGGL(wino3x3_c128_shared_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+        else if ((W & 1) == 0) hipLaunchKernelGGL(wino3x3_c128_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL(wino3x3_c128_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
     }
     IC_LAUNCH_CHECK();
