@@ -628,7 +628,7 @@ extern "C" int ic_pack_wino3x3_c128_f32(const float* w_tf, float* w_packed, int 
 static unsigned long long* g_wino_prof = nullptr;
 static int g_wino_ksplit = -1;      // -1 automatic, 0 never, 1 always (tuning key 2)
 static int g_wino_share = 1;        // whole-K form: 1 = input transform shared between the waves through LDS (tuning key 4)
-static int g_wino_ratio = 290;      // cost of a whole-K round in K-split rounds, x100 (tuning key 3)
+static int g_wino_ratio = 270;      // cost of a whole-K round in K-split rounds, x100 (tuning key 3)
 // tuning only: key 0 = device buffer (as two 32-bit halves: key 0 low, key 1 high) for WN_PROF builds
 extern "C" void ic_wino3x3_c128_set_tuning(int key, int value) {
     static unsigned long long bits = 0;
