@@ -426,9 +426,13 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
                 (void*)(a.res2 ? a.res2 + (size_t)n * WN_C * HW : a.x), 0, a.res2 ? img_bytes : 0, 0x00020000);
             const unsigned lo0 = inside ? (unsigned)((4 * kh * HW + oy * W + ox) * 4) : WN_OOB;
             const unsigned lo1 = inside && row1 ? lo0 + 4u * W : WN_OOB;
-            constexpr int EPD = 6;
+#ifndef WN_EPD
+#define WN_EPD 6
+#endif
+            constexpr int EPD = WN_EPD;
             float sc[EPD], sh[EPD];
             f32x2 ra0[EPD], ra1[EPD], rb0[EPD], rb1[EPD];
+            const float relu_lo = a.relu ? 0.f : -__builtin_inff();
             const float* __restrict__ scp = a.scale + 32 * cot + 4 * kh;
             const float* __restrict__ shp = a.shift + 32 * cot + 4 * kh;
             auto fetch = [&](int r) __attribute__((always_inline)) {
@@ -457,7 +461,7 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
                 float o10 = t1[0] + t1[1] + t1[2], o11 = t1[1] - t1[2] - t1[3];
                 o00 = fmaf(o00, sc[sl], sh[sl]); o01 = fmaf(o01, sc[sl], sh[sl]);
                 o10 = fmaf(o10, sc[sl], sh[sl]); o11 = fmaf(o11, sc[sl], sh[sl]);
-                if (a.relu) { o00 = fmaxf(o00, 0.f); o01 = fmaxf(o01, 0.f); o10 = fmaxf(o10, 0.f); o11 = fmaxf(o11, 0.f); }
+                o00 = fmaxf(o00, relu_lo); o01 = fmaxf(o01, relu_lo); o10 = fmaxf(o10, relu_lo); o11 = fmaxf(o11, relu_lo);
                 f32x2 q0 = {o00, o01}, q1 = {o10, o11};
                 q0 += ra0[sl]; q1 += ra1[sl];
                 q0 += rb0[sl]; q1 += rb1[sl];
