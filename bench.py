@@ -166,7 +166,7 @@ def main():
                 traffic, traffic_src = e['fetch_bytes'] + e['write_bytes'], tj['source']
         except (IOError, OSError, KeyError, ValueError):
             pass
-        roofline = {'kernel': ('wino3x3_c128_kernel' if wino else 'conv3x3_c128_kernel') + ' (ic_conv3x3_c128_auto_f32)',
+        roofline = {'kernel': ('wino3x3_c128_shared_kernel' if wino else 'conv3x3_c128_kernel') + ' (ic_conv3x3_c128_auto_f32)',
                     'algorithm': 'winograd F(2x2,3x3)' if wino else 'direct', 'bound': 'mfma',
                     'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_unit': 'bytes per launch',
