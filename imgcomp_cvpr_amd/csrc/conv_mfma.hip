@@ -115,10 +115,18 @@ __device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph,
         const int q = 32 * (PT * wn + p) + j;
         boff[p] = (GKC * wk + kh) * CS + (q / TC) * PS * S + (q % TC) * PS;
     }
-    // wp[(c8*NT + t)*ncot*64] = A fragments of 8-channel chunk c8, tap t for this wave's output channels
-    const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(ph.wp) + (size_t)cot * 64 + lane;
-    const int wstep = ncot * 64;
-    const size_t cstep = (size_t)NT * wstep;              // one 8-channel chunk of fragments
+    // A fragments of (8-channel chunk c8, tap t) for this wave's output channels sit at float4 index
+    // ((c8*NT + t)*ncot + cot)*64 + lane: a buffer load with a per-lane offset that never changes and a SCALAR offset per
+    // (chunk, tap) -- no vector address arithmetic in the loop.
+    const int cot_u = __builtin_amdgcn_readfirstlane(cot), wk_u = __builtin_amdgcn_readfirstlane(wk);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)ph.wp, 0, (CIN / GKC) * NT * ncot * 256 * 4, 0x00020000);
+    const unsigned wlane = (unsigned)lane * 16u;
+    const int wstep = ncot * 1024;                         // bytes per tap
+    const int cstep = NT * wstep;                          // bytes per 8-channel chunk
+    auto wload = [&](int c8, int t) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, wlane, c8 * cstep + t * wstep + cot_u * 1024, 0));
+    };
 
     f32x16 acc[PT];
 #pragma unroll
@@ -127,11 +135,8 @@ __device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph,
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
     f32x4 ring[RD];
-    {
-        const f32x4* w0 = wp + (size_t)wk * cstep;
 #pragma unroll
-        for (int t = 0; t < RD - 2; ++t) ring[t] = w0[(size_t)t * wstep];
-    }
+    for (int t = 0; t < RD - 2; ++t) ring[t] = wload(wk_u, t);
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
         const float v = xin[goff[i]];
@@ -148,26 +153,43 @@ __device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph,
             for (int i = 0; i < NST; ++i) st[i] = xc[goff[i]];
         }
         const float* __restrict__ L = lds + (c & 1) * (NST * 256);
-        const f32x4* wc = wp + (size_t)(c * WK + wk) * cstep;
-        const f32x4* wnx = wp + (size_t)((c + 1) * WK + wk) * cstep;
+        const int c8 = c * WK + wk_u, c8n = more ? (c + 1) * WK + wk_u : c8;     // past the end: re-read (never used)
+        // B operands of tap t + 1 are read while the MFMAs of tap t run (left alone the compiler reads each one right
+        // before its use: load, wait, multiply); the first tap of a chunk reads its own after the barrier
+        float bq[2][4][PT];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int p = 0; p < PT; ++p) bq[0][ks][p] = L[boff[p] + 2 * ks * CS];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             // ring: request tap g + RD - 2 into the slot whose last reader was tap g - 2
             {
                 const int tn = t + RD - 2;
-                if (tn < NT) ring[tn % RD] = wc[(size_t)tn * wstep];
-                else if (more) ring[tn % RD] = wnx[(size_t)(tn - NT) * wstep];
+                if (tn < NT) ring[tn % RD] = wload(c8, tn);
+                else ring[tn % RD] = wload(c8n, tn - NT);
             }
-            const int tapoff = (t / NTX) * S + (t % NTX);
+            if (t + 1 < NT) {
+                const int tapoff = ((t + 1) / NTX) * S + ((t + 1) % NTX);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int p = 0; p < PT; ++p) bq[(t + 1) & 1][ks][p] = L[boff[p] + 2 * ks * CS + tapoff];
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const float av = ring[t % RD][ks];
 #pragma unroll
-                for (int p = 0; p < PT; ++p) {
-                    const float bv = L[boff[p] + 2 * ks * CS + tapoff];
-                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[p], 0, 0, 0);
-                }
+                for (int p = 0; p < PT; ++p)
+                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[t & 1][ks][p], acc[p], 0, 0, 0);
             }
+#pragma unroll
+            for (int i = 0; i < 4 * PT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // 1 MFMA
+                if (i == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // the tap's filter request
+                if (t + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // 1 LDS read of the next tap
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (more) {
             float* __restrict__ Ln = lds + ((c & 1) ^ 1) * (NST * 256);
