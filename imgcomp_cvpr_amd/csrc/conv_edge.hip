@@ -171,10 +171,17 @@ __global__ __launch_bounds__(256) void deconv3_mfma_kernel(const ConvArgs a, int
             for (int q = 0; q < 4; ++q)
                 A[t][q] = *reinterpret_cast<const e_f32x4*>(wl + (size_t)t * 128 * CIN + 32 * c + 4 * q);
         if (c == 0) __syncthreads();
+        // the four shifted views of step s + 1 are read behind the nine MFMAs of step s
+        float bv[2][4];
+        auto views = [&](int s, int buf) __attribute__((always_inline)) {
+            const float* Ls = L + (32 * c + s) * D3_CS;
+            bv[buf][0] = Ls[0]; bv[buf][1] = Ls[-1]; bv[buf][2] = Ls[-D3_S]; bv[buf][3] = Ls[-D3_S - 1];
+        };
+        views(0, 0);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const float* Ls = L + (32 * c + s) * D3_CS;
-            const float b00 = Ls[0], b0m = Ls[-1], bm0 = Ls[-D3_S], bmm = Ls[-D3_S - 1];
+            if (s + 1 < 16) views(s + 1, (s + 1) & 1);
+            const float b00 = bv[s & 1][0], b0m = bv[s & 1][1], bm0 = bv[s & 1][2], bmm = bv[s & 1][3];
 #define D3_A(t) A[t][s >> 2][s & 3]
             p00a = __builtin_amdgcn_mfma_f32_32x32x2f32(D3_A(0), b00, p00a, 0, 0, 0);   // ky 0, kx 0
             p01 = __builtin_amdgcn_mfma_f32_32x32x2f32(D3_A(1), b00, p01, 0, 0, 0);     // ky 0, kx 1
@@ -186,7 +193,13 @@ __global__ __launch_bounds__(256) void deconv3_mfma_kernel(const ConvArgs a, int
             p01 = __builtin_amdgcn_mfma_f32_32x32x2f32(D3_A(7), bm0, p01, 0, 0, 0);     // ky 2, kx 1
             p00b = __builtin_amdgcn_mfma_f32_32x32x2f32(D3_A(8), bmm, p00b, 0, 0, 0);   // ky 2, kx 2
 #undef D3_A
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < 4 && s + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // epilogue: D[i][j], i = (r&3) + 8*(r>>2) + 4*kh channel of the wave's tile, j = grid position
@@ -286,37 +299,35 @@ __global__ __launch_bounds__(256) void conv5s2_cin3_mfma_kernel(const ConvArgs a
     __syncthreads();
 
     const int j = lane & 31, kh = lane >> 5;
-    // filter fragments A[cot][step], step = (ci*3 + p)*5 + kx, row ky = 2p + kh
-    float A[2][45];
-#pragma unroll
-    for (int ci = 0; ci < 3; ++ci)
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int kx = 0; kx < 5; ++kx) {
-                const int ky = 2 * p + kh;
-                const int kyc = ky < 5 ? ky : 4;
-                const float* wp = wl + ((kyc * 5 + kx) * 3 + ci) * 64 + j;
-                const float w0 = wp[0], w1 = wp[32];
-                A[0][(ci * 3 + p) * 5 + kx] = ky < 5 ? w0 : 0.f;
-                A[1][(ci * 3 + p) * 5 + kx] = ky < 5 ? w1 : 0.f;
-            }
-
     const float* __restrict__ L = lds + (2 * wave + kh) * H1_S + j;
     e_f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    // step s = (ci*3 + p)*5 + kx multiplies filter row ky = 2p + kh; the operands of step s + 1 (two filter fragments,
+    // one input value, all from LDS) are read behind the MFMAs of step s
+    float fa[2][2], fb[2];
+    auto operands = [&](int s, int buf) __attribute__((always_inline)) {
+        const int ci = s / 15, p = (s / 5) % 3, kx = s % 5;
+        const int ky = 2 * p + kh;
+        const float* wp = wl + (((p < 2 ? ky : 4) * 5 + kx) * 3 + ci) * 64 + j;
+        const float w0 = wp[0], w1 = wp[32];
+        fa[buf][0] = (p < 2 || kh == 0) ? w0 : 0.f;            // ky = 5 does not exist
+        fa[buf][1] = (p < 2 || kh == 0) ? w1 : 0.f;
+        fb[buf] = L[ci * H1_CS + 2 * p * H1_S + (kx & 1) * H1_HALF + (kx >> 1)];
+    };
+    operands(0, 0);
 #pragma unroll
-    for (int ci = 0; ci < 3; ++ci)
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int kx = 0; kx < 5; ++kx) {
-                const int s = (ci * 3 + p) * 5 + kx;
-                const float bv = L[ci * H1_CS + 2 * p * H1_S + (kx & 1) * H1_HALF + (kx >> 1)];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0][s], bv, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1][s], bv, acc1, 0, 0, 0);
-            }
+    for (int s = 0; s < 45; ++s) {
+        if (s + 1 < 45) operands(s + 1, (s + 1) & 1);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][0], fb[s & 1], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][1], fb[s & 1], acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     const int gy = oy0 + wave, gx = ox0 + j;
     if (gy >= a.OH || gx >= a.OW) return;
