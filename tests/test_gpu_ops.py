@@ -422,19 +422,72 @@ def test_conv3x3_c128_forms_agree_on_random_shapes(cuda):
             x = torch.randn((N, 128, H, W), device=cuda)
             r = torch.randn((N, 128, H, W), device=cuda)
             outs = []
-            for algo, ks in ((0, -1), (1, 0), (1, 1)):
+            # direct, Winograd whole-K (transform shared through LDS / per wave), Winograd K-split
+            for algo, ks, share in ((0, -1, 1), (1, 0, 1), (1, 1, 1), (1, 0, 0)):
                 L.lib.ic_conv3x3_c128_set_algo(algo)
                 L.lib.ic_wino3x3_c128_set_tuning(2, ks)
+                L.lib.ic_wino3x3_c128_set_tuning(4, share)
                 y = torch.full((N, 128, H, W), float('nan'), device=cuda)
                 L.check(L.lib.ic_conv3x3_c128_auto_f32(L.ptr(x), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(r), None, L.ptr(y),
                                                        N, H, W, 1, L.current_stream()))
                 outs.append(y)
             torch.cuda.synchronize()
             scale_ = max(1.0, float(outs[0].abs().max()))
-            for k in (1, 2):
+            for k in (1, 2, 3):
                 err = float((outs[k] - outs[0]).abs().max()) / scale_
                 assert err < 2e-5, 'shape {} form {}: {}'.format((N, H, W), k, err)
             assert bool(torch.isfinite(outs[2]).all())
+            # sharing the transformed input between the waves changes no operation: bit-identical to the per-wave form
+            assert torch.equal(outs[1], outs[3]), 'shape {}'.format((N, H, W))
     finally:
         L.lib.ic_conv3x3_c128_set_algo(-1)
         L.lib.ic_wino3x3_c128_set_tuning(2, -1)
+        L.lib.ic_wino3x3_c128_set_tuning(4, 1)
+
+
+def test_edge_layers_random_shapes(cuda):
+    """fuzz: the matrix-core edge layers (h1, from_bn, h13 in conv_edge.hip) on random (N, H, W) -- tile borders, widths that
+    are not multiples of the 16-byte staging moves, single rows -- against the float64 reference convolution."""
+    L = _lib()
+    from oracle import oracle as O
+    rs = np.random.RandomState(77)
+    mean, std = O.norm_consts(torch.float32)
+    m_d, s_d = dev(mean.flatten(), cuda), dev(std.flatten(), cuda)
+    d = lambda a: dev(a, cuda)
+    st = L.current_stream()
+    for it in range(10):
+        N, H, W = int(rs.randint(1, 3)), int(rs.randint(1, 40)), int(rs.randint(1, 75))
+        # h1: 5x5 / 2 conv 3 -> 64, input normalisation, ReLU
+        x = rs.uniform(0, 255, (N, 3, H, W)).astype(np.float32)
+        w = rs.normal(0, 0.1, (5, 5, 3, 64)).astype(np.float32)
+        sc, sh = _bn(rs, 64)
+        y = torch.full((N, 64, -(-H // 2), -(-W // 2)), float('nan'), device=cuda)
+        t = [d(x), d(w), d(sc), d(sh)]
+        L.check(L.lib.ic_conv2d_bn_act_f32(L.ptr(t[0]), L.ptr(t[1]), L.ptr(t[2]), L.ptr(t[3]), None, None, L.ptr(y), N, 3, H, W, 64,
+                                           5, 5, 2, 1, L.ptr(m_d), L.ptr(s_d), st))
+        torch.cuda.synchronize()
+        assert_close(y, _ref_conv(x, w, sc, sh, 2, 1, norm=True), 'h1 {}'.format((N, H, W)))
+        # from_bn: 3x3 / 2 transposed conv 32 -> 128, ReLU
+        x = rs.normal(0, 1, (N, 32, H, W)).astype(np.float32)
+        w = rs.normal(0, 0.1, (3, 3, 128, 32)).astype(np.float32)
+        sc, sh = _bn(rs, 128)
+        y = torch.full((N, 128, 2 * H, 2 * W), float('nan'), device=cuda)
+        t = [d(x), d(w), d(sc), d(sh)]
+        L.check(L.lib.ic_deconv2d_bn_act_f32(L.ptr(t[0]), L.ptr(t[1]), L.ptr(t[2]), L.ptr(t[3]), L.ptr(y), N, 32, H, W, 128, 3, 3, 1,
+                                             None, None, st))
+        torch.cuda.synchronize()
+        assert_close(y, _ref_conv(x, w, sc, sh, 2, 1, transposed=True), 'from_bn {}'.format((N, H, W)))
+        # h13: 5x5 / 2 transposed conv 64 -> 3, de-normalise + clip
+        x = rs.normal(0, 1, (N, 64, H, W)).astype(np.float32)
+        w = rs.normal(0, 0.1, (5, 5, 3, 64)).astype(np.float32)
+        sc, sh = _bn(rs, 3)
+        y = torch.full((N, 3, 2 * H, 2 * W), float('nan'), device=cuda)
+        t = [d(x), d(w), d(sc), d(sh)]
+        for tpw in (0, 1, 3):
+            L.lib.ic_edge_set_tuning(0, tpw)
+            y.fill_(float('nan'))
+            L.check(L.lib.ic_deconv2d_bn_act_f32(L.ptr(t[0]), L.ptr(t[1]), L.ptr(t[2]), L.ptr(t[3]), L.ptr(y), N, 64, H, W, 3, 5, 5, 0,
+                                                 L.ptr(m_d), L.ptr(s_d), st))
+            torch.cuda.synchronize()
+            assert_close(y, _ref_conv(x, w, sc, sh, 2, 0, transposed=True, denorm=True), 'h13 {} tpw {}'.format((N, H, W), tpw))
+        L.lib.ic_edge_set_tuning(0, 0)
