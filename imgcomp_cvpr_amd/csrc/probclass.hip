@@ -219,8 +219,14 @@ void pc_mfma_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
     const int q = 32 * wn + j;
     const int boff = kh * CS + (q / TC) * S + (q % TC);
     const int cot = blockIdx.y * WM + wm, ncot = gridDim.y * WM;
-    const pc_f32x4* __restrict__ wp = reinterpret_cast<const pc_f32x4*>(wpk) + (size_t)cot * 64 + lane;
-    const int wstep = ncot * 64;
+    // filter fragments: float4 index ((group * PC_NT + tap) * ncot + cot) * 64 + lane -- one loop-invariant lane offset and
+    // a SCALAR offset per (8-channel group, tap): no vector address arithmetic in the loop
+    const int cot_u = __builtin_amdgcn_readfirstlane(cot);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, (CIN / 8) * PC_NT * ncot * 1024, 0x00020000);
+    const unsigned wlane = (unsigned)lane * 16u;
+    auto wload = [&](int gt) -> pc_f32x4 {                   // gt = group * PC_NT + tap
+        return __builtin_bit_cast(pc_f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, wlane, (gt * ncot + cot_u) * 1024, 0));
+    };
 
     // The K sequence (chunk, 8-channel group, tap, k-step) is cut into PC_NP contiguous parts with one accumulator each,
     // summed as (p0 + p1) + (p2 + p3) in the epilogue.  A dependent fp32 MFMA chain issues only every ~128 clocks; the
@@ -235,7 +241,7 @@ void pc_mfma_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
         for (int r = 0; r < 16; ++r) accp[p][r] = 0.f;
     pc_f32x4 ring[RD];
 #pragma unroll
-    for (int t = 0; t < RD - 2; ++t) ring[t] = wp[(size_t)t * wstep];
+    for (int t = 0; t < RD - 2; ++t) ring[t] = wload(t);
 
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -255,28 +261,45 @@ void pc_mfma_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
         for (int p = 0; p < 2 * KC; ++p) lds[lw + p * lstep] = stv[p];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        // B operands of tap g + 1 are read while the MFMAs of tap g run (left alone the compiler reads each one right before
+        // its use: load, wait, multiply); the first tap of a brick reads its own after the barrier
+        auto tapoff_of = [](int t) {
+            return FLIP ? (1 - pc_tap_kd(t)) * DS + (2 - pc_tap_kh(t)) * S + (2 - pc_tap_kw(t))
+                        : pc_tap_kd(t) * DS + pc_tap_kh(t) * S + pc_tap_kw(t);
+        };
+        float bq[2][4];
 #pragma unroll
-        for (int c8 = 0; c8 < C8; ++c8) {
-            const pc_f32x4* wc = wp + (size_t)((c * C8 + c8) * PC_NT) * wstep;
+        for (int ks = 0; ks < 4; ++ks) bq[0][ks] = lds[boff + (2 * ks) * CS + tapoff_of(0)];
+#pragma unroll
+        for (int g = 0; g < C8 * PC_NT; ++g) {
+            const int c8 = g / PC_NT, t = g % PC_NT;
             const bool more = (c * C8 + c8 + 1) * 8 < CIN;
-#pragma unroll
-            for (int t = 0; t < PC_NT; ++t) {
+            {
                 const int tn = t + RD - 2;
-                if (tn < PC_NT || more) ring[tn % RD] = wc[(size_t)tn * wstep];
-                const int tapoff = FLIP ? (1 - pc_tap_kd(t)) * DS + (2 - pc_tap_kh(t)) * S + (2 - pc_tap_kw(t))
-                                        : pc_tap_kd(t) * DS + pc_tap_kh(t) * S + pc_tap_kw(t);
+                if (tn < PC_NT || more) ring[tn % RD] = wload((c * C8 + c8) * PC_NT + tn);
+            }
+            if (g + 1 < C8 * PC_NT) {
+                const int c8n = (g + 1) / PC_NT, tn1 = (g + 1) % PC_NT;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const float bv = lds[boff + (8 * c8 + 2 * ks) * CS + tapoff];
-                    const int step = c * STEPS_PER_CHUNK + (c8 * PC_NT + t) * 4 + ks, part = step / (STEPS / PC_NP);
-                    accp[part] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[t % RD][ks], bv, accp[part], 0, 0, 0);
-                    // fold finished parts as early as the summation order allows: fewer live accumulators
-                    if (step + 1 == 2 * (STEPS / PC_NP)) {
+                for (int ks = 0; ks < 4; ++ks) bq[(g + 1) & 1][ks] = lds[boff + (8 * c8n + 2 * ks) * CS + tapoff_of(tn1)];
+            }
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) accp[0][r] = accp[0][r] + accp[1][r];
-                    }
+            for (int ks = 0; ks < 4; ++ks) {
+                const int step = c * STEPS_PER_CHUNK + g * 4 + ks, part = step / (STEPS / PC_NP);
+                accp[part] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[t % RD][ks], bq[g & 1][ks], accp[part], 0, 0, 0);
+                // fold finished parts as early as the summation order allows: fewer live accumulators
+                if (step + 1 == 2 * (STEPS / PC_NP)) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accp[0][r] = accp[0][r] + accp[1][r];
                 }
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // 1 MFMA
+                if (i == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);         // the tap's filter request
+                if (g + 1 < C8 * PC_NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 LDS read of the next tap
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     pc_f32x16 acc;
