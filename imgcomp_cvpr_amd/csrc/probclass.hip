@@ -33,7 +33,9 @@ struct PcLayerArgs {
     int prepadded;        // layer 0: `in` already is the padded volume (N,D,H,W)
 };
 
-template <int COB, bool FIRST, bool FINAL>
+// CONTIG: Cout == COB (one channel block covers the layer): filter taps and bias are runs of COB consecutive scalars that
+// the scalar unit fetches 8 at a time, instead of COB clamped single loads per tap
+template <int COB, bool FIRST, bool FINAL, bool CONTIG = false>
 __global__ __launch_bounds__(256) void pc_conv3d_kernel(const PcLayerArgs a) {
     const int n = blockIdx.z;
     const int co0 = blockIdx.y * COB;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void pc_conv3d_kernel(const PcLayerArgs a) {
                     }
                     const float* wp = a.w + (size_t)((kd * 3 + kh) * 3 + kw) * tapstride + (size_t)ci * a.Cout;
 #pragma unroll
-                    for (int j = 0; j < COB; ++j) acc[j] = fmaf(xv, wp[wofs[j]], acc[j]);
+                    for (int j = 0; j < COB; ++j) acc[j] = fmaf(xv, CONTIG ? wp[j] : wp[wofs[j]], acc[j]);
                 }
             }
         }
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void pc_conv3d_kernel(const PcLayerArgs a) {
     if (!live) return;
 #pragma unroll
     for (int j = 0; j < COB; ++j) {
-        float r = acc[j] + a.bias[wofs[j]];
+        float r = acc[j] + (CONTIG ? a.bias[j] : a.bias[wofs[j]]);
         if (a.relu) r = fmaxf(r, 0.f);
         if (a.res && co0 + j < a.Cout) {
             const size_t ro = (((size_t)n * a.Cout + co0 + j) * a.RD + od + 2) * a.RH * a.RW
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void pc_conv3d_kernel(const PcLayerArgs a) {
 // logits are still a fixed, position-independent fp32 expression (what an incremental decoder must match).
 //   B: the (2, TR+2, TC+2) x KC-channel halo brick of the work-group's TR x TC voxels of ONE depth slice,
 //      staged through LDS once per KC channels;
-//   A: filter fragments packed per call into the workspace by pc_pack_kernel (filters are tiny: 14 KB per
+//   A: filter fragments packed per call into the workspace by pc_pack3_kernel (filters are tiny: 14 KB per
 //      8-channel chunk), streamed through a 7-slot register ring.
 // Output channels are padded to 32 per tile (24 -> 32, L = 6 -> 32): the padding costs matrix-pipe time
 // (25 % / 81 %) but the layers are small; the VALU kernel above stays as the any-shape fallback.
@@ -149,17 +151,21 @@ __device__ __forceinline__ constexpr int pc_tap_kd(int t) { return t < 9 ? 0 : 1
 __device__ __forceinline__ constexpr int pc_tap_kh(int t) { return t < 9 ? t / 3 : (t < 12 ? 0 : 1); }
 __device__ __forceinline__ constexpr int pc_tap_kw(int t) { return t < 9 ? t % 3 : (t < 12 ? t - 9 : t - 12); }
 
-// packed[((c8*14 + t)*NCOT + n)*256 + l*4 + j] = w[kd][kh][kw][ci = 8 c8 + 2j + (l>>5)][co = 32n + (l&31)] (0 if co >= Cout)
-__global__ void pc_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout, int NCOT, int total) {
+// packed[((c8*14 + t)*NCOT + n)*256 + l*4 + j] = w[kd][kh][kw][ci = 8 c8 + 2j + (l>>5)][co = 32n + (l&31)] (0 if co >= Cout);
+// the three matrix-core layers of one network in ONE launch (blockIdx.y = layer): three 5 us launches cost more than the
+// packing itself
+struct PcPack3 { const float* w[3]; float* out[3]; int cout[3], ncot[3], total[3]; };
+__global__ void pc_pack3_kernel(const PcPack3 a, int Cin) {
+    const int y = blockIdx.y;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+    if (idx >= a.total[y]) return;
     const int j = idx & 3, l = (idx >> 2) & 63;
     int r = idx >> 8;
-    const int n = r % NCOT; r /= NCOT;
+    const int n = r % a.ncot[y]; r /= a.ncot[y];
     const int t = r % PC_NT, c8 = r / PC_NT;
     const int tap = (pc_tap_kd(t) * 3 + pc_tap_kh(t)) * 3 + pc_tap_kw(t);
     const int ci = 8 * c8 + 2 * j + (l >> 5), co = 32 * n + (l & 31);
-    out[idx] = co < Cout ? w[((size_t)tap * Cin + ci) * Cout + co] : 0.f;
+    a.out[y][idx] = co < a.cout[y] ? a.w[y][((size_t)tap * Cin + ci) * a.cout[y] + co] : 0.f;
 }
 
 // the same fragments for the ADJOINT layer (data gradient): the GEMM's k axis runs over the forward layer's OUTPUT
@@ -389,10 +395,10 @@ extern "C" size_t ic_pc_workspace_bytes(int N, int C, int h, int w, int k) {
     return bytes;
 }
 
-template <int COB, bool FIRST, bool FINAL>
+template <int COB, bool FIRST, bool FINAL, bool CONTIG = false>
 static int launch_pc(const PcLayerArgs& a, hipStream_t st) {
     dim3 g(ic_cdiv(a.OD * a.OH * a.OW, 256), FINAL ? 1 : ic_cdiv(a.Cout, COB), a.N);
-    hipLaunchKernelGGL((pc_conv3d_kernel<COB, FIRST, FINAL>), g, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((pc_conv3d_kernel<COB, FIRST, FINAL, CONTIG>), g, dim3(256), 0, st, a);
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
@@ -436,7 +442,7 @@ static int pc_forward(const float* q, int prepadded, const int64_t* symbols, con
     a.Cin = 1; a.Cout = k; a.D = C + 4; a.H = h + 8; a.W = w + 8; a.OD = C + 3; a.OH = h + 6; a.OW = w + 6;
     a.qC = C; a.qh = h; a.qw = w; a.relu = 1;
     // all k output channels of a voxel in one lane when k = 24: the input brick is read once instead of three times
-    if ((rc = (k == 24 ? launch_pc<24, true, false>(a, st) : launch_pc<8, true, false>(a, st)))) return rc;
+    if ((rc = (k == 24 ? launch_pc<24, true, false, true>(a, st) : launch_pc<8, true, false>(a, st)))) return rc;
     // (the matrix-core kernels address one image's feature volume with 31-bit byte offsets)
     const bool use_mfma = pc_mfma_supported(k, L) && (size_t)k * (C + 3) * (h + 6) * (w + 6) * 4 < (1ull << 31);
     float* pk1 = b2 + (size_t)N * k * (C + 1) * (h + 2) * (w + 2);
@@ -444,9 +450,13 @@ static int pc_forward(const float* q, int prepadded, const int64_t* symbols, con
     float* pk3 = pk2 + pc_packed_floats(k, k);
     if (use_mfma && !prepacked) {
         const int t1 = (int)pc_packed_floats(k, k), t3 = (int)pc_packed_floats(k, L);
-        hipLaunchKernelGGL(pc_pack_kernel, dim3(ic_cdiv(t1, 256)), dim3(256), 0, st, wt[2], pk1, k, k, ic_cdiv(k, 32), t1);
-        hipLaunchKernelGGL(pc_pack_kernel, dim3(ic_cdiv(t1, 256)), dim3(256), 0, st, wt[4], pk2, k, k, ic_cdiv(k, 32), t1);
-        hipLaunchKernelGGL(pc_pack_kernel, dim3(ic_cdiv(t3, 256)), dim3(256), 0, st, wt[6], pk3, k, L, 1, t3);
+        PcPack3 pa{};
+        pa.w[0] = wt[2]; pa.w[1] = wt[4]; pa.w[2] = wt[6];
+        pa.out[0] = pk1; pa.out[1] = pk2; pa.out[2] = pk3;
+        pa.cout[0] = pa.cout[1] = k; pa.cout[2] = L;
+        pa.ncot[0] = pa.ncot[1] = ic_cdiv(k, 32); pa.ncot[2] = 1;
+        pa.total[0] = pa.total[1] = t1; pa.total[2] = t3;
+        hipLaunchKernelGGL(pc_pack3_kernel, dim3(ic_cdiv(t1 > t3 ? t1 : t3, 256), 3), dim3(256), 0, st, pa, k);
         IC_LAUNCH_CHECK();
     }
     // res1/conv1: k -> k, other mask, ReLU
@@ -965,9 +975,13 @@ extern "C" int ic_pc_decode_f32(const uint8_t* bitstream, long long nbytes, int 
         float* pk2 = pk1 + pc_packed_floats(k, k);
         float* pk3 = pk2 + pc_packed_floats(k, k);
         const int t1 = (int)pc_packed_floats(k, k), t3 = (int)pc_packed_floats(k, L);
-        hipLaunchKernelGGL(pc_pack_kernel, dim3(ic_cdiv(t1, 256)), dim3(256), 0, st, wtab_host[2], pk1, k, k, ic_cdiv(k, 32), t1);
-        hipLaunchKernelGGL(pc_pack_kernel, dim3(ic_cdiv(t1, 256)), dim3(256), 0, st, wtab_host[4], pk2, k, k, ic_cdiv(k, 32), t1);
-        hipLaunchKernelGGL(pc_pack_kernel, dim3(ic_cdiv(t3, 256)), dim3(256), 0, st, wtab_host[6], pk3, k, L, 1, t3);
+        PcPack3 pa{};
+        pa.w[0] = wtab_host[2]; pa.w[1] = wtab_host[4]; pa.w[2] = wtab_host[6];
+        pa.out[0] = pk1; pa.out[1] = pk2; pa.out[2] = pk3;
+        pa.cout[0] = pa.cout[1] = k; pa.cout[2] = L;
+        pa.ncot[0] = pa.ncot[1] = ic_cdiv(k, 32); pa.ncot[2] = 1;
+        pa.total[0] = pa.total[1] = t1; pa.total[2] = t3;
+        hipLaunchKernelGGL(pc_pack3_kernel, dim3(ic_cdiv(t1 > t3 ? t1 : t3, 256), 3), dim3(256), 0, st, pa, k);
     }
     hipLaunchKernelGGL(pc_dec_fill_kernel, dim3((unsigned)((nvol + 255) / 256)), dim3(256), 0, st, a.vol, nvol, centers);
     if (use_mfma && k == 24 && g_pc_dec_mode == 0) {
