@@ -331,13 +331,16 @@ def test_branch_streams_cu_range(cuda, configs, syn_weights, nets):
     ae, pc = nets
     bs = streams.BranchStreams(cuda)
     try:
-        assert bs.n_cus >= 64
-        # Kodak: 192 whole-K work-groups -> a quarter of the chip is idle; 4K: the decoder fills every round
-        assert bs.idle_cus(1, 512, 768) == (bs.n_cus - 192) // 8 * 8
+        # Kodak: 192 whole-K work-groups -> on a 256-CU MI355X a quarter of the chip is idle; 4K: the decoder fills every round
+        wgs = int(_lib.lib.ic_wino3x3_c128_workgroups(1, 128, 192))
+        assert wgs == 192
+        expect = min((bs.n_cus - wgs) // 8 * 8, bs.n_cus // 2) if wgs < bs.n_cus else 0
+        assert bs.idle_cus(1, 512, 768) == expect
         assert bs.idle_cus(1, 2160, 3840) == 0
         assert bs.context_model_stream(1, 2160, 3840) is bs._plain
         side = bs.context_model_stream(1, 512, 768)
-        assert side is not bs._plain and side.cuda_stream != bs.main.cuda_stream
+        if expect >= bs.MIN_CUS:
+            assert side is not bs._plain and side.cuda_stream != bs.main.cuda_stream
         assert bs.context_model_stream(1, 512, 768) is side                    # cached
         x = dev(W.synthetic_image((1, 3, 128, 192), 'natural', seed=5), cuda)
         pad = pc.auto_pad_value(ae)
@@ -361,6 +364,6 @@ def test_branch_streams_cu_range(cuda, configs, syn_weights, nets):
         assert float(bpp) == ref_bpp
         # out-of-range requests are refused, not clamped
         h = ctypes.c_void_p()
-        assert _lib.lib.ic_stream_create_cu_range(bs.n_cus - 8, 16, ctypes.byref(h)) != 0
+        assert _lib.lib.ic_stream_create_cu_range(max(bs.n_cus - 8, 0), 16, ctypes.byref(h)) != 0
     finally:
         bs.close()
