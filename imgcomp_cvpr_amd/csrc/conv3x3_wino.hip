@@ -43,6 +43,7 @@ struct WnArgs {
     const float* x; const float* wp; const float* scale; const float* shift;
     const float* res1; const float* res2; float* y;
     int N, H, W, grows, gcols, relu;
+    int xcd_runs;               // shared-transform kernel: 1 = contiguous runs of tile groups per XCD (tuning key 5)
     unsigned long long* prof;   // tuning builds (WN_PROF) only
 };
 
@@ -564,8 +565,13 @@ __global__ __launch_bounds__(256) void wino3x3_c128_kernel(const WnArgs a) {
 
 // whole-K with the input transform shared between the four waves through LDS (even widths)
 __global__ __launch_bounds__(256) void wino3x3_c128_shared_kernel(const WnArgs a) {
-    const int gx = blockIdx.x % a.gcols;
-    const int t = blockIdx.x / a.gcols;
+    // work-group i runs on XCD i % 8 (round-robin dispatch): give every XCD a contiguous run of tile groups, so that the
+    // halo rows shared by vertically adjacent groups are found in ONE L2 instead of being fetched by several
+    int b = blockIdx.x;
+    const int per = gridDim.x >> 3;
+    if (a.xcd_runs && b < 8 * per) b = (b & 7) * per + (b >> 3);
+    const int gx = b % a.gcols;
+    const int t = b / a.gcols;
     wino_body<true, 1, true>(a, t / a.grows, t % a.grows, gx, 0);
 }
 
@@ -631,6 +637,7 @@ extern "C" int ic_pack_wino3x3_c128_f32(const float* w_tf, float* w_packed, int 
 
 static unsigned long long* g_wino_prof = nullptr;
 static int g_wino_ksplit = -1;      // -1 automatic, 0 never, 1 always (tuning key 2)
+static int g_wino_xcd = 1;          // tuning key 5
 static int g_wino_share = 1;        // whole-K form: 1 = input transform shared between the waves through LDS (tuning key 4)
 static int g_wino_ratio = 270;      // cost of a whole-K round in K-split rounds, x100 (tuning key 3)
 // tuning only: key 0 = device buffer (as two 32-bit halves: key 0 low, key 1 high) for WN_PROF builds
@@ -641,6 +648,7 @@ extern "C" void ic_wino3x3_c128_set_tuning(int key, int value) {
     if (key == 2) g_wino_ksplit = value;
     if (key == 3) g_wino_ratio = value;
     if (key == 4) g_wino_share = value;
+    if (key == 5) g_wino_xcd = value;
 }
 
 static bool wino_use_ksplit(long long groups) {
@@ -664,7 +672,7 @@ extern "C" int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed,
     WnArgs a{};
     a.x = x; a.wp = w_packed; a.scale = scale; a.shift = shift; a.res1 = res1; a.res2 = res2; a.y = y;
     a.N = N; a.H = H; a.W = W; a.relu = relu;
-    a.grows = ic_cdiv(H, 4); a.gcols = ic_cdiv(W, 32); a.prof = g_wino_prof;
+    a.grows = ic_cdiv(H, 4); a.gcols = ic_cdiv(W, 32); a.prof = g_wino_prof; a.xcd_runs = g_wino_xcd;
     const long long groups = (long long)N * a.grows * a.gcols;
     // K-split when whole-K waves (4 per group) would leave most of the 1024 SIMDs idle
     // measured cross-over: up to 128 tile groups (<= 2 rounds of 256 K-split work-groups at ~18 us) the K-split form wins
