@@ -21,3 +21,14 @@ static inline int ic_same_pad_before(int in, int k, int stride) {
 // reference: code/autoencoder.py:162-163 (mean, var) and :143 (sqrt(var + 1e-10), float32)
 static __device__ __constant__ const float IC_IMG_MEAN[3] = {121.85369873f, 113.58860779f, 100.63715363f};
 static __device__ __constant__ const float IC_IMG_STD[3] = {68.8939514f, 66.7393417f, 69.3702698f};
+// Work-group i of a launch runs on XCD i % 8 (round-robin dispatch), each XCD with its own L2.  Kernels whose neighbouring
+// tiles share input (halo rows, the channel tiles of one tile group) decode their tile from ic_xcd_run(blockIdx.x, gridDim.x)
+// instead of blockIdx.x: every XCD then walks ONE contiguous run of tiles and finds its neighbours' data in its own L2.
+// A bijection on [0, n): the first 8 * (n / 8) indices are permuted, the tail keeps its place.
+#ifdef __HIPCC__
+__device__ __forceinline__ int ic_xcd_run(int b, int n) {
+    const int per = n >> 3;
+    return b < 8 * per ? (b & 7) * per + (b >> 3) : b;
+}
+#endif
+

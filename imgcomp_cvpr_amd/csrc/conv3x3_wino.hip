@@ -567,9 +567,7 @@ __global__ __launch_bounds__(256) void wino3x3_c128_kernel(const WnArgs a) {
 __global__ __launch_bounds__(256) void wino3x3_c128_shared_kernel(const WnArgs a) {
     // work-group i runs on XCD i % 8 (round-robin dispatch): give every XCD a contiguous run of tile groups, so that the
     // halo rows shared by vertically adjacent groups are found in ONE L2 instead of being fetched by several
-    int b = blockIdx.x;
-    const int per = gridDim.x >> 3;
-    if (a.xcd_runs && b < 8 * per) b = (b & 7) * per + (b >> 3);
+    const int b = a.xcd_runs ? ic_xcd_run(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const int gx = b % a.gcols;
     const int t = b / a.gcols;
     wino_body<true, 1, true>(a, t / a.grows, t % a.grows, gx, 0);
@@ -578,8 +576,10 @@ __global__ __launch_bounds__(256) void wino3x3_c128_shared_kernel(const WnArgs a
 // K-split form for maps that do not fill the chip: one work-group per (tile group, channel tile)
 template <bool VEC>
 __global__ __launch_bounds__(256) void wino3x3_c128_ksplit_kernel(const WnArgs a) {
-    const int cot = blockIdx.x & 3;
-    const int g = blockIdx.x >> 2;
+    // the four channel tiles of a tile group read the same input: keep them (and the neighbouring groups) on one XCD
+    const int b = a.xcd_runs ? ic_xcd_run(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int cot = b & 3;
+    const int g = b >> 2;
     const int gx = g % a.gcols;
     const int t = g / a.gcols;
     wino_body<VEC, 4>(a, t / a.grows, t % a.grows, gx, cot);

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void deconv3_mfma_kernel(const ConvArgs a, int
     constexpr int NE = CIN * D3_CS, NST = (NE + 255) / 256, NCH = CIN / 32;
     __shared__ float lds[NST * 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int b = blockIdx.x;
+    int b = ic_xcd_run(blockIdx.x, gridDim.x);
     const int tx = b % tiles_x; b /= tiles_x;
     const int ty = b % tiles_y; const int n = b / tiles_y;
     const int gx0 = tx * D3_TC, gy0 = ty * D3_TR;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void conv5s2_cin3_mfma_kernel(const ConvArgs a
     __shared__ float lds[3 * H1_CS];
     __shared__ __attribute__((aligned(16))) float wl[25 * 3 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int b = blockIdx.x;
+    int b = ic_xcd_run(blockIdx.x, gridDim.x);
     const int tx = b % tiles_x; b /= tiles_x;
     const int ty = b % tiles_y; const int n = b / tiles_y;
     const int ox0 = tx * H1_TC, oy0 = ty * H1_TR;
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void deconv5_cout3_mfma_kernel(const ConvArgs 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // work-group = a run of up to tpw x-adjacent tiles of one tile row
     const int strips = (tiles_x + tpw - 1) / tpw;
-    int b = blockIdx.x;
+    int b = ic_xcd_run(blockIdx.x, gridDim.x);
     const int sx = b % strips; b /= strips;
     const int ty = b % tiles_y; const int n = b / tiles_y;
     const int tx0 = sx * tpw, nt = min(tpw, tiles_x - tx0);

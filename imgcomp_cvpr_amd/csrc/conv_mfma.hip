@@ -85,7 +85,7 @@ __device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph,
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = (wave / WM) % WN, wk = wave / (WM * WN);
-    int b = blockIdx.x;
+    int b = ic_xcd_run(blockIdx.x, gridDim.x);             // contiguous runs of tiles per XCD: halo rows in one L2
     const int tx_ = b % a.tiles_x; b /= a.tiles_x;
     const int ty_ = b % a.tiles_y; const int n = b / a.tiles_y;
     const int cot = blockIdx.y * WM + wm;                 // this wave's 32-channel output tile

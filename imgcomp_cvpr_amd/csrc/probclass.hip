@@ -200,7 +200,7 @@ void pc_mfma_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
     const int tiles_x = (a.OW + TC - 1) / TC, tiles_y = (a.OH + TR - 1) / TR;
-    int b = blockIdx.x;
+    int b = ic_xcd_run(blockIdx.x, gridDim.x);             // contiguous runs of bricks per XCD: shared planes in one L2
     const int tx = b % tiles_x; b /= tiles_x;
     const int ty = b % tiles_y; const int od = b / tiles_y;
     const int n = blockIdx.z;
