@@ -275,14 +275,17 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
                 for (int st = 0; st < 4; ++st) {
                     const int ks = 4 * j + st;
                     load_filter((st + WN_STAGES - 1) % WN_STAGES, ks + WN_STAGES - 1 < 64 ? ks + WN_STAGES - 1 : 63);
-                    if (st == 0) {
-                        // own k-step of iteration j + 2 into the patch slot transformed one iteration ago; own k-step of
-                        // iteration j + 1 (loaded one iteration ago) through the transform.  Past the end both repeat the
-                        // last own k-step: same instruction stream, the extra ring entries are never read.
+#ifndef WN_PATCH_ST
+#define WN_PATCH_ST 0
+#endif
+                    if (st == WN_PATCH_ST) {
+                        // own k-step of iteration j + 2 into the patch slot transformed one iteration ago.  Past the end it
+                        // repeats the last own k-step: same instruction stream, the extra ring entries are never read.
                         const int kp = 4 * (j + 2) + wave < 64 ? 4 * (j + 2) + wave : 60 + wave;
                         load_patch(u, kp);
-                        transform(u ^ 1, vt);
                     }
+                    // own k-step of iteration j + 1 (loaded one iteration ago) through the transform
+                    if (st == 0) transform(u ^ 1, vt);
                     if (st == 1) put(u ^ 1, vt);
                     if (st < 3) get(u, st + 1, bq[(st + 1) & 1]);
                     else get(u ^ 1, 0, bq[0]);
@@ -292,7 +295,7 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
 #pragma unroll
                     for (int p = 0; p < 16; ++p) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             // 1 MFMA
-                        if (p < (st == 0 ? 12 : 4)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+                        if (p < (st == WN_PATCH_ST ? 12 : 4)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
                         if (p >= 4 && p < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // 1 LDS read
                         if (st == 1 && p >= 8 && p < 12) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 LDS write
                         if (st == 0) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                // the transform
