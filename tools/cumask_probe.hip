@@ -1,6 +1,6 @@
 // Probe: which physical CUs does a hipExtStreamCreateWithCUMask stream use?  Prints, per mask, the number of distinct
 // (XCC, SE, CU) a launch of 2048 spinning work-groups touched and the per-XCC CU counts.
-//   hipcc --offload-arch=gfx950 -O2 tools/cumask_probe.hip -o gpurun_out/cumask_probe
+//   hipcc --offload-arch=gfx950 -O2 tools/cumask_probe.hip -o ab/cumask_probe   (ab/ is git-ignored scratch that still travels to the GPU box)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <set>
