@@ -31,6 +31,7 @@ struct GArgs {
     int OH, OW, OS;         // output tensor extent, grid -> output stride (2 for transposed phases)
     int Cout, relu;
     int tiles_x, tiles_y;
+    unsigned long long* prof;   // tuning builds (CM_PROF) only
 };
 
 // packed[((c*NT + t)*NCOT + n)*256 + l*4 + j] = W[ky(ty)][kx(tx)][ci = 8c + 2j + (l>>5)][co = 32n + (l&31)]
@@ -73,6 +74,9 @@ struct GGeo {
 // with whole-K tiles (to_bn: 6144 pixels x 33 channels, K = 3200).
 template <int NTY, int NTX, int PS, int CIN, int WM, int WN, int WK, int PT, int TR, int TC, int RD>
 __device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph, float* __restrict__ lds) {
+#ifdef CM_PROF
+    const unsigned long long cm_t0 = __builtin_amdgcn_s_memtime();
+#endif
     using G = GGeo<NTY, NTX, PS, WK, TR, TC>;
     constexpr int NT = NTY * NTX;
     constexpr int NCH = CIN / (GKC * WK);
@@ -134,6 +138,22 @@ __device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph,
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
+    // BN scale / shift of the channels this lane finishes, requested before the main loop: fetched inside the store loop,
+    // each of the 16 channel iterations waited out its own L2 round trip (25 k of a wave's 165 k clocks in h2,
+    // tools/cm_prof.py).  Channels past Cout read 0 through the descriptor's range check.
+    constexpr int RPW = 16 / WK;                           // accumulator registers finished by each K-slice wave
+    float bsc[RPW], bsh[RPW];
+    {
+        const __amdgpu_buffer_rsrc_t scr = __builtin_amdgcn_make_buffer_rsrc((void*)a.scale, 0, a.Cout * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t shr = __builtin_amdgcn_make_buffer_rsrc((void*)a.shift, 0, a.Cout * 4, 0x00020000);
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = (WK > 1 ? wk * RPW : 0) + rr;
+            const unsigned co4 = (unsigned)(32 * cot + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 4u;
+            bsc[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(scr, co4, 0, 0));
+            bsh[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(shr, co4, 0, 0));
+        }
+    }
     f32x4 ring[RD];
 #pragma unroll
     for (int t = 0; t < RD - 2; ++t) ring[t] = wload(wk_u, t);
@@ -143,6 +163,9 @@ __device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph,
         lds[tid + 256 * i] = ((inb >> i) & 1) ? v : 0.f;
     }
     __syncthreads();
+#ifdef CM_PROF
+    const unsigned long long cm_t1 = __builtin_amdgcn_s_memtime();
+#endif
 
     for (int c = 0; c < NCH; ++c) {
         const bool more = c + 1 < NCH;
@@ -201,13 +224,13 @@ __device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph,
         __builtin_amdgcn_s_barrier();
     }
 
+#ifdef CM_PROF
+    const unsigned long long cm_t2 = __builtin_amdgcn_s_memtime();
+#endif
     // epilogue: D[i][j], i = (r&3) + 8*(r>>2) + 4*kh channel, j pixel
-    const float* __restrict__ scale = a.scale;
-    const float* __restrict__ shift = a.shift;
     float* __restrict__ y = a.y;
     const size_t OHW = (size_t)a.OH * a.OW;
     const size_t cbase = ((size_t)n * a.Cout + 32 * cot + 4 * kh) * OHW;
-    constexpr int RPW = 16 / WK;                           // accumulator registers finished by each K-slice wave
     if (WK > 1) {
         // all waves passed the loop's last barrier: the staging buffers are free
         float* red = lds + (size_t)((wm * WN + wn) * WK) * (PT * 16 * 64);
@@ -239,13 +262,19 @@ __device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph,
                 const int crow = (r & 3) + 8 * (r >> 2);
                 const int co = 32 * cot + crow + 4 * kh;
                 if (co < a.Cout) {
-                    float v = fmaf(acc[p][rr], scale[co], shift[co]);
+                    float v = fmaf(acc[p][rr], bsc[rr], bsh[rr]);
                     if (a.relu) v = fmaxf(v, 0.f);
                     y[pix + (size_t)crow * OHW] = v;
                 }
             }
         }
     }
+#ifdef CM_PROF
+    if (a.prof && lane == 0) {
+        unsigned long long* d = a.prof + 4 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave);
+        d[0] = cm_t0; d[1] = cm_t1; d[2] = cm_t2; d[3] = __builtin_amdgcn_s_memtime();
+    }
+#endif
 }
 
 template <int NTY, int NTX, int PS, int CIN, int WM, int WN, int WK, int PT, int TR, int TC, int RD>
@@ -271,6 +300,10 @@ __global__ __launch_bounds__(256) void deconv5_mfma_kernel(const GArgs a, const 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+static unsigned long long* g_cm_prof = nullptr;
+#ifdef CM_PROF      // tuning builds only (tools/cm_prof.py): device buffer of 4 x u64 shader-clock stamps per wave
+extern "C" void ic_conv2d_mfma_set_prof(unsigned lo, unsigned hi) { g_cm_prof = (unsigned long long*)(((unsigned long long)hi << 32) | lo); }
+#endif
 static int ncot_for(int Cout) { return ic_cdiv(Cout, 32) <= 2 ? 2 : ic_cdiv(ic_cdiv(Cout, 32), 4) * 4; }
 
 // number of taps of transposed-conv phase p (0/1) along one axis, and the offset of its first tap
@@ -336,7 +369,7 @@ extern "C" int ic_conv2d_mfma_bn_act_f32(const float* x, const float* w_packed, 
     const int ncot = ncot_for(Cout);
     GArgs a{};
     a.x = x; a.scale = scale; a.shift = shift; a.y = y;
-    a.N = N; a.IH = H; a.IW = W; a.Cout = Cout; a.relu = relu;
+    a.N = N; a.IH = H; a.IW = W; a.Cout = Cout; a.relu = relu; a.prof = g_cm_prof;
     if (!transposed) {
         GPhase ph{};
         ph.wp = w_packed; ph.py = 0; ph.px = 0;
