@@ -30,7 +30,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
-SUSTAINED_F32_MFMA_TFLOPS = 103.0   # measured: h2 at 100 % matrix-pipe occupancy on all 1024 SIMDs runs at 1.57 GHz (tools/cm_prof.py)
 # algorithmic work per input pixel, C = 32 (FLOP = 2 MAC, dense, mask-agnostic, halo-free)
 FLOP_PER_PX_ENC = 621124.0
 FLOP_PER_PX_DEC = 618976.0
@@ -174,11 +173,7 @@ def main():
                     'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': int(3 * 512 * N * h4 * w4 + (1048576 if wino else 589824)),
                     'executed_tflops': round(executed, 2), 'executed_frac': round(executed / PEAK_F32_MFMA_TFLOPS, 4),
                     'avg_launch_us': round(ms_conv * 1e3, 2), 'flop_per_launch': flop,
-                    'launches_per_step': 2 * (6 * int(ae_cfg.arch_param_B) + 2),
-                    # informational: what fp32 MFMA sustains under the power limit with every SIMD busy, measured on the h2
-                    # layer at 100 % matrix-pipe occupancy; `peak` above stays the datasheet figure
-                    'sustained_mfma_tflops_measured': SUSTAINED_F32_MFMA_TFLOPS,
-                    'executed_frac_of_sustained': round(executed / SUSTAINED_F32_MFMA_TFLOPS, 4)}
+                    'launches_per_step': 2 * (6 * int(ae_cfg.arch_param_B) + 2)}
         for e in ev:
             lib.ic_event_destroy(e)
         # Extra, NOT the contract value: the same step with three independent batch-1 pipelines in flight (one stream and
