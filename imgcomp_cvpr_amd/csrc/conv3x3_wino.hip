@@ -536,7 +536,10 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
             const f32x4* q = red + (o * 4 + wave) * 64 + lane;
             mine[o] = (q[0] + q[16 * 64]) + (q[2 * 16 * 64] + q[3 * 16 * 64]);
         }
-        if (!inside) return;
+#ifdef WN_PROF
+        const unsigned long long t_xchg = __builtin_amdgcn_s_memtime();
+#endif
+        if (inside) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float o00 = mine[0][i], o01 = mine[1][i], o10 = mine[2][i], o11 = mine[3][i];
@@ -555,6 +558,13 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
                 finish(32 * cot + 8 * (r >> 2) + 4 * kh + (r & 3), o00, o01, o10, o11);
             }
         }
+        }
+#ifdef WN_PROF
+        if (a.prof && lane == 0) {     // K-split: prologue, k-loop, transform + exchange, rest of the epilogue
+            unsigned long long* d = a.prof + 4 * ((size_t)blockIdx.x * 4 + wave);
+            d[0] = t_loop0 - t_entry; d[1] = t_loop1 - t_loop0; d[2] = t_xchg - t_loop1; d[3] = __builtin_amdgcn_s_memtime() - t_xchg;
+        }
+#endif
     }
 }
 
