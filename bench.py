@@ -241,7 +241,11 @@ def main():
                                    'ae_configs/cvpr/{} + pc_configs/cvpr/res_shallow, encode + parallel '
                                    'context-model bitcost + decode(qhard); random-init weights'.format(
                                        N, H, Wd, a.ae_config),
-                       'batch_per_gpu': N, 'height': H, 'width': Wd, 'parallelism': 'image-sharded x{}'.format(world)},
+                       'batch_per_gpu': N, 'height': H, 'width': Wd, 'parallelism': 'image-sharded x{}'.format(world),
+                       'schedule': 'one image at a time; bitcost and decode of that image run concurrently (val.py:85-89 '
+                                   'evaluates both in one session.run), the bitcost on {}'.format(
+                                       'a stream limited to the {} CUs the decoder leaves idle'.format(extra['context_model_stream_cus'])
+                                       if extra.get('context_model_stream_cus') else 'a second stream')},
             'model_tflops_per_s': round(flop_step * world * a.steps / elapsed / 1e12, 2),
             'roofline': roofline, 'cpu_baseline': cpu,
         }
