@@ -43,7 +43,8 @@ struct WnArgs {
     const float* x; const float* wp; const float* scale; const float* shift;
     const float* res1; const float* res2; float* y;
     int N, H, W, grows, gcols, relu;
-    int xcd_runs;               // shared-transform kernel: 1 = contiguous runs of tile groups per XCD (tuning key 5)
+    int xcd_runs;               // 1 = contiguous runs of tile groups per XCD (tuning key 5)
+    int g0;                     // first tile group of this launch (a shape may be split into a whole-K and a K-split launch)
     unsigned long long* prof;   // tuning builds (WN_PROF) only
 };
 
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(256) void wino3x3_c128_ksplit_kernel(const WnArgs a
     // the four channel tiles of a tile group read the same input: keep them (and the neighbouring groups) on one XCD
     const int b = a.xcd_runs ? ic_xcd_run(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const int cot = b & 3;
-    const int g = b >> 2;
+    const int g = (b >> 2) + a.g0;
     const int gx = g % a.gcols;
     const int t = g / a.gcols;
     wino_body<VEC, 4>(a, t / a.grows, t % a.grows, gx, cot);
@@ -664,16 +665,27 @@ extern "C" void ic_wino3x3_c128_set_tuning(int key, int value) {
     if (key == 5) g_wino_xcd = value;
 }
 
-static bool wino_use_ksplit(long long groups) {
-    const long long rounds_w = (groups + 255) / 256, rounds_k = (4 * groups + 255) / 256;
-    return g_wino_ksplit < 0 ? 100 * rounds_k < g_wino_ratio * rounds_w : g_wino_ksplit != 0;
+// One work-group per CU at a time (512 registers per lane), so a launch runs in rounds of 256 work-groups.  A round of
+// whole-K work-groups (one tile group each, four channel tiles sharing the input transform) costs ~2.7 rounds of K-split
+// ones (one channel tile of a tile group each; sustained: 37.3 us against 3 x 13.2 us on a Kodak map).  Plan: the full rounds
+// of 256 tile groups run whole-K; the remainder r runs whole-K as one partly empty round, or K-split in ceil(r / 64) short
+// rounds when that is cheaper (r <= 128).  A Kodak map (192 groups) is one 75 % full whole-K round; a 64x64 map (32 groups)
+// one K-split round; 272 groups = one full whole-K round + one K-split round (51 us; all whole-K 88, all K-split 72).
+static void wino_plan(long long groups, long long* gw, long long* gk) {
+    if (g_wino_ksplit == 0) { *gw = groups; *gk = 0; return; }
+    if (g_wino_ksplit > 0) { *gw = 0; *gk = groups; return; }
+    const long long r = groups % 256;
+    const bool rem_ksplit = r > 0 && 100 * ((r + 63) / 64) < g_wino_ratio;
+    *gk = rem_ksplit ? r : 0;
+    *gw = groups - *gk;
 }
 
-// work-groups (= CUs kept busy, one each) of the launch ic_wino3x3_c128_bn_act_f32 would make for this shape
+// work-groups of the launch(es) ic_wino3x3_c128_bn_act_f32 would make for this shape; each occupies one whole CU
 extern "C" long long ic_wino3x3_c128_workgroups(int N, int H, int W) {
     if (N <= 0 || H <= 0 || W <= 0) return 0;
-    const long long groups = (long long)N * ic_cdiv(H, 4) * ic_cdiv(W, 32);
-    return wino_use_ksplit(groups) ? 4 * groups : groups;
+    long long gw, gk;
+    wino_plan((long long)N * ic_cdiv(H, 4) * ic_cdiv(W, 32), &gw, &gk);
+    return gw + 4 * gk;
 }
 
 extern "C" int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
@@ -686,25 +698,21 @@ extern "C" int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed,
     a.x = x; a.wp = w_packed; a.scale = scale; a.shift = shift; a.res1 = res1; a.res2 = res2; a.y = y;
     a.N = N; a.H = H; a.W = W; a.relu = relu;
     a.grows = ic_cdiv(H, 4); a.gcols = ic_cdiv(W, 32); a.prof = g_wino_prof; a.xcd_runs = g_wino_xcd;
-    const long long groups = (long long)N * a.grows * a.gcols;
-    // K-split when whole-K waves (4 per group) would leave most of the 1024 SIMDs idle
-    // measured cross-over: up to 128 tile groups (<= 2 rounds of 256 K-split work-groups at ~18 us) the K-split form wins
-    // (37 us vs 43-50 us); at Kodak's 192 groups the micro-benchmark is a tie and the whole step is 6 % slower with K-split
-    // One work-group per CU at a time (512 registers per lane), so a launch runs in rounds of 256 work-groups, and K-split
-    // issues four times as many.  A full round of whole-K work-groups costs ~2.9 K-split rounds in a sustained run (Kodak
-    // map, 192 groups, inside bench.py: one 75 % full whole-K round 41.5 us, three full K-split rounds 43.1 us -- with
-    // every SIMD busy the clock drops, a short burst in tools/bench_wino.py shows 50 against 46 us); K-split wins where the
-    // whole-K launch would leave most of a round empty (<= 128 groups; 272 groups: 72 against 88 us).
-    const bool ksplit = wino_use_ksplit(groups);
-    if (ksplit) {
-        const dim3 grid((unsigned)(groups * 4));
-        if ((W & 1) == 0) hipLaunchKernelGGL(wino3x3_c128_ksplit_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL(wino3x3_c128_ksplit_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    } else {
-        const dim3 grid((unsigned)groups);
-        if ((W & 1) == 0 && g_wino_share != 0) hipLaunchKernelGGL(wino3x3_c128_shared_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
-        else if ((W & 1) == 0) hipLaunchKernelGGL(wino3x3_c128_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL(wino3x3_c128_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    long long gw, gk;
+    wino_plan((long long)N * a.grows * a.gcols, &gw, &gk);
+    hipStream_t st = (hipStream_t)stream;
+    if (gw > 0) {
+        const dim3 grid((unsigned)gw);
+        a.g0 = 0;
+        if ((W & 1) == 0 && g_wino_share != 0) hipLaunchKernelGGL(wino3x3_c128_shared_kernel, grid, dim3(256), 0, st, a);
+        else if ((W & 1) == 0) hipLaunchKernelGGL(wino3x3_c128_kernel<true>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(wino3x3_c128_kernel<false>, grid, dim3(256), 0, st, a);
+    }
+    if (gk > 0) {
+        const dim3 grid((unsigned)(gk * 4));
+        a.g0 = (int)gw;
+        if ((W & 1) == 0) hipLaunchKernelGGL(wino3x3_c128_ksplit_kernel<true>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(wino3x3_c128_ksplit_kernel<false>, grid, dim3(256), 0, st, a);
     }
     IC_LAUNCH_CHECK();
     return IC_OK;

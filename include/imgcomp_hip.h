@@ -113,8 +113,9 @@ int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed, const floa
                                int N, int H, int W, int relu, ic_stream_t stream);
 /* tuning / tests: key 2 = work decomposition (-1 automatic, 0 whole-K waves: 4 output-channel tiles per work-group,
  * 1 K-split: one channel tile per work-group, 4 quarters of the input channels summed through LDS after the output
- * transform -- the form every map runs whose whole-K launch would leave a round of 256 work-groups partly empty);
- * key 3 = cost of a whole-K round in K-split rounds x 100 (default 270) for the automatic choice; keys 0, 1: profiling
+ * transform).  Automatic: full rounds of 256 tile groups whole-K, a remainder of <= 128 groups as a second, K-split launch;
+ * key 3 = cost of a whole-K round in K-split rounds x 100 (default 270) for that choice; key 4 = whole-K input transform
+ * shared through LDS (default 1); key 5 = XCD-contiguous tile order (default 1); keys 0, 1: profiling
  * builds. */
 void ic_wino3x3_c128_set_tuning(int key, int value);
 /* work-groups of the launch above for this shape; each occupies one whole CU (what a caller sizing a CU-range stream

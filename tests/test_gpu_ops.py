@@ -491,3 +491,41 @@ def test_edge_layers_random_shapes(cuda):
             torch.cuda.synchronize()
             assert_close(y, _ref_conv(x, w, sc, sh, 2, 0, transposed=True, denorm=True), 'h13 {} tpw {}'.format((N, H, W), tpw))
         L.lib.ic_edge_set_tuning(0, 0)
+
+
+@pytest.mark.parametrize('N,H,W', [(1, 136, 240), (2, 136, 240)])
+def test_winograd_hybrid_plan(cuda, N, H, W):
+    """272 / 544 tile groups: the full rounds of 256 run whole-K, the remainder (16 / 32 groups) K-split, in two launches of
+    one call; every output tile is written exactly once and agrees with the single-form launches."""
+    L = _lib()
+    rs = np.random.RandomState(5)
+    w = rs.normal(0, 0.05, (3, 3, 128, 128)).astype(np.float32)
+    scale, shift = _bn(rs, 128)
+    wd, sd, hd = dev(w, cuda), dev(scale, cuda), dev(shift, cuda)
+    wp = torch.empty(L.lib.ic_wino3x3_c128_packed_floats(), device=cuda)
+    L.check(L.lib.ic_pack_wino3x3_c128_f32(L.ptr(wd), L.ptr(wp), 0, L.current_stream()))
+    x = torch.randn((N, 128, H, W), device=cuda)
+    r = torch.randn((N, 128, H, W), device=cuda)
+    groups = N * -(-H // 4) * -(-W // 32)
+    assert groups % 256 in (16, 32)
+    assert int(L.lib.ic_wino3x3_c128_workgroups(N, H, W)) == groups - groups % 256 + 4 * (groups % 256)
+    outs = []
+    try:
+        for ks in (-1, 0, 1):
+            L.lib.ic_wino3x3_c128_set_tuning(2, ks)
+            y = torch.full((N, 128, H, W), float('nan'), device=cuda)
+            L.check(L.lib.ic_wino3x3_c128_bn_act_f32(L.ptr(x), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(r), None, L.ptr(y), N, H, W, 1,
+                                                     L.current_stream()))
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(y).all())
+            outs.append(y)
+    finally:
+        L.lib.ic_wino3x3_c128_set_tuning(2, -1)
+    scale_ = float(outs[1].abs().max())
+    assert float((outs[0] - outs[1]).abs().max()) / scale_ < 2e-5
+    assert float((outs[2] - outs[1]).abs().max()) / scale_ < 2e-5
+    # the whole-K part of the hybrid launch is the whole-K launch's own output, bit for bit
+    gw = groups - groups % 256
+    rows_w = (gw // (-(-W // 32))) % (-(-H // 4))       # tile-group rows of the last image fully inside the whole-K part
+    if N == 1:
+        assert torch.equal(outs[0][:, :, :4 * rows_w], outs[1][:, :, :4 * rows_w])
