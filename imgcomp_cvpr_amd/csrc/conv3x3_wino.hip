@@ -11,7 +11,7 @@
 //   * the B operand of position p is V_p[ci = 2 ks + (l >> 5)][tile = l & 31]: ONE input patch transform per lane yields
 //     the B operands of all 16 positions of that k-step.  Each lane loads the aligned pixel pair of its tile for the 4
 //     patch rows (coalesced dwordx2) and takes the two outer columns from its neighbour lanes by DPP row shifts, does
-//     the 32 add/subs of Bt d B in registers and feeds 16 MFMAs.  No LDS, no barrier: a wave never waits for another.
+//     the 32 add/subs of Bt d B in registers and feeds 16 MFMAs.
 //   * the A operands (transformed filters) are pre-packed in fragment order: 4 global_load_dwordx4 per k-step, each
 //     reading 1 KB contiguous across the wave (L2 resident, 1 MB per layer).
 //   * a wave owns (32 output channels) x (32 tiles) x (16 positions) = 16 accumulators of 16 registers = 256 AGPRs;
@@ -19,8 +19,13 @@
 //     followed by BN scale/shift, ReLU, residual adds and 8-byte stores (a tile row is 2 neighbouring pixels).
 //   * one wave per SIMD (512 registers): latency is hidden by a 4-stage register ring -- patch and filter fragments
 //     are requested 3 k-steps (~3000 clocks of MFMA work) before they are consumed.
-//   * work-group = 4 waves = the 4 output-channel tiles of the same 32 spatial tiles: the patch loads of the four
-//     waves hit the same lines (L1), the filter streams are disjoint.
+//   * work-group = 4 waves = the 4 output-channel tiles of the same 32 spatial tiles.  In the per-wave form every wave
+//     loads and transforms every k-step (the patch loads of the four waves hit the same L1 lines); in the SHARED form
+//     (wino3x3_c128_shared_kernel, the one the even-width maps run) wave w loads and transforms only k-steps 4j + w and
+//     the B operands travel to the other waves through a 32 KB LDS ring, one barrier per 4 k-steps -- a quarter of the
+//     vector instructions per MFMA.  The filter streams are disjoint.
+//   * launches: full rounds of 256 tile groups run this whole-K form; small maps and small remainders run the K-split
+//     form (one channel tile per work-group, the four waves = four quarters of the input channels), see wino_plan.
 //
 // Rounding differs from the direct form (different summation tree); measured against the float64 oracle both stay
 // inside the 1e-4 parity bound (tests/test_gpu_ops.py).
