@@ -89,7 +89,9 @@ def main():
         with torch.cuda.stream(side):
             bc = pc.bitcost(enc.qbar, enc.symbols, is_training=False, pad_value=pad_value)
             bpp = bits.bitcost_to_bpp(bc, x)
+        branch.reserve_idle_cus(side is not branch._plain)     # the decoder's 3x3 launches leave the side stream's CUs alone
         x_out = ae.decode(enc.qhard, is_training=False)
+        branch.reserve_idle_cus(False)
         cur.wait_stream(side)
         return bpp, x_out
 
@@ -166,7 +168,9 @@ def main():
                 traffic, traffic_src = e['fetch_bytes'] + e['write_bytes'], tj['source']
         except (IOError, OSError, KeyError, ValueError):
             pass
-        roofline = {'kernel': ('wino3x3_c128_shared_kernel' if wino else 'conv3x3_c128_kernel') + ' (ic_conv3x3_c128_auto_f32)',
+        groups = N * (-(-h4 // 4)) * (-(-w4 // 32))
+        t16 = wino and lib.ic_wino3x3_c128_workgroups(N, h4, w4) >= 256 > groups
+        roofline = {'kernel': (('wino3x3_c128_t16_kernel' if t16 else 'wino3x3_c128_shared_kernel') if wino else 'conv3x3_c128_kernel') + ' (ic_conv3x3_c128_auto_f32)',
                     'algorithm': 'winograd F(2x2,3x3)' if wino else 'direct', 'bound': 'mfma',
                     'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_unit': 'bytes per launch',

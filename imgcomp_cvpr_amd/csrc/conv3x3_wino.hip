@@ -31,6 +31,7 @@
 // inside the 1e-4 parity bound (tests/test_gpu_ops.py).
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 #include "internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -38,7 +39,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define WN_C 128
-#define WN_PACKED_FLOATS (16 * WN_C * WN_C)
+#define WN_FRAG_FLOATS (16 * WN_C * WN_C)          // one layout of the transformed filter
+#define WN_PACKED_FLOATS (2 * WN_FRAG_FLOATS)      // [32-channel-tile fragments | 16-channel-tile fragments]
 #define WN_STAGES 4
 #ifndef WN_ABL
 #define WN_ABL 0      // tuning builds only: 1 no patch loads, 2 no filter loads, 4 no transform in the main loop
@@ -79,10 +81,14 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
         t[3][b] = g[2][b];
     }
     float* o = out + (((size_t)(cout >> 5) * 64 + (cin >> 1)) * 4 * 64 + ((cin & 1) * 32 + (cout & 31))) * 4;
+    // second layout, for v_mfma_f32_16x16x4_f32 (wino3x3_c128_t16_kernel): cot16 = co / 16, ks4 = ci / 4,
+    // lane = (ci & 3) * 16 + (co & 15)
+    float* o16 = out + WN_FRAG_FLOATS + (((size_t)(cout >> 4) * 32 + (cin >> 2)) * 4 * 64 + ((cin & 3) * 16 + (cout & 15))) * 4;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         f32x4 q = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
         *(f32x4*)(o + a * 256) = q;
+        *(f32x4*)(o16 + a * 256) = q;
     }
 }
 
@@ -604,6 +610,211 @@ __global__ __launch_bounds__(256) void wino3x3_c128_ksplit_kernel(const WnArgs a
     wino_body<VEC, 4>(a, t / a.grows, t % a.grows, gx, cot);
 }
 
+// ---- 16 tiles x 16 channels per wave on v_mfma_f32_16x16x4_f32 -------------------------------------------------------------
+// The 32 x 32 form above makes (tile groups x 4) wave-jobs of 1024 MFMAs; a Kodak map is 768 of them for 1024 SIMDs and a
+// quarter of the chip idles.  Here a wave-job is 16 tiles (ONE tile row of 16 = 2 x 32 output pixels) x 16 output channels:
+// 16 positions x 4 accumulator registers = 64 instead of 256, four times as many jobs (3072 for a Kodak map = three per
+// SIMD), half as long (32 k-steps of 4 input channels, 16 MFMAs of 32 clocks each).  A work-group is one tile row x one HALF of
+// the output channels (4 waves = 4 channel tiles); as in the shared kernel, wave w loads and transforms the input of k-steps
+// 4j + w only and the B operands reach the other waves through the LDS ring.  ~240 registers per lane: two work-groups per CU.
+// Lane l: B operand k = l >> 4 (input channel of the k-step), n = l & 15 (tile); A operand row = l & 15 (channel of the tile),
+// k = l >> 4; D rows 4 (l >> 4) .. +3 (channels), column l & 15 (tile).
+__global__ __launch_bounds__(256) void wino3x3_c128_t16_kernel(const WnArgs a) {
+#ifdef WN_PROF
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
+    __shared__ f32x4 ring[2 * 4 * 4 * 64];                    // [half][k-step of the iteration][position quad][lane]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, kq = lane >> 4, tj = lane & 15;
+    // work-groups of this launch: tile groups [g0, g0 + gridDim.x / 4) of the 32 x 32 form, each as 2 tile rows x 2 channel
+    // halves; channel half major, so that the work-groups sharing a CU stream the same half of the filter
+    const int b = a.xcd_runs ? ic_xcd_run(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int per_half = gridDim.x >> 1;
+    const int hc = b >= per_half;
+    const int rem = hc ? b - per_half : b;
+    const int g = a.g0 + (rem >> 1);
+    const int gx = g % a.gcols, t = g / a.gcols;
+    const int n = t / a.grows, ty = 2 * (t % a.grows) + (rem & 1);
+    if (2 * ty >= a.H) return;                                 // second tile row of a group below the map (whole work-group)
+    const int ct = 4 * hc + wave;                              // 16-channel output tile of this wave
+    const int tx = gx * 16 + tj;
+    const int r0 = 2 * ty - 1;
+    const int H = a.H, W = a.W, HW = H * W;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)n * WN_C * HW), 0, WN_C * HW * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wp + WN_FRAG_FLOATS), 0, WN_FRAG_FLOATS * 4, 0x00020000);
+    const int ecol = tj == 0 ? 2 * tx - 2 : (tj == 15 ? 2 * tx + 2 : -1);
+    unsigned o0[4], oe[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + i;
+        const bool rok = r >= 0 && r < H;
+        const unsigned rb = (unsigned)(kq * HW + r * W) * 4u;
+        o0[i] = (rok && 2 * tx < W) ? rb + 8u * tx : WN_OOB;
+        oe[i] = (rok && ecol >= 0 && ecol < W) ? rb + 4u * ecol : WN_OOB;
+    }
+    const unsigned fo = lane * 16u;
+
+    f32x4 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[p][r] = 0.f;
+    f32x2 pp[2][4], pe[2][4];
+    f32x4 fl[WN_STAGES][4];
+    auto load_patch = [&](int s, int ks) {
+        const int so = ks * 4 * HW * 4;                     // scalar: channels 4 ks ..
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pp[s][i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, o0[i], so, 0));
+            pe[s][i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, oe[i], so, 0));
+        }
+    };
+    auto load_filter = [&](int s, int ks) {
+        const int so = (ct * 32 + ks) * 4096;               // scalar: 4 KB per (channel tile, k-step)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            fl[s][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(fr, fo + q * 1024u, so, 0));
+    };
+    auto transform = [&](int s, float (&v)[16]) {
+        f32x2 A[4], B[4];       // A = (x0, x1);  B = (right, left)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            A[i] = pp[s][i];
+            B[i][0] = dpp_from_right(pe[s][i][0], A[i][0]);
+            B[i][1] = dpp_from_left(pe[s][i][1], A[i][1]);
+        }
+        const f32x2 uA[4] = {pk_sub(A[0], A[2]), pk_add(A[1], A[2]), pk_sub(A[2], A[1]), pk_sub(A[1], A[3])};
+        const f32x2 uB[4] = {pk_sub(B[0], B[2]), pk_add(B[1], B[2]), pk_sub(B[2], B[1]), pk_sub(B[1], B[3])};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x2 v30, v12;
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v30) : "v"(uA[i]), "v"(uB[i]));
+            asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(v12) : "v"(uA[i]));
+            v[4 * i] = v30[1]; v[4 * i + 1] = v12[0]; v[4 * i + 2] = v12[1]; v[4 * i + 3] = v30[0];
+        }
+    };
+    auto put = [&](int half, const float (&vv)[16]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 tq = {vv[4 * q], vv[4 * q + 1], vv[4 * q + 2], vv[4 * q + 3]};
+            ring[((half * 4 + wave) * 4 + q) * 64 + lane] = tq;
+        }
+    };
+    auto get = [&](int half, int st, f32x4 (&bb)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bb[q] = ring[((half * 4 + st) * 4 + q) * 64 + lane];
+    };
+    constexpr int NKS = 32;
+    load_patch(0, wave);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int st = 0; st < WN_STAGES - 1; ++st) {
+        load_filter(st, st);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    load_patch(1, 4 + wave);
+    __builtin_amdgcn_sched_barrier(0);
+    float vt[16];
+    transform(0, vt);
+    put(0, vt);
+    __syncthreads();
+    f32x4 bq[2][4];
+    get(0, 0, bq[0]);
+#ifdef WN_PROF
+    const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
+#endif
+    for (int jj = 0; jj < NKS / 4; jj += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                         // iteration j = jj + u reads ring half u
+            const int j = jj + u;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int ks = 4 * j + st;
+                load_filter((st + WN_STAGES - 1) % WN_STAGES, ks + WN_STAGES - 1 < NKS ? ks + WN_STAGES - 1 : NKS - 1);
+                if (st == 0) {
+                    const int kp = 4 * (j + 2) + wave < NKS ? 4 * (j + 2) + wave : NKS - 4 + wave;
+                    load_patch(u, kp);
+                    transform(u ^ 1, vt);
+                }
+                if (st == 1) put(u ^ 1, vt);
+                if (st < 3) get(u, st + 1, bq[(st + 1) & 1]);
+                else get(u ^ 1, 0, bq[0]);
+#pragma unroll
+                for (int p = 0; p < 16; ++p)
+                    acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(fl[st][p >> 2][p & 3], bq[st & 1][p >> 2][p & 3], acc[p], 0, 0, 0);
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             // 1 MFMA
+                    if (p < (st == 0 ? 12 : 4)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+                    if (p >= 4 && p < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // 1 LDS read
+                    if (st == 1 && p >= 8 && p < 12) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 LDS write
+                    if (st == 0) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                // the transform
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (st == 2) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+#ifdef WN_PROF
+    const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- At M A, BN fold, activation, residuals, store: lane (q4 = l >> 4, tile l & 15) holds channels 16 ct + 4 q4 + r ----
+    const int oy = 2 * ty, ox = 2 * tx;
+    const bool inside = oy < H && ox < W;
+    const bool row1 = oy + 1 < H;
+    const int img_bytes = WN_C * HW * 4;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (size_t)n * WN_C * HW), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1r = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.res1 ? a.res1 + (size_t)n * WN_C * HW : a.x), 0, a.res1 ? img_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2r = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.res2 ? a.res2 + (size_t)n * WN_C * HW : a.x), 0, a.res2 ? img_bytes : 0, 0x00020000);
+    const unsigned lo0 = inside ? (unsigned)((4 * kq * HW + oy * W + ox) * 4) : WN_OOB;
+    const unsigned lo1 = inside && row1 ? lo0 + 4u * W : WN_OOB;
+    const float relu_lo = a.relu ? 0.f : -__builtin_inff();
+    const f32x4 sc4 = *(const f32x4*)(a.scale + 16 * ct + 4 * kq);
+    const f32x4 sh4 = *(const f32x4*)(a.shift + 16 * ct + 4 * kq);
+    f32x2 ra0[4], ra1[4], rb0[4], rb1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int so = (16 * ct + r) * HW * 4;
+        ra0[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r1r, lo0, so, 0));
+        ra1[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r1r, lo1, so, 0));
+        rb0[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r2r, lo0, so, 0));
+        rb1[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r2r, lo1, so, 0));
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float t0[4], t1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float m0 = acc[j][r], m1 = acc[4 + j][r], m2 = acc[8 + j][r], m3 = acc[12 + j][r];
+            t0[j] = m0 + m1 + m2;
+            t1[j] = m1 - m2 - m3;
+        }
+        float o00 = t0[0] + t0[1] + t0[2], o01 = t0[1] - t0[2] - t0[3];
+        float o10 = t1[0] + t1[1] + t1[2], o11 = t1[1] - t1[2] - t1[3];
+        o00 = fmaf(o00, sc4[r], sh4[r]); o01 = fmaf(o01, sc4[r], sh4[r]);
+        o10 = fmaf(o10, sc4[r], sh4[r]); o11 = fmaf(o11, sc4[r], sh4[r]);
+        o00 = fmaxf(o00, relu_lo); o01 = fmaxf(o01, relu_lo); o10 = fmaxf(o10, relu_lo); o11 = fmaxf(o11, relu_lo);
+        f32x2 q0 = {o00, o01}, q1 = {o10, o11};
+        q0 += ra0[r]; q1 += ra1[r];
+        q0 += rb0[r]; q1 += rb1[r];
+        const int so = (16 * ct + r) * HW * 4;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q0), yr, lo0, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q1), yr, lo1, so, 0);
+    }
+#ifdef WN_PROF
+    if (a.prof && lane == 0) {
+        unsigned long long* d = a.prof + 4 * ((size_t)blockIdx.x * 4 + wave);
+        d[0] = t_loop0 - t_entry; d[1] = t_loop1 - t_loop0; d[2] = __builtin_amdgcn_s_memtime() - t_loop1; d[3] = t_entry;
+    }
+#endif
+}
+
 // all the 3x3 filters of a network in one launch (training re-packs every filter every step; 128 five-microsecond
 // launches per step otherwise): layer l reads w_tab[l], writes out + l * WN_PACKED_FLOATS
 __global__ __launch_bounds__(256) void wino_pack_batch_kernel(const float* const* __restrict__ w_tab, float* __restrict__ out,
@@ -629,10 +840,12 @@ __global__ __launch_bounds__(256) void wino_pack_batch_kernel(const float* const
         t[3][b] = g[2][b];
     }
     float* o = o_l + (((size_t)(cout >> 5) * 64 + (cin >> 1)) * 4 * 64 + ((cin & 1) * 32 + (cout & 31))) * 4;
+    float* o16 = o_l + WN_FRAG_FLOATS + (((size_t)(cout >> 4) * 32 + (cin >> 2)) * 4 * 64 + ((cin & 3) * 16 + (cout & 15))) * 4;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         f32x4 q = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
         *(f32x4*)(o + a * 256) = q;
+        *(f32x4*)(o16 + a * 256) = q;
     }
 }
 
@@ -657,6 +870,8 @@ extern "C" int ic_pack_wino3x3_c128_f32(const float* w_tf, float* w_packed, int 
 static unsigned long long* g_wino_prof = nullptr;
 static int g_wino_ksplit = -1;      // -1 automatic, 0 never, 1 always (tuning key 2)
 static int g_wino_xcd = 1;          // tuning key 5
+static int g_wino_t16 = -1;         // tuning key 6: 16 x 16 jobs (wino3x3_c128_t16_kernel): -1 automatic, 0 never, 1 every whole-K group
+static int g_wino_leave_idle = 0;   // tuning key 7: 1 = keep the CUs a partly filled whole-K round leaves idle free (a concurrent branch uses them)
 static int g_wino_share = 1;        // whole-K form: 1 = input transform shared between the waves through LDS (tuning key 4)
 static int g_wino_ratio = 270;      // cost of a whole-K round in K-split rounds, x100 (tuning key 3)
 // tuning only: key 0 = device buffer (as two 32-bit halves: key 0 low, key 1 high) for WN_PROF builds
@@ -668,6 +883,8 @@ extern "C" void ic_wino3x3_c128_set_tuning(int key, int value) {
     if (key == 3) g_wino_ratio = value;
     if (key == 4) g_wino_share = value;
     if (key == 5) g_wino_xcd = value;
+    if (key == 6) g_wino_t16 = value;
+    if (key == 7) g_wino_leave_idle = value;
 }
 
 // One work-group per CU at a time (512 registers per lane), so a launch runs in rounds of 256 work-groups.  A round of
@@ -676,21 +893,35 @@ extern "C" void ic_wino3x3_c128_set_tuning(int key, int value) {
 // of 256 tile groups run whole-K; the remainder r runs whole-K as one partly empty round, or K-split in ceil(r / 64) short
 // rounds when that is cheaper (r <= 128).  A Kodak map (192 groups) is one 75 % full whole-K round; a 64x64 map (32 groups)
 // one K-split round; 272 groups = one full whole-K round + one K-split round (51 us; all whole-K 88, all K-split 72).
-static void wino_plan(long long groups, long long* gw, long long* gk) {
-    if (g_wino_ksplit == 0) { *gw = groups; *gk = 0; return; }
-    if (g_wino_ksplit > 0) { *gw = 0; *gk = groups; return; }
-    const long long r = groups % 256;
-    const bool rem_ksplit = r > 0 && 100 * ((r + 63) / 64) < g_wino_ratio;
-    *gk = rem_ksplit ? r : 0;
-    *gw = groups - *gk;
+static void wino_plan(long long groups, bool even_w, long long* gw, long long* gk, long long* gt) {
+    *gt = 0;
+    if (g_wino_ksplit == 0) { *gw = groups; *gk = 0; }
+    else if (g_wino_ksplit > 0) { *gw = 0; *gk = groups; }
+    else {
+        const long long r = groups % 256;
+        const bool rem_ksplit = r > 0 && 100 * ((r + 63) / 64) < g_wino_ratio;
+        *gk = rem_ksplit ? r : 0;
+        *gw = groups - *gk;
+    }
+    // 16 x 16 jobs (wino3x3_c128_t16_kernel) for a last whole-K round that would leave a quarter or more of the CUs idle --
+    // unless the caller wants exactly those CUs for an independent branch (tuning key 7, see imgcomp_cvpr_amd/streams.py).
+    // Measured on a Kodak map (192 groups): 34.4 against 38.7 us; at full occupancy (256 groups) it is the slower form (47
+    // against 42 us: twice the filter bytes per MFMA clock).
+    static const int env_t16 = getenv("IMGCOMP_WINO_T16") ? atoi(getenv("IMGCOMP_WINO_T16")) : -2;      // A/B runs
+    const int t16 = env_t16 > -2 ? env_t16 : g_wino_t16;
+    const long long r = *gw % 256;
+    if (even_w && (t16 > 0 || (t16 < 0 && !g_wino_leave_idle && r > 128 && r <= 192))) {
+        *gt = t16 > 0 ? *gw : r;
+        *gw -= *gt;
+    }
 }
 
 // work-groups of the launch(es) ic_wino3x3_c128_bn_act_f32 would make for this shape; each occupies one whole CU
 extern "C" long long ic_wino3x3_c128_workgroups(int N, int H, int W) {
     if (N <= 0 || H <= 0 || W <= 0) return 0;
-    long long gw, gk;
-    wino_plan((long long)N * ic_cdiv(H, 4) * ic_cdiv(W, 32), &gw, &gk);
-    return gw + 4 * gk;
+    long long gw, gk, gt;
+    wino_plan((long long)N * ic_cdiv(H, 4) * ic_cdiv(W, 32), (W & 1) == 0, &gw, &gk, &gt);
+    return gt > 0 ? (gw + 4 * gk + 4 * gt > 256 ? gw + 4 * gk + 4 * gt : 256) : gw + 4 * gk;      // the 16 x 16 form fills the chip
 }
 
 extern "C" int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
@@ -703,8 +934,8 @@ extern "C" int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed,
     a.x = x; a.wp = w_packed; a.scale = scale; a.shift = shift; a.res1 = res1; a.res2 = res2; a.y = y;
     a.N = N; a.H = H; a.W = W; a.relu = relu;
     a.grows = ic_cdiv(H, 4); a.gcols = ic_cdiv(W, 32); a.prof = g_wino_prof; a.xcd_runs = g_wino_xcd;
-    long long gw, gk;
-    wino_plan((long long)N * a.grows * a.gcols, &gw, &gk);
+    long long gw, gk, gt;
+    wino_plan((long long)N * a.grows * a.gcols, (W & 1) == 0, &gw, &gk, &gt);
     hipStream_t st = (hipStream_t)stream;
     if (gw > 0) {
         const dim3 grid((unsigned)gw);
@@ -713,9 +944,13 @@ extern "C" int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed,
         else if ((W & 1) == 0) hipLaunchKernelGGL(wino3x3_c128_kernel<true>, grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(wino3x3_c128_kernel<false>, grid, dim3(256), 0, st, a);
     }
+    if (gt > 0) {
+        a.g0 = (int)gw;
+        hipLaunchKernelGGL(wino3x3_c128_t16_kernel, dim3((unsigned)(4 * gt)), dim3(256), 0, st, a);
+    }
     if (gk > 0) {
         const dim3 grid((unsigned)(gk * 4));
-        a.g0 = (int)gw;
+        a.g0 = (int)(gw + gt);
         if ((W & 1) == 0) hipLaunchKernelGGL(wino3x3_c128_ksplit_kernel<true>, grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(wino3x3_c128_ksplit_kernel<false>, grid, dim3(256), 0, st, a);
     }

@@ -13,7 +13,9 @@ context model completely (tools/bench_cumask.py: 3.15 -> 2.98 ms per Kodak image
         side = bs.context_model_stream(N, H, W)
         side.wait_stream(bs.main)
         with torch.cuda.stream(side): ... pc.bitcost(...)
+        bs.reserve_idle_cus(side is not bs._plain)
         x_out = ae.decode(enc.qhard)
+        bs.reserve_idle_cus(False)
         bs.main.wait_stream(side)
 """
 import ctypes
@@ -36,7 +38,9 @@ class BranchStreams(object):
 
     def idle_cus(self, N, H, W):
         """CUs the decoder's 3x3 launches leave idle for an (N, 3, H, W) image, rounded down to whole CUs per XCD."""
+        _lib.lib.ic_wino3x3_c128_set_tuning(7, 1)          # the plan the decoder runs when it leaves its idle CUs alone
         wgs = int(_lib.lib.ic_wino3x3_c128_workgroups(N, H // 4, W // 4))
+        _lib.lib.ic_wino3x3_c128_set_tuning(7, 0)
         if wgs <= 0 or wgs >= self.n_cus:
             return 0
         return min((self.n_cus - wgs) // 8 * 8, self.n_cus // 2)
@@ -55,6 +59,11 @@ class BranchStreams(object):
                 self._handles.append(h)
                 self._ranged[n] = torch.cuda.ExternalStream(h.value, device=self.device)
         return self._ranged[n]
+
+    def reserve_idle_cus(self, on):
+        """Around the launches of the branch that shares the chip with a CU-range stream: its partly filled 3x3 rounds stay
+        whole-K (one work-group per CU, the idle CUs untouched) instead of being spread over every CU as 16 x 16 jobs."""
+        _lib.lib.ic_wino3x3_c128_set_tuning(7, 1 if on else 0)
 
     def close(self):
         for h in self._handles:

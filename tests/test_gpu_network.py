@@ -332,7 +332,10 @@ def test_branch_streams_cu_range(cuda, configs, syn_weights, nets):
     bs = streams.BranchStreams(cuda)
     try:
         # Kodak: 192 whole-K work-groups -> on a 256-CU MI355X a quarter of the chip is idle; 4K: the decoder fills every round
-        wgs = int(_lib.lib.ic_wino3x3_c128_workgroups(1, 128, 192))
+        assert int(_lib.lib.ic_wino3x3_c128_workgroups(1, 128, 192)) >= 256      # alone, the layer is spread over the whole chip
+        bs.reserve_idle_cus(True)
+        wgs = int(_lib.lib.ic_wino3x3_c128_workgroups(1, 128, 192))             # next to a CU-range stream it stays whole-K
+        bs.reserve_idle_cus(False)
         assert wgs == 192
         expect = min((bs.n_cus - wgs) // 8 * 8, bs.n_cus // 2) if wgs < bs.n_cus else 0
         assert bs.idle_cus(1, 512, 768) == expect
@@ -356,7 +359,9 @@ def test_branch_streams_cu_range(cuda, configs, syn_weights, nets):
                 side.wait_stream(bs.main)
                 with torch.cuda.stream(side):
                     bpp = bits.bitcost_to_bpp(pc.bitcost(enc.qbar, enc.symbols, False, pad_value=pad), x)
+                bs.reserve_idle_cus(True)
                 out = ae.decode(enc.qhard, False)
+                bs.reserve_idle_cus(False)
                 bs.main.wait_stream(side)
         outer.wait_stream(bs.main)
         torch.cuda.synchronize()

@@ -214,7 +214,8 @@ def test_conv3x3_c128_auto_selection(cuda):
     """one packed blob, both forms: Winograd wherever its 31-bit addressing reaches, the direct form beyond; the
     override works, and both give the oracle's result through the same entry point."""
     L = _lib()
-    assert L.lib.ic_conv3x3_c128_both_packed_floats() == 9 * 128 * 128 + 16 * 128 * 128
+    # direct fragments + the Winograd fragments in both layouts (32-channel tiles | 16-channel tiles)
+    assert L.lib.ic_conv3x3_c128_both_packed_floats() == 9 * 128 * 128 + 2 * 16 * 128 * 128
     assert L.lib.ic_conv3x3_c128_pick_algo(1, 16, 16) == 1              # K-split work-groups serve small maps
     assert L.lib.ic_conv3x3_c128_pick_algo(1, 128, 192) == 1
     assert L.lib.ic_conv3x3_c128_pick_algo(32, 32, 32) == 1
@@ -422,18 +423,19 @@ def test_conv3x3_c128_forms_agree_on_random_shapes(cuda):
             x = torch.randn((N, 128, H, W), device=cuda)
             r = torch.randn((N, 128, H, W), device=cuda)
             outs = []
-            # direct, Winograd whole-K (transform shared through LDS / per wave), Winograd K-split
-            for algo, ks, share in ((0, -1, 1), (1, 0, 1), (1, 1, 1), (1, 0, 0)):
+            # direct, Winograd whole-K (transform shared through LDS / per wave), Winograd K-split, 16 x 16 jobs (even widths)
+            for algo, ks, share, t16 in ((0, -1, 1, 0), (1, 0, 1, 0), (1, 1, 1, 0), (1, 0, 0, 0), (1, -1, 1, 1)):
                 L.lib.ic_conv3x3_c128_set_algo(algo)
                 L.lib.ic_wino3x3_c128_set_tuning(2, ks)
                 L.lib.ic_wino3x3_c128_set_tuning(4, share)
+                L.lib.ic_wino3x3_c128_set_tuning(6, t16)
                 y = torch.full((N, 128, H, W), float('nan'), device=cuda)
                 L.check(L.lib.ic_conv3x3_c128_auto_f32(L.ptr(x), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(r), None, L.ptr(y),
                                                        N, H, W, 1, L.current_stream()))
                 outs.append(y)
             torch.cuda.synchronize()
             scale_ = max(1.0, float(outs[0].abs().max()))
-            for k in (1, 2, 3):
+            for k in (1, 2, 3, 4):
                 err = float((outs[k] - outs[0]).abs().max()) / scale_
                 assert err < 2e-5, 'shape {} form {}: {}'.format((N, H, W), k, err)
             assert bool(torch.isfinite(outs[2]).all())
@@ -443,6 +445,7 @@ def test_conv3x3_c128_forms_agree_on_random_shapes(cuda):
         L.lib.ic_conv3x3_c128_set_algo(-1)
         L.lib.ic_wino3x3_c128_set_tuning(2, -1)
         L.lib.ic_wino3x3_c128_set_tuning(4, 1)
+        L.lib.ic_wino3x3_c128_set_tuning(6, 0)
 
 
 def test_edge_layers_random_shapes(cuda):

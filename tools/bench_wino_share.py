@@ -14,9 +14,10 @@ _lib.check(lib.ic_pack_wino3x3_c128_f32(_lib.ptr(wt), _lib.ptr(ww), 0, st))
 sc = torch.rand(128, device=dev) + 0.5; sh = torch.randn(128, device=dev)
 lib.ic_wino3x3_c128_set_tuning(2, 0)
 outs = []
-for share in (0, 1, 2, 1, 2):
+for share in (0, 2, 3, 2, 3):
     lib.ic_wino3x3_c128_set_tuning(4, 1 if share else 0)
-    lib.ic_wino3x3_c128_set_tuning(5, 1 if share == 2 else 0)
+    lib.ic_wino3x3_c128_set_tuning(5, 1 if share >= 2 else 0)
+    lib.ic_wino3x3_c128_set_tuning(6, 1 if share == 3 else 0)
     y = torch.full_like(x, float('nan'))
     def run():
         _lib.check(lib.ic_wino3x3_c128_bn_act_f32(_lib.ptr(x), _lib.ptr(ww), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(r), None, _lib.ptr(y), n, h, w, 1, st))
@@ -27,5 +28,5 @@ for share in (0, 1, 2, 1, 2):
     for _ in range(64): run()
     e1.record(); torch.cuda.synchronize()
     outs.append(y)
-    print('share %d (2 = shared + XCD runs): %.2f us' % (share, e0.elapsed_time(e1) / 64 * 1e3))
-print('max |diff| = %.3e  identical %s  nan %d' % ((outs[0] - outs[1]).abs().max().item(), bool(torch.equal(outs[0], outs[1])), int(torch.isnan(outs[1]).sum())))
+    print('form %d (0 per-wave, 2 shared + XCD runs, 3 = 16x16 jobs): %.2f us' % (share, e0.elapsed_time(e1) / 64 * 1e3))
+print('max |diff| 0 vs 2 = %.3e, 2 vs 3 = %.3e  nan %d' % ((outs[0] - outs[1]).abs().max().item(), (outs[1] - outs[2]).abs().max().item(), int(torch.isnan(outs[2]).sum())))
