@@ -115,7 +115,9 @@ int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed, const floa
  * 1 K-split: one channel tile per work-group, 4 quarters of the input channels summed through LDS after the output
  * transform).  Automatic: full rounds of 256 tile groups whole-K, a remainder of <= 128 groups as a second, K-split launch;
  * key 3 = cost of a whole-K round in K-split rounds x 100 (default 270) for that choice; key 4 = whole-K input transform
- * shared through LDS (default 1); key 5 = XCD-contiguous tile order (default 1); keys 0, 1: profiling
+ * shared through LDS (default 1); key 5 = XCD-contiguous tile order (default 1); key 6 = 16 x 16 jobs on
+ * v_mfma_f32_16x16x4_f32 (-1 automatic: a last whole-K round that would leave >= 1/4 of the CUs idle; 0 never; 1 always);
+ * key 7 = 1: leave those CUs idle (a caller's concurrent branch runs there, ic_stream_create_cu_range); keys 0, 1: profiling
  * builds. */
 void ic_wino3x3_c128_set_tuning(int key, int value);
 /* work-groups of the launch above for this shape; each occupies one whole CU (what a caller sizing a CU-range stream
