@@ -98,9 +98,11 @@ int ic_conv3x3_c128_set_tuning(int key, int value);
 void ic_conv3x3_c128_set_debug_buffer(void* dev_u64);
 
 /* The same layer (3x3, stride 1, 128 -> 128, autoencoder.py:274-287) in Winograd F(2x2,3x3) form: 16/36 of the
- * multiply-adds of the direct form, each wave transforming its own input patches in registers (no LDS, no barrier).
- * Same contract as ic_conv3x3_c128_bn_act_f32 with its own packed filter (16 x 128 x 128 floats = G g Gt in MFMA
- * A-fragment order); backward != 0 packs the adjoint filter used for the data gradient in training.
+ * multiply-adds of the direct form; input transforms in registers, shared between the waves of a work-group through LDS.
+ * Same contract as ic_conv3x3_c128_bn_act_f32 with its own packed filter: G g Gt (16 x 128 x 128 floats) in MFMA
+ * A-fragment order, stored twice -- for v_mfma_f32_32x32x2_f32 and for v_mfma_f32_16x16x4_f32 work-groups -- so
+ * ic_wino3x3_c128_packed_floats() = 2 x 16 x 128 x 128; backward != 0 packs the adjoint filter used for the data
+ * gradient in training.
  * Results differ from the direct form by fp32 rounding only (both within 1e-4 of the float64 oracle). */
 size_t ic_wino3x3_c128_packed_floats(void);
 int ic_pack_wino3x3_c128_f32(const float* w_tf, float* w_packed, int backward, ic_stream_t stream);
