@@ -8,15 +8,20 @@ A "step" is one pass of the hot path over one batch of synthetic input: BASELINE
 Inputs and weights are resident in HBM before the timed region.  Data: seeded synthetic image and
 random-init weights (no network for Kodak or the 0515_1103 checkpoint).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            (--mode train: one cfg3 training step per step)
 N > 1 is launched by torch.distributed.run, one rank per GPU; the path shards by image (independent
 units, no data-path collective), so every rank runs the same per-GPU workload: weak scaling.
 
-Prints ONE JSON line on rank 0 (see the contract in the task statement) with two extra objects:
-  roofline     -- the dominant kernel (3x3 128->128 conv on the fp32 matrix cores): algorithmic FLOP per
-                  launch / average launch duration measured with HIP events on the launch stream
-  cpu_baseline -- the CPU oracle (torch fp32 restatement of the reference, all host cores) timed on a
-                  bounded sample of the same workload (rank 0, N = 1 only)
+Prints ONE JSON line on rank 0 (see the contract in the task statement) with extra objects:
+  roofline               -- the dominant kernel (3x3 128->128 conv on the fp32 matrix cores), timed IN-STEP: HIP events on
+                            the launch stream around the 32-layer residual stack of the encoder / of the decoder, cycling
+                            the 32 real packed filters, / 32.  `achieved` = FLOPs the matrix pipe executes (Winograd:
+                            16/36 of the direct form's) / that time; `frac` = achieved / 157.3 TFLOP/s, <= 1 by
+                            construction; the direct-form (SURVEY 8(d) algorithmic) figure is kept under `direct_equivalent_*`
+  roofline_context_model -- the same for the masked-3D-conv context model, standalone
+  shapes                 -- the north_star's 256x256 shape (batch 1 and 8) through the same step
+  cpu_baseline           -- the CPU oracle (torch fp32 restatement of the reference) timed on a bounded sample of the same
+                            workload (rank 0, N = 1 only)
 """
 import argparse
 import ctypes
@@ -29,24 +34,77 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 # algorithmic work per input pixel, C = 32 (FLOP = 2 MAC, dense, mask-agnostic, halo-free)
 FLOP_PER_PX_ENC = 621124.0
 FLOP_PER_PX_DEC = 618976.0
-FLOP_PER_SYMBOL_PC = 47520.0
-CONV3_FLOP_PER_OUT_PX = 2.0 * 9 * 128 * 128      # per 128-channel output pixel of one 3x3 layer
+FLOP_PER_SYMBOL_PC = 47520.0             # dense; 36,912 counting only the live taps of the causal masks
+FLOP_PER_SYMBOL_PC_LIVE = 36912.0
+CONV3_FLOP_PER_OUT_PX = 2.0 * 9 * 128 * 128      # per 128-channel output pixel of one 3x3 layer, direct form
+
+FORM_NAMES = {0: 'automatic'}
+
+
+def conv3_scopes(W, ae_cfg, which):
+    root = W.ENC if which == 'enc' else W.DEC
+    return [s for s, kind, shape in W.ae_conv_specs(int(ae_cfg.num_chan_bn), int(ae_cfg.arch_param_B), bool(ae_cfg.heatmap))
+            if s.startswith(root) and tuple(shape) == (3, 3, 128, 128)]
+
+
+class Pipeline(object):
+    """encode -> (bitcost on the side stream || decode) of one batch, the val.py wiring."""
+
+    def __init__(self, dev, ae_config='low', share='cu_range', seed=0):
+        import torch
+        from imgcomp_cvpr_amd import autoencoder, probclass, config_parser as cp, weights as W, streams
+        self.torch, self.dev, self.W = torch, dev, W
+        self.ae_cfg, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', ae_config))
+        self.pc_cfg, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
+        self.wts = W.synthetic_weights(self.ae_cfg, self.pc_cfg)
+        self.ae = autoencoder.get_network_cls(self.ae_cfg)(self.ae_cfg).load_weights(self.wts, dev)
+        self.pc = probclass.get_network_cls(self.pc_cfg)(self.pc_cfg, num_centers=self.ae_cfg.num_centers).load_weights(self.wts, dev)
+        self.pad_value = float(self.wts['autoencoder/encoder/centers'][0])
+        self.branch = streams.BranchStreams(dev, share=share)
+        self.seed = seed
+
+    def set_input(self, N, H, Wd):
+        self.N, self.H, self.Wd = N, H, Wd
+        self.x_np = self.W.synthetic_image((N, 3, H, Wd), 'natural', seed=self.seed)
+        self.x = self.torch.as_tensor(self.x_np).float().to(self.dev)
+        self.side = self.branch.context_model_stream(N, H, Wd)
+        self.dec_flags = self.branch.decode_flags(self.side)
+        return self
+
+    def step(self):
+        from imgcomp_cvpr_amd import bits
+        torch = self.torch
+        cur = torch.cuda.current_stream(self.dev)
+        enc = self.ae.encode(self.x, is_training=False)
+        self.side.wait_stream(cur)
+        with torch.cuda.stream(self.side):
+            bc = self.pc.bitcost(enc.qbar, enc.symbols, is_training=False, pad_value=self.pad_value)
+            bpp = bits.bitcost_to_bpp(bc, self.x)
+        # per-call plan flag: next to a CU-range side stream the decoder's 3x3 launches leave that stream's CUs alone
+        x_out = self.ae.decode(enc.qhard, is_training=False, plan_flags=self.dec_flags)
+        cur.wait_stream(self.side)
+        return bpp, x_out
 
 
 def main():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=20)
-    p.add_argument('--warmup', type=int, default=3)
+    p.add_argument('--steps', type=int, default=50)
+    p.add_argument('--warmup', type=int, default=5)
     p.add_argument('--height', type=int, default=512)
     p.add_argument('--width', type=int, default=768)
     p.add_argument('--batch', type=int, default=1)
     p.add_argument('--ae_config', default='low')
+    p.add_argument('--mode', default='infer', choices=['infer', 'train'])
+    p.add_argument('--share', default='auto', choices=['auto', 'cu_range', 'full_chip'],
+                   help='how decoder and context model share the chip (imgcomp_cvpr_amd/streams.py); auto = the package default')
     p.add_argument('--no_cpu_baseline', action='store_true')
+    p.add_argument('--no_extras', action='store_true', help='headline only: no stage split, roofline, extra shapes (rocprofv3 runs)')
+    p.add_argument('--pipelined', action='store_true', help='also run the informational three-pipelines-in-flight section')
     a = p.parse_args()
 
     import torch
@@ -61,71 +119,52 @@ def main():
     if world > 1:
         dist.init_process_group('nccl', device_id=dev)
 
-    from imgcomp_cvpr_amd import autoencoder, probclass, bits, config_parser as cp, weights as W, _lib
+    if a.mode == 'train':
+        return train_main(a, dev, rank, world)
+
+    from imgcomp_cvpr_amd import weights as W, _lib, streams
     lib = _lib.lib
-    ae_cfg, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', a.ae_config))
-    pc_cfg, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
-    wts = W.synthetic_weights(ae_cfg, pc_cfg)
-    ae = autoencoder.get_network_cls(ae_cfg)(ae_cfg).load_weights(wts, dev)
-    pc = probclass.get_network_cls(pc_cfg)(pc_cfg, num_centers=ae_cfg.num_centers).load_weights(wts, dev)
+    share = streams.DEFAULT_SHARE if a.share == 'auto' else a.share
+    pipe = Pipeline(dev, a.ae_config, share, seed=rank).set_input(a.batch, a.height, a.width)
+    ae, pc, ae_cfg = pipe.ae, pipe.pc, pipe.ae_cfg
     N, H, Wd = a.batch, a.height, a.width
-    x_np = W.synthetic_image((N, 3, H, Wd), 'natural', seed=rank)
-    x = torch.as_tensor(x_np).float().to(dev)
-    pad_value = float(wts['autoencoder/encoder/centers'][0])
-
-    # The context model and the decoder both hang off the encoder output and do not depend on each other (val.py:85-89):
-    # the bitcost goes on a second HIP stream restricted to the CUs the decoder's one-work-group-per-CU 3x3 launches
-    # leave idle (imgcomp_cvpr_amd/streams.py; a Kodak map: 64 of 256 CUs), the same arrangement val.py runs.
-    from imgcomp_cvpr_amd import streams
-    branch = streams.BranchStreams(dev)
-    side = branch.context_model_stream(N, H, Wd)
     torch.cuda.synchronize(dev)
-    torch.cuda.set_stream(branch.main)      # CU-range streams are blocking with respect to the legacy default stream
-
-    def step():
-        cur = torch.cuda.current_stream(dev)
-        enc = ae.encode(x, is_training=False)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            bc = pc.bitcost(enc.qbar, enc.symbols, is_training=False, pad_value=pad_value)
-            bpp = bits.bitcost_to_bpp(bc, x)
-        branch.reserve_idle_cus(side is not branch._plain)     # the decoder's 3x3 launches leave the side stream's CUs alone
-        x_out = ae.decode(enc.qhard, is_training=False)
-        branch.reserve_idle_cus(False)
-        cur.wait_stream(side)
-        return bpp, x_out
+    torch.cuda.set_stream(pipe.branch.main)      # CU-range streams are blocking with respect to the legacy default stream
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(a.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        bpp, x_out = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def run(pl, steps, warmup):
+        for _ in range(warmup):
+            pl.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = pl.step()
+        barrier()
+        return time.perf_counter() - t0, out
+
+    elapsed, (bpp, x_out) = run(pipe, a.steps, a.warmup)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    pixels_per_step = N * H * Wd * world
-    value = pixels_per_step * a.steps / elapsed / 1e6
+    value = N * H * Wd * world * a.steps / elapsed / 1e6
 
-    # ---- stage split and the dominant kernel, HIP events on the launch stream (rank 0) ----
-    extra = {'context_model_stream_cus': branch.idle_cus(N, H, Wd) if side is not branch._plain else 0}
-    roofline = None
-    if rank == 0:
+    cus = pipe.branch.idle_cus(N, H, Wd) if pipe.side is not pipe.branch._plain else 0
+    extra = {'branch_sharing': share, 'context_model_stream_cus': cus, 'bpp_synthetic': round(float(bpp), 5)}
+    roofline = roofline_pc = None
+    if rank == 0 and not a.no_extras:
         st = _lib.current_stream(dev)
         ev = [ctypes.c_void_p() for _ in range(2)]
         for e in ev:
             _lib.check(lib.ic_event_create(ctypes.byref(e)))
 
-        def timed(fn, reps):
-            fn()
+        def timed(fn, reps, warm=2):
+            for _ in range(warm):
+                fn()
             torch.cuda.synchronize(dev)
             _lib.check(lib.ic_event_record(ev[0], st))
             for _ in range(reps):
@@ -135,98 +174,132 @@ def main():
             _lib.check(lib.ic_event_elapsed_ms(ev[0], ev[1], ctypes.byref(ms)))
             return ms.value / reps
 
-        enc = ae.encode(x, False)
-        ms_enc = timed(lambda: ae.encode(x, False), 5)
-        ms_pc = timed(lambda: pc.bitcost(enc.qbar, enc.symbols, False, pad_value=pad_value), 5)
-        ms_dec = timed(lambda: ae.decode(enc.qhard, False), 5)
+        # ---- stage split (each stage alone on the stream) ----
+        enc = ae.encode(pipe.x, False)
+        ms_enc = timed(lambda: ae.encode(pipe.x, False), 10)
+        ms_pc = timed(lambda: pc.bitcost(enc.qbar, enc.symbols, False, pad_value=pipe.pad_value), 20)
+        ms_dec = timed(lambda: ae.decode(enc.qhard, False), 10)
+        ms_dec_shared = timed(lambda: ae.decode(enc.qhard, False, plan_flags=pipe.dec_flags), 10) if pipe.dec_flags else ms_dec
         extra.update({'ms_encode': round(ms_enc, 4), 'ms_pc_bitcost': round(ms_pc, 4), 'ms_decode': round(ms_dec, 4),
-                      'bpp_synthetic': round(float(bpp), 5)})
-        # dominant kernel: the shape the residual stacks run at, (N,128,H/4,W/4)
+                      'ms_decode_with_step_flags': round(ms_dec_shared, 4)})
+
+        # ---- dominant kernel, in-step: the 32-layer residual stack with its own 32 filters, launch pattern of network.hip ----
         h4, w4 = H // 4, Wd // 4
-        xin = torch.randn((N, 128, h4, w4), device=dev)
-        res = torch.randn((N, 128, h4, w4), device=dev)
-        yout = torch.empty_like(xin)
-        wpk, sc, sh = ae._plan['autoencoder/encoder/res_block_enc_0/enc_0_1/conv2']
-        def conv():
-            _lib.check(lib.ic_conv3x3_c128_auto_f32(_lib.ptr(xin), _lib.ptr(wpk), _lib.ptr(sc), _lib.ptr(sh),
-                                                    _lib.ptr(res), None, _lib.ptr(yout), N, h4, w4, 0, st))
-        ms_conv = timed(conv, 64)
-        flop = CONV3_FLOP_PER_OUT_PX * N * h4 * w4
-        achieved = flop / (ms_conv * 1e-3) / 1e12
-        wino = lib.ic_conv3x3_c128_pick_algo(N, h4, w4) == 1
-        # 'achieved' counts the ALGORITHMIC (direct-form) multiply-adds of the layer; the Winograd
-        # form issues 16/36 of them to the matrix cores -- 'executed_*' is what the MFMA pipe actually did.
-        executed = achieved * (16.0 / 36.0 if wino else 1.0)
-        # HBM-side bytes per launch: PMC counters cannot be read from inside this process; they are collected with
-        # rocprofv3 --pmc on the same kernel and shape (tools/pmc_wino.sh) and committed under profiles/
-        traffic, traffic_src = None, None
+        bufs = [torch.randn((N, 128, h4, w4), device=dev) * 0.5 for _ in range(5)]
+
+        def res_stack(which, flags):
+            plan = [ae._plan[s] for s in conv3_scopes(W, ae_cfg, which)]
+            B = int(ae_cfg.arch_param_B)
+
+            def conv(src, li, r1, r2, dst, relu):
+                wpk, sc, sh = plan[li]
+                _lib.check(lib.ic_conv3x3_c128_auto_f32(_lib.ptr(bufs[src]), _lib.ptr(wpk), _lib.ptr(sc), _lib.ptr(sh),
+                                                        _lib.ptr(bufs[r1]) if r1 is not None else None,
+                                                        _lib.ptr(bufs[r2]) if r2 is not None else None,
+                                                        _lib.ptr(bufs[dst]), N, h4, w4, relu, flags, st))
+
+            def go():
+                cur, li = 0, 0
+                for b in range(B):
+                    G = cur
+                    for i in range(3):
+                        O = next(o for o in (1, 2, 3) if o != G and o != cur)
+                        conv(cur, li, None, None, 4, 1)
+                        conv(4, li + 1, cur, G if i == 2 else None, O, 0)
+                        cur, li = O, li + 2
+                O = next(o for o in (1, 2, 3) if o != cur)
+                conv(cur, li, None, None, 4, 0)
+                conv(4, li + 1, cur, 0, O, 0)
+            return go, len(plan)
+
+        def layer_entry(which, flags):
+            go, nl = res_stack(which, flags)
+            ms = timed(go, 6) / nl
+            flop_direct = CONV3_FLOP_PER_OUT_PX * N * h4 * w4
+            wino = lib.ic_conv3x3_c128_pick_algo(N, h4, w4, flags) == 1
+            executed = flop_direct * (16.0 / 36.0 if wino else 1.0)
+            return {'avg_launch_us': round(ms * 1e3, 2), 'layers_timed': nl,
+                    'achieved': round(executed / (ms * 1e-3) / 1e12, 2),
+                    'frac': round(executed / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                    'direct_equivalent_tflops': round(flop_direct / (ms * 1e-3) / 1e12, 2),
+                    'direct_equivalent_frac': round(flop_direct / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                    'executed_flop_per_launch': executed, 'plan': plan_name(lib, _lib, N, h4, w4, flags)}
+
+        enc_l = layer_entry('enc', 0)
+        dec_l = layer_entry('dec', pipe.dec_flags)
+        # PMC counters cannot be read from inside this process: rocprofv3 --pmc passes over `bench.py --no_extras`
+        # (tools/profile.sh) write profiles/r02_conv3x3_traffic.json, keyed by kernel name and shape
+        traffic = traffic_src = None
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_conv3x3_traffic.json')) as f:
+            with open(os.path.join(ROOT, 'profiles', 'r02_conv3x3_traffic.json')) as f:
                 tj = json.load(f)
-            if tj['shape'] == [N, 128, h4, w4]:
-                e = tj['winograd F(2x2,3x3)' if wino else 'direct']
-                traffic, traffic_src = e['fetch_bytes'] + e['write_bytes'], tj['source']
+            ent = tj['kernels'].get(enc_l['plan']['kernel'])
+            if ent and tj['shape'] == [N, 128, h4, w4]:
+                traffic, traffic_src = ent['hbm_bytes_per_launch'], tj['source']
+                extra['conv3x3_l2_to_l1_bytes_per_launch'] = ent.get('l2_to_l1_bytes_per_launch')
         except (IOError, OSError, KeyError, ValueError):
             pass
-        groups = N * (-(-h4 // 4)) * (-(-w4 // 32))
-        t16 = wino and lib.ic_wino3x3_c128_workgroups(N, h4, w4) >= 256 > groups
-        roofline = {'kernel': (('wino3x3_c128_t16_kernel' if t16 else 'wino3x3_c128_shared_kernel') if wino else 'conv3x3_c128_kernel') + ' (ic_conv3x3_c128_auto_f32)',
+        wino = lib.ic_conv3x3_c128_pick_algo(N, h4, w4, 0) == 1
+        roofline = {'kernel': enc_l['plan']['kernel'] + ' (ic_conv3x3_c128_auto_f32, encoder residual stack, in-step)',
                     'algorithm': 'winograd F(2x2,3x3)' if wino else 'direct', 'bound': 'mfma',
-                    'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_unit': 'bytes per launch',
-                    'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': int(3 * 512 * N * h4 * w4 + (1048576 if wino else 589824)),
-                    'executed_tflops': round(executed, 2), 'executed_frac': round(executed / PEAK_F32_MFMA_TFLOPS, 4),
-                    'avg_launch_us': round(ms_conv * 1e3, 2), 'flop_per_launch': flop,
-                    'launches_per_step': 2 * (6 * int(ae_cfg.arch_param_B) + 2)}
+                    'achieved': enc_l['achieved'], 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': enc_l['frac'],
+                    'traffic': traffic, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': traffic_src,
+                    'algorithmic_bytes_per_launch': int(3 * 512 * N * h4 * w4 + (1048576 if wino else 589824)),
+                    'launches_per_step': 2 * (6 * int(ae_cfg.arch_param_B) + 2),
+                    'note': 'achieved = FLOPs the matrix pipe executes (Winograd: 16/36 of the direct form) / in-step launch time',
+                    'encoder': enc_l, 'decoder': dec_l}
+        sym = N * int(ae_cfg.num_chan_bn) * (H // 8) * (Wd // 8)
+        roofline_pc = {'kernel': 'context model, 4 masked conv3d layers + cross-entropy (ic_pc_bitcost_f32), standalone',
+                       'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': PEAK_F32_MFMA_TFLOPS,
+                       'achieved': round(FLOP_PER_SYMBOL_PC_LIVE * sym / (ms_pc * 1e-3) / 1e12, 2),
+                       'frac': round(FLOP_PER_SYMBOL_PC_LIVE * sym / (ms_pc * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                       'dense_algorithmic_tflops': round(FLOP_PER_SYMBOL_PC * sym / (ms_pc * 1e-3) / 1e12, 2),
+                       'dense_algorithmic_frac': round(FLOP_PER_SYMBOL_PC * sym / (ms_pc * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                       'ms': round(ms_pc, 4), 'symbols': sym,
+                       'note': 'achieved counts the live taps of the causal masks (36,912 FLOP/symbol); SURVEY 8(d) dense figure 47,520 alongside'}
         for e in ev:
             lib.ic_event_destroy(e)
-        # Extra, NOT the contract value: the same step with three independent batch-1 pipelines in flight (one stream and
-        # one set of workspaces each).  A Kodak-sized 3x3 launch fills 768 of the 1024 SIMDs; kernels of the other
-        # pipelines take the rest.  `value` above stays the strictly sequential single-stream number.
-        try:
-            pipes = [(ae, pc, torch.cuda.Stream(device=dev))]
-            for _ in range(2):
-                ae2 = autoencoder.get_network_cls(ae_cfg)(ae_cfg).load_weights(wts, dev)
-                pc2 = probclass.get_network_cls(pc_cfg)(pc_cfg, num_centers=ae_cfg.num_centers).load_weights(wts, dev)
-                pipes.append((ae2, pc2, torch.cuda.Stream(device=dev)))
 
-            def one(aei, pci):
-                e = aei.encode(x, is_training=False)
-                b = pci.bitcost(e.qbar, e.symbols, is_training=False, pad_value=pad_value)
-                bits.bitcost_to_bpp(b, x)
-                return aei.decode(e.qhard, is_training=False)
-            torch.cuda.synchronize(dev)
-            for i in range(6):
-                with torch.cuda.stream(pipes[i % 3][2]):
-                    one(*pipes[i % 3][:2])
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            n_img = 36
-            for i in range(n_img):
-                with torch.cuda.stream(pipes[i % 3][2]):
-                    one(*pipes[i % 3][:2])
-            torch.cuda.synchronize(dev)
-            dt3 = time.perf_counter() - t1
-            extra['pipelined_3_streams'] = {'value': round(N * H * Wd * n_img / dt3 / 1e6, 3), 'unit': 'Mpix/s',
-                                            'ms_per_image': round(dt3 / n_img * 1e3, 4), 'images': n_img,
-                                            'note': 'three independent batch-1 pipelines in flight on one GPU; not the contract value'}
-        except Exception as ex:                                       # informational only
-            extra['pipelined_3_streams'] = {'error': str(ex)[:200]}
+        # ---- the other sharing arrangement and the north_star's 256x256 shape through the same step() ----
+        other = 'full_chip' if share == 'cu_range' else 'cu_range'
+        try:
+            po = Pipeline(dev, a.ae_config, other, seed=rank).set_input(N, H, Wd)
+            dt, _ = run(po, 20, 3)
+            extra['other_branch_sharing'] = {'share': other, 'value': round(N * H * Wd * 20 / dt / 1e6, 3), 'unit': 'Mpix/s',
+                                             'ms_per_step': round(dt / 20 * 1e3, 4)}
+            po.branch.close()
+        except Exception as ex:                                        # informational only
+            extra['other_branch_sharing'] = {'error': str(ex)[:200]}
+        shapes = []
+        for (n2, h2, w2) in ((1, 256, 256), (8, 256, 256)):
+            if (n2, h2, w2) == (N, H, Wd):
+                continue
+            ps = Pipeline(dev, a.ae_config, share, seed=rank).set_input(n2, h2, w2)
+            dt, _ = run(ps, 30, 5)
+            flop = n2 * h2 * w2 * (FLOP_PER_PX_ENC * 16.0 / 36.0 + FLOP_PER_PX_DEC * 16.0 / 36.0)
+            shapes.append({'batch': n2, 'height': h2, 'width': w2, 'value': round(n2 * h2 * w2 * 30 / dt / 1e6, 3), 'unit': 'Mpix/s',
+                           'ms_per_step': round(dt / 30 * 1e3, 4),
+                           'executed_frac_of_mfma_peak_whole_step': round(flop * 30 / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                           'plan_3x3': plan_name(lib, _lib, n2, h2 // 4, w2 // 4, 0)['kernel']})
+            ps.branch.close()
+        extra['shapes'] = shapes
+        if a.pipelined:
+            extra['pipelined_3_streams'] = pipelined_section(torch, dev, a, N, H, Wd, pipe)
 
     # ---- CPU baseline: the oracle on the host cores (rank 0, N == 1 only) ----
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.no_extras:
         from oracle import oracle as O
         # torch's CPU conv kernels oversubscribe badly beyond a few dozen threads on the 256-core host
-        # (tools/cpu_threads.py: 16 threads is the fastest setting measured on the MI355X box)
+        # (16 threads is the fastest setting measured on the MI355X box)
         cores = min(os.cpu_count() or 1, 16)
         torch.set_num_threads(cores)
-        sample = x_np[:1]
+        sample = pipe.x_np[:1]
         with torch.no_grad():
-            O.validate_forward(sample[:, :, :64, :64], wts, ae_cfg.as_dict(), torch.float32)     # warm-up (primitive caches)
+            O.validate_forward(sample[:, :, :64, :64], pipe.wts, ae_cfg.as_dict(), torch.float32)     # warm-up (primitive caches)
             runs, t1 = 0, time.perf_counter()
             while runs < 3 or (time.perf_counter() - t1 < 10.0 and runs < 200):
-                O.validate_forward(sample, wts, ae_cfg.as_dict(), torch.float32)
+                O.validate_forward(sample, pipe.wts, ae_cfg.as_dict(), torch.float32)
                 runs += 1
             dt = (time.perf_counter() - t1) / runs
         cpu = {'value': round(sample.shape[2] * sample.shape[3] / dt / 1e6, 4), 'unit': 'Mpix/s', 'cores': cores,
@@ -236,6 +309,8 @@ def main():
     if rank == 0:
         C = int(ae_cfg.num_chan_bn)
         flop_step = N * H * Wd * (FLOP_PER_PX_ENC + FLOP_PER_PX_DEC + FLOP_PER_SYMBOL_PC * C / 64.0)
+        sched = ('a stream limited to the {} CUs the decoder leaves idle'.format(cus) if cus else
+                 'a second stream next to the decoder (which fills the chip)')
         out = {
             'metric': 'Megapixels/s encode+pc-logits (and decode) per node',
             'value': round(value, 3), 'unit': 'Mpix/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -247,16 +322,109 @@ def main():
                                        N, H, Wd, a.ae_config),
                        'batch_per_gpu': N, 'height': H, 'width': Wd, 'parallelism': 'image-sharded x{}'.format(world),
                        'schedule': 'one image at a time; bitcost and decode of that image run concurrently (val.py:85-89 '
-                                   'evaluates both in one session.run), the bitcost on {}'.format(
-                                       'a stream limited to the {} CUs the decoder leaves idle'.format(extra['context_model_stream_cus'])
-                                       if extra.get('context_model_stream_cus') else 'a second stream')},
+                                   'evaluates both in one session.run), the bitcost on ' + sched},
             'model_tflops_per_s': round(flop_step * world * a.steps / elapsed / 1e12, 2),
-            'roofline': roofline, 'cpu_baseline': cpu,
+            'roofline': roofline, 'roofline_context_model': roofline_pc, 'cpu_baseline': cpu,
         }
         out.update(extra)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()                 # rank 0 is still timing the stage split / dominant kernel: leave together
+        dist.destroy_process_group()
+
+
+def plan_name(lib, _lib, N, h4, w4, flags):
+    """which kernel(s) ic_conv3x3_c128_auto_f32 launches for this shape and these flags (the library's own plan query)."""
+    if lib.ic_conv3x3_c128_pick_algo(N, h4, w4, flags) != 1:
+        return {'kernel': 'conv3x3_c128_kernel', 'cus': 256}
+    pl = (ctypes.c_longlong * 5)()
+    _lib.check(lib.ic_wino3x3_c128_plan(N, h4, w4, flags, pl))
+    names = []
+    if pl[0]:
+        names.append('wino3x3_c128_shared_kernel' if w4 % 2 == 0 else 'wino3x3_c128_kernel')
+    if pl[1]:
+        names.append('wino3x3_c128_tn_kernel<{}>'.format(int(pl[2])))
+    if pl[3]:
+        names.append('wino3x3_c128_t16_kernel')
+    if pl[4]:
+        names.append('wino3x3_c128_ksplit_kernel')
+    return {'kernel': ' + '.join(names), 'cus': int(lib.ic_wino3x3_c128_workgroups(N, h4, w4, flags)),
+            'tile_groups': {'whole_k': int(pl[0]), 'segment_jobs': int(pl[1]), 'nb': int(pl[2]), 't16': int(pl[3]), 'ksplit': int(pl[4])}}
+
+
+def pipelined_section(torch, dev, a, N, H, Wd, pipe):
+    """Extra, NOT the contract value: the same step with three independent batch-1 pipelines in flight."""
+    from imgcomp_cvpr_amd import bits
+    try:
+        pipes = [Pipeline(dev, a.ae_config, 'full_chip', seed=0).set_input(N, H, Wd) for _ in range(3)]
+        streams_ = [torch.cuda.Stream(device=dev) for _ in range(3)]
+
+        def one(pl):
+            e = pl.ae.encode(pl.x, is_training=False)
+            b = pl.pc.bitcost(e.qbar, e.symbols, is_training=False, pad_value=pl.pad_value)
+            bits.bitcost_to_bpp(b, pl.x)
+            return pl.ae.decode(e.qhard, is_training=False)
+        torch.cuda.synchronize(dev)
+        for i in range(6):
+            with torch.cuda.stream(streams_[i % 3]):
+                one(pipes[i % 3])
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        n_img = 36
+        for i in range(n_img):
+            with torch.cuda.stream(streams_[i % 3]):
+                one(pipes[i % 3])
+        torch.cuda.synchronize(dev)
+        dt3 = time.perf_counter() - t1
+        return {'value': round(N * H * Wd * n_img / dt3 / 1e6, 3), 'unit': 'Mpix/s', 'ms_per_image': round(dt3 / n_img * 1e3, 4),
+                'images': n_img, 'note': 'three independent batch-1 pipelines in flight on one GPU; not the contract value'}
+    except Exception as ex:                                       # informational only
+        return {'error': str(ex)[:200]}
+
+
+def train_main(a, dev, rank, world):
+    """--mode train: BASELINE configs[2] -- ae_configs/cvpr/med + res_shallow, batch 32 of random 128x128 crops per GPU
+    (weak scaling: every rank its own 32 crops), one full training step per bench step: forward in training mode, MS-SSIM
+    loss, hand-written backward, RCCL gradient all-reduce of the three flat buckets, two Adam updates."""
+    import torch
+    import torch.distributed as dist
+    from imgcomp_cvpr_amd import config_parser as cp, weights as W, training
+    ae_cfg, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'med'))
+    pc_cfg, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
+    wts = W.synthetic_weights(ae_cfg, pc_cfg)
+    N, H, Wd = 32, 128, 128
+    tr = training.Trainer(ae_cfg, pc_cfg, wts, dev, num_itr_per_epoch=1000)
+    x = torch.as_tensor(W.synthetic_image((N, 3, H, Wd), 'natural', seed=rank)).float().to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+    for _ in range(a.warmup):
+        tr.step(x)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = tr.step(x)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'training images/s (cfg3: cvpr/med + res_shallow, 128x128 crops, batch 32 per GPU)',
+            'value': round(N * world * a.steps / elapsed, 2), 'unit': 'img/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(elapsed / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[2]: train step, ae_configs/cvpr/med + pc_configs/cvpr/res_shallow, {}x3x{}x{} '
+                                   'per GPU, MS-SSIM loss, two Adam optimisers, data-parallel gradient all-reduce'.format(N, H, Wd),
+                       'batch_per_gpu': N, 'parallelism': 'dp{}'.format(world)},
+            'mpix_per_s': round(N * H * Wd * world * a.steps / elapsed / 1e6, 3),
+            'last_step': {k: round(float(v), 5) for k, v in out.items()}}), flush=True)
+    if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -18,6 +18,24 @@ class HipLibraryError(RuntimeError):
     pass
 
 
+# per-call plan flags (include/imgcomp_hip.h, IC_CONV3_* / IC_EDGE_* / IC_PC_*): the library keeps no process-wide state
+CONV3_FORM_MASK = 0x0f
+CONV3_AUTO, CONV3_DIRECT, CONV3_WINO, CONV3_WINO_WHOLEK, CONV3_WINO_WHOLEK_PW = 0, 1, 2, 3, 4
+CONV3_WINO_KSPLIT, CONV3_WINO_T16, CONV3_WINO_SEG1, CONV3_WINO_SEG2, CONV3_WINO_SEG3 = 5, 6, 7, 8, 9
+CONV3_LEAVE_IDLE_CUS = 0x10
+CONV3_NO_XCD_RUNS = 0x20
+CONV3_PACKED_TRANSFORM = 0x40
+PC_DECODE_PER_LAYER = 0x01
+
+
+def conv3_direct_variant(v):
+    return ((v + 1) & 0xf) << 8
+
+
+def edge_tiles_per_wg(n):
+    return n & 0xff
+
+
 # name -> (restype, argtypes); mirrors include/imgcomp_hip.h one-to-one (tests/test_abi.py checks
 # that every ic_* prototype of the header is listed here and exported by the .so).
 PROTOTYPES = {
@@ -25,25 +43,20 @@ PROTOTYPES = {
     'ic_strerror': (c_char_p, [c_int]),
     'ic_crc32c': (c_uint32, [c_void_p, c_size_t, c_uint32]),
     'ic_conv2d_bn_act_f32': (c_int, [c_void_p] * 7 + [c_int] * 9 + [c_void_p, c_void_p, c_void_p]),
-    'ic_deconv2d_bn_act_f32': (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p, c_void_p, c_void_p]),
+    'ic_deconv2d_bn_act_f32': (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p, c_void_p, c_int, c_void_p]),
     'ic_conv3x3_c128_packed_floats': (c_size_t, []),
     'ic_pack_conv3x3_c128_f32': (c_int, [c_void_p, c_void_p, c_void_p]),
-    'ic_conv3x3_c128_bn_act_f32': (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_void_p]),
-    'ic_conv3x3_c128_set_variant': (c_int, [c_int]),
-    'ic_conv3x3_c128_set_tuning': (c_int, [c_int, c_int]),
-    'ic_conv3x3_c128_set_debug_buffer': (None, [c_void_p]),
+    'ic_conv3x3_c128_bn_act_f32': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
     'ic_wino3x3_c128_packed_floats': (c_size_t, []),
     'ic_pack_wino3x3_c128_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     'ic_pack_wino3x3_c128_batch_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
-    'ic_wino3x3_c128_bn_act_f32': (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_void_p]),
-    'ic_wino3x3_c128_set_tuning': (None, [c_int, c_int]),
-    'ic_edge_set_tuning': (None, [c_int, c_int]),
-    'ic_wino3x3_c128_workgroups': (c_longlong, [c_int, c_int, c_int]),
+    'ic_wino3x3_c128_bn_act_f32': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
+    'ic_wino3x3_c128_workgroups': (c_longlong, [c_int, c_int, c_int, c_int]),
+    'ic_wino3x3_c128_plan': (c_int, [c_int, c_int, c_int, c_int, POINTER(c_longlong)]),
     'ic_conv3x3_c128_both_packed_floats': (c_size_t, []),
     'ic_pack_conv3x3_c128_both_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
-    'ic_conv3x3_c128_pick_algo': (c_int, [c_int, c_int, c_int]),
-    'ic_conv3x3_c128_set_algo': (c_int, [c_int]),
-    'ic_conv3x3_c128_auto_f32': (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_void_p]),
+    'ic_conv3x3_c128_pick_algo': (c_int, [c_int, c_int, c_int, c_int]),
+    'ic_conv3x3_c128_auto_f32': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
     'ic_conv2d_mfma_packed_floats': (c_size_t, [c_int] * 6),
     'ic_pack_conv2d_mfma_f32': (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     'ic_conv2d_mfma_bn_act_f32': (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p]),
@@ -60,19 +73,17 @@ PROTOTYPES = {
                                   c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),
     'ic_pc_logits_to_freqs_f32': (c_int, [c_void_p, c_longlong, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     'ic_pc_decode_workspace_bytes': (c_size_t, [c_int] * 4),
-    'ic_pc_decode_set_mode': (c_int, [c_int]),
     'ic_pc_decode_f32': (c_int, [c_void_p, c_longlong, c_int, POINTER(c_void_p), c_void_p, c_int, c_int, c_float,
-                                 c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+                                 c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     'ic_sum_f32': (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p]),
     'ic_ae_workspace_bytes': (c_size_t, [c_int] * 4),
     'ic_ae_encode_f32': (c_int, [c_void_p, POINTER(c_void_p)] + [c_int] * 5 + [c_void_p] * 6 +
-                         [c_int] * 3 + [c_void_p, c_size_t, c_void_p]),
+                         [c_int] * 3 + [c_void_p, c_size_t, c_int, c_void_p]),
     'ic_ae_decode_f32': (c_int, [c_void_p, POINTER(c_void_p)] + [c_int] * 3 + [c_void_p] +
-                         [c_int] * 3 + [c_void_p, c_size_t, c_void_p]),
+                         [c_int] * 3 + [c_void_p, c_size_t, c_int, c_void_p]),
     'ic_bn_workspace_bytes': (c_size_t, [c_int]),
     'ic_bn_stats_f32': (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p, c_void_p]),
     'ic_bn_train_stats_f32': (c_int, [c_void_p] * 5 + [c_float] * 2 + [c_void_p] * 4 + [c_int] * 3 + [c_void_p, c_void_p]),
-    'ic_bn_set_tuning': (c_int, [c_int]),
     'ic_bn_apply_f32': (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
     'ic_bn_backward_f32': (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p, c_void_p]),
     'ic_conv2d_wgrad_workspace_bytes': (c_size_t, [c_int] * 7),

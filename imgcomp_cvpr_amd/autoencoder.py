@@ -56,6 +56,7 @@ class _Network(object):
         self.config = config
         self.quantize = quantize
         self.num_chan_bn_including_heatmap = config.num_chan_bn + 1
+        self.plan_flags = 0        # IC_CONV3_* bits OR-ed into every call of THIS object (tests force a kernel form with it)
         self._centers = None       # set by load_weights(); access with get_centers_variable()
         self._params = None        # OrderedDict name -> device tensor (reference layouts)
         self._device = None
@@ -66,15 +67,16 @@ class _Network(object):
     def get_subsampling_factor():
         raise NotImplementedError()
 
-    def encode(self, x, is_training):
-        """x: (N,3,H,W) float32 in 0..255 on the HIP device.  -> EncoderOutput."""
+    def encode(self, x, is_training, plan_flags=0):
+        """x: (N,3,H,W) float32 in 0..255 on the HIP device.  -> EncoderOutput.
+        plan_flags (not in the reference): per-call IC_CONV3_* launch-plan bits for the 3x3 layers, see _lib.CONV3_*."""
         assert x.dtype == torch.float32, 'Expected float32 for x, got {}'.format(x.dtype)
         self._require_weights()
-        return self._encode(x, is_training)
+        return self._encode(x, is_training, int(plan_flags) | int(self.plan_flags))
 
-    def decode(self, q, is_training):
+    def decode(self, q, is_training, plan_flags=0):
         self._require_weights()
-        return self._decode(q, is_training)
+        return self._decode(q, is_training, int(plan_flags) | int(self.plan_flags))
 
     def get_centers_variable(self):
         if self._centers is None:
@@ -137,10 +139,10 @@ class _Network(object):
     def _prepare(self, weights):
         raise NotImplementedError()
 
-    def _encode(self, x, is_training):
+    def _encode(self, x, is_training, plan_flags=0):
         raise NotImplementedError()
 
-    def _decode(self, q, is_training):
+    def _decode(self, q, is_training, plan_flags=0):
         raise NotImplementedError()
 
 
@@ -203,7 +205,7 @@ class _CVPR(_Network):
 
     # -- forward -----------------------------------------------------------------------------------
 
-    def _encode(self, x, is_training):
+    def _encode(self, x, is_training, plan_flags=0):
         if is_training:
             raise NotImplementedError('is_training=True: the training forward keeps a tape for its hand-written backward and '
                                       'lives in imgcomp_cvpr_amd.training.TrainGraph (see train.py)')
@@ -227,13 +229,13 @@ class _CVPR(_Network):
         check(lib.ic_ae_encode_f32(ptr(x), self._enc_tab, self._B, C, self._L, int(heat_on),
                                    int(self.config.normalization == 'FIXED'),
                                    ptr(heatmap), ptr(z), ptr(qsoft), ptr(qhard), ptr(qbar), ptr(symbols),
-                                   N, H, W, ptr(ws), need, _lib.current_stream(x.device)), 'ic_ae_encode_f32')
+                                   N, H, W, ptr(ws), need, plan_flags, _lib.current_stream(x.device)), 'ic_ae_encode_f32')
         if qbar is None:
             qbar = qhard      # forward value of qsoft + stop_gradient(qhard - qsoft)
         self._last_qsoft = qsoft
         return EncoderOutput(qbar, qhard, symbols, z, heatmap)
 
-    def _decode(self, q, is_training):
+    def _decode(self, q, is_training, plan_flags=0):
         if is_training:
             raise NotImplementedError('is_training=True: the training forward keeps a tape for its hand-written backward and '
                                       'lives in imgcomp_cvpr_amd.training.TrainGraph (see train.py)')
@@ -246,6 +248,6 @@ class _CVPR(_Network):
         x_out = torch.empty((N, 3, H, W), dtype=torch.float32, device=q.device)
         ws, need = self._workspace(N, H, W)
         check(lib.ic_ae_decode_f32(ptr(q), self._dec_tab, self._B, C, int(self.config.normalization == 'FIXED'),
-                                   ptr(x_out), N, H, W, ptr(ws), need, _lib.current_stream(q.device)),
+                                   ptr(x_out), N, H, W, ptr(ws), need, plan_flags, _lib.current_stream(q.device)),
               'ic_ae_decode_f32')
         return x_out

@@ -405,24 +405,17 @@ static const C3Variant kVariants[] = {
     {4, 8, 16}, {4, 4, 32}, {3, 8, 12}, {3, 6, 16}, {3, 3, 32}, {2, 4, 16}, {2, 2, 32}, {2, 8, 8}, {1, 2, 16}, {1, 4, 8},
 };
 static const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
-static int g_variant_override = -1;
-static int g_lds_pad = 0;      // extra dynamic LDS per work-group (tuning: limits work-groups per CU)
+// No process-wide state: the tile variant of a launch comes from the per-call flags (IC_CONV3_DIRECT_VARIANT(v), tests);
+// the schedule knobs of the tuning tools exist only in -DIC_TUNING builds.
+#ifdef IC_TUNING
+static int g_lds_pad = 0;      // extra dynamic LDS per work-group (limits work-groups per CU)
 static unsigned long long* g_dbg = nullptr;
 static int g_pipe = -1;        // -1: automatic (pipelined schedule for PT >= 2, plain for PT == 1), 0: plain, 1: pipelined
 static int g_abl = 0;
-
-extern "C" int ic_conv3x3_c128_set_variant(int v) {
-    int prev = g_variant_override;
-    g_variant_override = (v >= 0 && v < kNumVariants) ? v : -1;
-    return prev;
-}
-
-extern "C" void ic_conv3x3_c128_set_debug_buffer(void* p) { g_dbg = (unsigned long long*)p; }
-
-extern "C" int ic_conv3x3_c128_set_tuning(int key, int value) {
+extern "C" void ic_conv3x3_c128_debug_set_buffer(void* p) { g_dbg = (unsigned long long*)p; }
+extern "C" int ic_conv3x3_c128_debug_set_tuning(int key, int value) {
     int prev = -1;
     switch (key) {
-        case 0: return ic_conv3x3_c128_set_variant(value);
         case 1: prev = g_lds_pad; g_lds_pad = value < 0 ? 0 : value; break;
         case 2: prev = g_pipe; g_pipe = value < 0 ? -1 : (value ? 1 : 0); break;
         case 3: prev = g_abl; g_abl = value; break;
@@ -430,6 +423,10 @@ extern "C" int ic_conv3x3_c128_set_tuning(int key, int value) {
     }
     return prev;
 }
+#else
+static constexpr int g_lds_pad = 0, g_pipe = -1, g_abl = 0;
+static constexpr unsigned long long* g_dbg = nullptr;
+#endif
 
 // Variant choice from a small cost model calibrated on MI355X (tools/bench_conv3x3.py, profiles/):
 // every CU gets W = ceil(nwg / 256) work-groups; up to `occ` of them are resident together, and the
@@ -437,8 +434,9 @@ extern "C" int ic_conv3x3_c128_set_tuning(int key, int value) {
 // pipelined schedule, 2: 0.85, >= 3: 0.95 -- prologue/epilogue of one group hide under the others).
 static int variant_occupancy(int PT) { return PT == 1 ? 3 : (PT <= 3 ? 2 : 1); }
 
-static int pick_variant(int N, int H, int W) {
-    if (g_variant_override >= 0) return g_variant_override;
+static int pick_variant(int N, int H, int W, int flags) {
+    const int forced = ((flags >> 8) & 0xf) - 1;                  // IC_CONV3_DIRECT_VARIANT(v)
+    if (forced >= 0 && forced < kNumVariants) return forced;
     static const double eff[4] = {0.0, 0.70, 0.85, 0.95};
     int best = 0; double bestc = 1e30;
     for (int v = 0; v < kNumVariants; ++v) {
@@ -483,14 +481,14 @@ extern "C" int ic_pack_conv3x3_c128_f32(const float* w_tf, float* w_packed, ic_s
 
 extern "C" int ic_conv3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale,
                                           const float* shift, const float* res1, const float* res2, float* y,
-                                          int N, int H, int W, int relu, ic_stream_t stream) {
+                                          int N, int H, int W, int relu, int flags, ic_stream_t stream) {
     IC_CHECK_ARG(x && w_packed && scale && shift && y);
     IC_CHECK_ARG(N > 0 && H > 0 && W > 0);
     if ((long long)C128 * H * W >= (1ll << 31)) return IC_ERR_UNSUPPORTED;
     C3Args a{};
     a.x = x; a.wp = w_packed; a.scale = scale; a.shift = shift; a.res1 = res1; a.res2 = res2; a.y = y;
     a.N = N; a.H = H; a.W = W; a.relu = relu; a.dbg = g_dbg; a.abl = g_abl;
-    switch (pick_variant(N, H, W)) {
+    switch (pick_variant(N, H, W, flags)) {
         case 0: C3_LAUNCH(4, 8, 16); break;
         case 1: C3_LAUNCH(4, 4, 32); break;
         case 2: C3_LAUNCH(3, 8, 12); break;

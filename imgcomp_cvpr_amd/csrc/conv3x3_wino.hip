@@ -29,31 +29,15 @@
 //
 // Rounding differs from the direct form (different summation tree); measured against the float64 oracle both stay
 // inside the 1e-4 parity bound (tests/test_gpu_ops.py).
-#include "common.h"
+#include "wino_common.h"
 #include <type_traits>
 #include <cstdlib>
 #include "internal.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-#define WN_C 128
-#define WN_FRAG_FLOATS (16 * WN_C * WN_C)          // one layout of the transformed filter
-#define WN_PACKED_FLOATS (2 * WN_FRAG_FLOATS)      // [32-channel-tile fragments | 16-channel-tile fragments]
 #define WN_STAGES 4
 #ifndef WN_ABL
 #define WN_ABL 0      // tuning builds only: 1 no patch loads, 2 no filter loads, 4 no transform in the main loop
 #endif
-
-struct WnArgs {
-    const float* x; const float* wp; const float* scale; const float* shift;
-    const float* res1; const float* res2; float* y;
-    int N, H, W, grows, gcols, relu;
-    int xcd_runs;               // 1 = contiguous runs of tile groups per XCD (tuning key 5)
-    int g0;                     // first tile group of this launch (a shape may be split into a whole-K and a K-split launch)
-    unsigned long long* prof;   // tuning builds (WN_PROF) only
-};
 
 // ---- filter transform + packing -----------------------------------------------------------------------------------
 // U = G g Gt, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].
@@ -93,30 +77,8 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
 }
 
 // ---- the convolution ----------------------------------------------------------------------------------------------
-// A wave owns 2 x 16 tiles (4 x 32 output pixels): a tile row is 16 lanes = one DPP row.
-__device__ __forceinline__ float dpp_from_left(float edge, float v) {    // lane i <- v of lane i-1; row lane 0 keeps edge
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x111, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float dpp_from_right(float edge, float v) {   // lane i <- v of lane i+1; row lane 15 keeps edge
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x101, 0xf, 0xf, false));
-}
-
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-#define WN_OOB 0x80000000u        // byte offset beyond any image (128 H W 4 < 2^31): the buffer load returns 0
-
+// A wave owns 2 x 16 tiles (4 x 32 output pixels): a tile row is 16 lanes = one DPP row (helpers in wino_common.h).
 // VEC: even W, the pixel pair (2tx, 2tx+1) is one aligned 8-byte load.
-__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
-    f32x2 r;
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
-    f32x2 r;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
 // KS = 1: the four waves of a work-group are the four output-channel tiles of one tile group (64 k-steps each).
 // KS = 4: small maps that cannot fill the chip with 4 x groups waves -- a work-group is ONE channel tile (cot) of a
 //         group, its four waves take a quarter of the input channels each (16 k-steps) and the partial accumulators are
@@ -867,91 +829,131 @@ extern "C" int ic_pack_wino3x3_c128_f32(const float* w_tf, float* w_packed, int 
     return IC_OK;
 }
 
+// ---- launch plan -------------------------------------------------------------------------------------------------------
+// No process-wide state: everything that used to be a tuning setter is a bit of the per-call `flags` word (imgcomp_hip.h,
+// IC_CONV3_*).  Profiling builds (-DWN_PROF) take their stamp buffer from ic_wino3x3_c128_debug_set_prof_buffer, which does
+// not exist in the product build.
+#ifdef WN_PROF
 static unsigned long long* g_wino_prof = nullptr;
-static int g_wino_ksplit = -1;      // -1 automatic, 0 never, 1 always (tuning key 2)
-static int g_wino_xcd = 1;          // tuning key 5
-static int g_wino_t16 = -1;         // tuning key 6: 16 x 16 jobs (wino3x3_c128_t16_kernel): -1 automatic, 0 never, 1 every whole-K group
-static int g_wino_leave_idle = 0;   // tuning key 7: 1 = keep the CUs a partly filled whole-K round leaves idle free (a concurrent branch uses them)
-static int g_wino_share = 1;        // whole-K form: 1 = input transform shared between the waves through LDS (tuning key 4)
-static int g_wino_ratio = 270;      // cost of a whole-K round in K-split rounds, x100 (tuning key 3)
-// tuning only: key 0 = device buffer (as two 32-bit halves: key 0 low, key 1 high) for WN_PROF builds
-extern "C" void ic_wino3x3_c128_set_tuning(int key, int value) {
-    static unsigned long long bits = 0;
-    if (key == 0) bits = (bits & 0xffffffff00000000ull) | (unsigned)value;
-    if (key == 1) { bits = (bits & 0xffffffffull) | ((unsigned long long)(unsigned)value << 32); g_wino_prof = (unsigned long long*)bits; }
-    if (key == 2) g_wino_ksplit = value;
-    if (key == 3) g_wino_ratio = value;
-    if (key == 4) g_wino_share = value;
-    if (key == 5) g_wino_xcd = value;
-    if (key == 6) g_wino_t16 = value;
-    if (key == 7) g_wino_leave_idle = value;
+extern "C" void ic_wino3x3_c128_debug_set_prof_buffer(void* p) { g_wino_prof = (unsigned long long*)p; }
+#endif
+
+struct WinoPlan {
+    long long whole;     // tile groups run as 32 x 32 whole-K work-groups (one per CU)
+    long long seg;       // tile groups run as NB-segment jobs (conv3x3_wino_tn.hip), seg_nb segments per job
+    long long t16;       // tile groups run by the two-slot 16 x 16 kernel of this file
+    long long ksplit;    // tile groups run K-split (4 work-groups each)
+    int seg_nb;
+};
+
+// Cost model, in thousands of shader clocks per CU (MI355X measurements):
+//   whole-K round (256 groups, one work-group per CU): 92 (38.4 us) partly filled, 100 (42 us) full;
+//   K-split round (64 groups): 100 / 2.7;
+//   NB-segment job: 16.4 NB of matrix pipe + ~10 of prologue / epilogue, one work-group per CU for NB >= 2; NB = 1 keeps two
+//   work-groups per CU (prologue of one under the k-loop of the other).
+static double seg_cost(long long groups, int nb) {
+    const long long wgs = 2 * ((2 * groups + nb - 1) / nb);
+    if (nb == 1) {
+        const long long per_cu = (wgs + 255) / 256;                  // 16.4 k clocks each, two at a time share the pipes
+        return 17.5 * per_cu + 10.0 * ((per_cu + 1) / 2);
+    }
+    return (double)((wgs + 255) / 256) * (17.5 * nb + 10.0);
 }
 
-// One work-group per CU at a time (512 registers per lane), so a launch runs in rounds of 256 work-groups.  A round of
-// whole-K work-groups (one tile group each, four channel tiles sharing the input transform) costs ~2.7 rounds of K-split
-// ones (one channel tile of a tile group each; sustained: 37.3 us against 3 x 13.2 us on a Kodak map).  Plan: the full rounds
-// of 256 tile groups run whole-K; the remainder r runs whole-K as one partly empty round, or K-split in ceil(r / 64) short
-// rounds when that is cheaper (r <= 128).  A Kodak map (192 groups) is one 75 % full whole-K round; a 64x64 map (32 groups)
-// one K-split round; 272 groups = one full whole-K round + one K-split round (51 us; all whole-K 88, all K-split 72).
-static void wino_plan(long long groups, bool even_w, long long* gw, long long* gk, long long* gt) {
-    *gt = 0;
-    if (g_wino_ksplit == 0) { *gw = groups; *gk = 0; }
-    else if (g_wino_ksplit > 0) { *gw = 0; *gk = groups; }
-    else {
-        const long long r = groups % 256;
-        const bool rem_ksplit = r > 0 && 100 * ((r + 63) / 64) < g_wino_ratio;
-        *gk = rem_ksplit ? r : 0;
-        *gw = groups - *gk;
+static WinoPlan wino_plan(long long groups, bool even_w, int flags) {
+    WinoPlan p{0, 0, 0, 0, 0};
+    const int form = flags & IC_CONV3_FORM_MASK;
+    const bool leave_idle = (flags & IC_CONV3_LEAVE_IDLE_CUS) != 0;
+    switch (form) {
+        case IC_CONV3_WINO_WHOLEK: case IC_CONV3_WINO_WHOLEK_PW: p.whole = groups; return p;
+        case IC_CONV3_WINO_KSPLIT: p.ksplit = groups; return p;
+        case IC_CONV3_WINO_T16: if (even_w) p.t16 = groups; else p.whole = groups; return p;
+        case IC_CONV3_WINO_SEG1: case IC_CONV3_WINO_SEG2: case IC_CONV3_WINO_SEG3:
+            if (even_w) { p.seg = groups; p.seg_nb = form - IC_CONV3_WINO_SEG1 + 1; } else p.whole = groups;
+            return p;
+        default: break;
     }
-    // 16 x 16 jobs (wino3x3_c128_t16_kernel) for a last whole-K round that would leave a quarter or more of the CUs idle --
-    // unless the caller wants exactly those CUs for an independent branch (tuning key 7, see imgcomp_cvpr_amd/streams.py).
-    // Measured on a Kodak map (192 groups): 34.4 against 38.7 us; at full occupancy (256 groups) it is the slower form (47
-    // against 42 us: twice the filter bytes per MFMA clock).
-    static const int env_t16 = getenv("IMGCOMP_WINO_T16") ? atoi(getenv("IMGCOMP_WINO_T16")) : -2;      // A/B runs
-    const int t16 = env_t16 > -2 ? env_t16 : g_wino_t16;
-    const long long r = *gw % 256;
-    if (even_w && (t16 > 0 || (t16 < 0 && !g_wino_leave_idle && r > 128 && r <= 192))) {
-        *gt = t16 > 0 ? *gw : r;
-        *gw -= *gt;
+    // automatic.  Odd widths have the per-wave whole-K kernel and K-split only.
+    const long long r = groups % 256, full = groups - r;
+    const bool rem_ksplit = r > 0 && 100 * ((r + 63) / 64) < 270;
+    if (!even_w || leave_idle) {
+        // one work-group per CU, CUs beyond the tile groups stay free (a caller's concurrent branch runs there)
+        p.ksplit = rem_ksplit ? r : 0;
+        p.whole = groups - p.ksplit;
+        return p;
     }
+    double best = (full / 256) * 100.0 + (r == 0 ? 0.0 : rem_ksplit ? 37.0 * ((r + 63) / 64) : 92.0);
+    p.ksplit = rem_ksplit ? r : 0;
+    p.whole = groups - p.ksplit;
+    for (int nb = 1; nb <= 3; ++nb) {
+        const double c = seg_cost(groups, nb);
+        if (c < best) { best = c; p = WinoPlan{0, groups, 0, 0, nb}; }
+    }
+    return p;
 }
 
-// work-groups of the launch(es) ic_wino3x3_c128_bn_act_f32 would make for this shape; each occupies one whole CU
-extern "C" long long ic_wino3x3_c128_workgroups(int N, int H, int W) {
+// work-groups-per-CU footprint of the launch(es) ic_wino3x3_c128_bn_act_f32 would make for this shape: the number of CUs a
+// caller sizing a CU-range stream for an independent branch has to leave to this layer (256 = the whole chip)
+extern "C" long long ic_wino3x3_c128_workgroups(int N, int H, int W, int flags) {
     if (N <= 0 || H <= 0 || W <= 0) return 0;
-    long long gw, gk, gt;
-    wino_plan((long long)N * ic_cdiv(H, 4) * ic_cdiv(W, 32), (W & 1) == 0, &gw, &gk, &gt);
-    return gt > 0 ? (gw + 4 * gk + 4 * gt > 256 ? gw + 4 * gk + 4 * gt : 256) : gw + 4 * gk;      // the 16 x 16 form fills the chip
+    const WinoPlan p = wino_plan((long long)N * ic_cdiv(H, 4) * ic_cdiv(W, 32), (W & 1) == 0, flags);
+    long long cus = p.whole + 4 * p.ksplit;                          // one 512-register work-group per CU
+    if (p.seg > 0) {
+        const long long wgs = 2 * ((2 * p.seg + p.seg_nb - 1) / p.seg_nb);
+        cus += p.seg_nb > 1 ? wgs : (wgs + 1) / 2;                   // NB = 1: two work-groups share a CU
+    }
+    cus += (4 * p.t16 + 1) / 2;
+    return cus;
+}
+
+// the plan itself: tile groups per form {whole-K, NB-segment, segments per job NB, 16 x 16 (two-slot), K-split}
+extern "C" int ic_wino3x3_c128_plan(int N, int H, int W, int flags, long long plan_out[5]) {
+    IC_CHECK_ARG(plan_out && N > 0 && H > 0 && W > 0);
+    const WinoPlan p = wino_plan((long long)N * ic_cdiv(H, 4) * ic_cdiv(W, 32), (W & 1) == 0, flags);
+    plan_out[0] = p.whole; plan_out[1] = p.seg; plan_out[2] = p.seg_nb; plan_out[3] = p.t16; plan_out[4] = p.ksplit;
+    return IC_OK;
 }
 
 extern "C" int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
                                           const float* res1, const float* res2, float* y, int N, int H, int W, int relu,
-                                          ic_stream_t stream) {
+                                          int flags, ic_stream_t stream) {
     IC_CHECK_ARG(x && w_packed && scale && shift && y);
     IC_CHECK_ARG(N > 0 && H > 0 && W > 0);
     if ((long long)WN_C * H * W * 4 >= (1ll << 31)) return IC_ERR_UNSUPPORTED;    // per-image byte offsets are 31-bit
     WnArgs a{};
     a.x = x; a.wp = w_packed; a.scale = scale; a.shift = shift; a.res1 = res1; a.res2 = res2; a.y = y;
     a.N = N; a.H = H; a.W = W; a.relu = relu;
-    a.grows = ic_cdiv(H, 4); a.gcols = ic_cdiv(W, 32); a.prof = g_wino_prof; a.xcd_runs = g_wino_xcd;
-    long long gw, gk, gt;
-    wino_plan((long long)N * a.grows * a.gcols, (W & 1) == 0, &gw, &gk, &gt);
+    a.grows = ic_cdiv(H, 4); a.gcols = ic_cdiv(W, 32); a.xcd_runs = (flags & IC_CONV3_NO_XCD_RUNS) ? 0 : 1;
+#ifdef WN_PROF
+    a.prof = g_wino_prof;
+#endif
+    const bool even_w = (W & 1) == 0;
+    const WinoPlan p = wino_plan((long long)N * a.grows * a.gcols, even_w, flags);
     hipStream_t st = (hipStream_t)stream;
-    if (gw > 0) {
-        const dim3 grid((unsigned)gw);
-        a.g0 = 0;
-        if ((W & 1) == 0 && g_wino_share != 0) hipLaunchKernelGGL(wino3x3_c128_shared_kernel, grid, dim3(256), 0, st, a);
-        else if ((W & 1) == 0) hipLaunchKernelGGL(wino3x3_c128_kernel<true>, grid, dim3(256), 0, st, a);
+    long long g0 = 0;
+    if (p.whole > 0) {
+        const dim3 grid((unsigned)p.whole);
+        a.g0 = (int)g0; a.ngroups = (int)p.whole;
+        if (even_w && (flags & IC_CONV3_FORM_MASK) != IC_CONV3_WINO_WHOLEK_PW) hipLaunchKernelGGL(wino3x3_c128_shared_kernel, grid, dim3(256), 0, st, a);
+        else if (even_w) hipLaunchKernelGGL(wino3x3_c128_kernel<true>, grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(wino3x3_c128_kernel<false>, grid, dim3(256), 0, st, a);
+        g0 += p.whole;
     }
-    if (gt > 0) {
-        a.g0 = (int)gw;
-        hipLaunchKernelGGL(wino3x3_c128_t16_kernel, dim3((unsigned)(4 * gt)), dim3(256), 0, st, a);
+    if (p.seg > 0) {
+        a.g0 = (int)g0; a.ngroups = (int)p.seg;
+        const int rc = icx_wino_tn_launch(a, p.seg_nb, (flags & IC_CONV3_PACKED_TRANSFORM) ? 0 : 1, st);
+        if (rc) return rc;
+        g0 += p.seg;
     }
-    if (gk > 0) {
-        const dim3 grid((unsigned)(gk * 4));
-        a.g0 = (int)(gw + gt);
-        if ((W & 1) == 0) hipLaunchKernelGGL(wino3x3_c128_ksplit_kernel<true>, grid, dim3(256), 0, st, a);
+    if (p.t16 > 0) {
+        a.g0 = (int)g0; a.ngroups = (int)p.t16;
+        hipLaunchKernelGGL(wino3x3_c128_t16_kernel, dim3((unsigned)(4 * p.t16)), dim3(256), 0, st, a);
+        g0 += p.t16;
+    }
+    if (p.ksplit > 0) {
+        const dim3 grid((unsigned)(p.ksplit * 4));
+        a.g0 = (int)g0; a.ngroups = (int)p.ksplit;
+        if (even_w) hipLaunchKernelGGL(wino3x3_c128_ksplit_kernel<true>, grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(wino3x3_c128_ksplit_kernel<false>, grid, dim3(256), 0, st, a);
     }
     IC_LAUNCH_CHECK();
@@ -959,12 +961,9 @@ extern "C" int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed,
 }
 
 // ---- both forms behind one packed filter: what the network / training entry points use ---------------------------------
-// blob = [direct-form fragments (ic_conv3x3_c128_packed_floats) | Winograd fragments (16 x 128 x 128)].
-// The form is picked per launch: Winograd whenever the shape is addressable with 31-bit offsets (whole-K waves for maps
-// that fill the chip, K-split work-groups for small ones), the direct kernel otherwise or on request.
-static int g_algo = -1;   // -1 automatic, 0 direct, 1 Winograd
-extern "C" int ic_conv3x3_c128_set_algo(int algo) { const int prev = g_algo; g_algo = algo; return prev; }
-
+// blob = [direct-form fragments (ic_conv3x3_c128_packed_floats) | Winograd fragments (2 x 16 x 128 x 128)].
+// The form is picked per launch: Winograd whenever the shape is addressable with 31-bit offsets, the direct kernel
+// otherwise or on request (flags & IC_CONV3_FORM_MASK == IC_CONV3_DIRECT).
 extern "C" size_t ic_conv3x3_c128_both_packed_floats(void) { return ic_conv3x3_c128_packed_floats() + WN_PACKED_FLOATS; }
 
 extern "C" int ic_pack_conv3x3_c128_both_f32(const float* w_tf, float* w_packed, int backward, ic_stream_t stream) {
@@ -974,23 +973,20 @@ extern "C" int ic_pack_conv3x3_c128_both_f32(const float* w_tf, float* w_packed,
     return ic_pack_wino3x3_c128_f32(w_tf, w_packed + ic_conv3x3_c128_packed_floats(), backward, stream);
 }
 
-extern "C" int ic_conv3x3_c128_pick_algo(int N, int H, int W) {
+extern "C" int ic_conv3x3_c128_pick_algo(int N, int H, int W, int flags) {
     if (N <= 0 || H <= 0 || W <= 0) return 0;
     if ((long long)WN_C * H * W * 4 >= (1ll << 31)) return 0;
-    if (g_algo >= 0) return g_algo;
-    // Measured on the MI355X (tools/bench_wino.py): the direct kernel has a ~27 us floor (16 sequential channel chunks per
-    // work-group) and 95-105 TFLOP/s at best; the Winograd kernel takes ~18 us per round of K-split work-groups (<= 128
-    // tile groups: 16.6 us for a 16x16 map, 37 us for 128x128) and 43-55 us per round of whole-K waves (Kodak 48-55 us,
-    // batch-32 training maps 55 us vs 93 us direct).  It wins at every shape it supports.
-    return 1;
+    // Measured on the MI355X: the direct kernel has a ~27 us floor (16 sequential channel chunks per work-group) and
+    // 95-105 TFLOP/s at best; the Winograd forms win at every shape they can address.
+    return (flags & IC_CONV3_FORM_MASK) == IC_CONV3_DIRECT ? 0 : 1;
 }
 
 extern "C" int ic_conv3x3_c128_auto_f32(const float* x, const float* w_both, const float* scale, const float* shift,
                                         const float* res1, const float* res2, float* y, int N, int H, int W, int relu,
-                                        ic_stream_t stream) {
+                                        int flags, ic_stream_t stream) {
     IC_CHECK_ARG(x && w_both && scale && shift && y && N > 0 && H > 0 && W > 0);
-    if (ic_conv3x3_c128_pick_algo(N, H, W) == 1)
+    if (ic_conv3x3_c128_pick_algo(N, H, W, flags) == 1)
         return ic_wino3x3_c128_bn_act_f32(x, w_both + ic_conv3x3_c128_packed_floats(), scale, shift, res1, res2, y, N, H, W,
-                                          relu, stream);
-    return ic_conv3x3_c128_bn_act_f32(x, w_both, scale, shift, res1, res2, y, N, H, W, relu, stream);
+                                          relu, flags, stream);
+    return ic_conv3x3_c128_bn_act_f32(x, w_both, scale, shift, res1, res2, y, N, H, W, relu, flags, stream);
 }

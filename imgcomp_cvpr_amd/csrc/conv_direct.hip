@@ -147,7 +147,7 @@ extern "C" int ic_conv2d_bn_act_f32(const float* x, const float* w, const float*
 
 extern "C" int ic_deconv2d_bn_act_f32(const float* x, const float* w, const float* scale, const float* shift,
                                       float* y, int N, int Cin, int H, int W, int Cout, int KH, int KW, int relu,
-                                      const float* out_mean, const float* out_std, ic_stream_t stream) {
+                                      const float* out_mean, const float* out_std, int flags, ic_stream_t stream) {
     IC_CHECK_ARG(x && w && scale && shift && y);
     IC_CHECK_ARG(N > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && KH > 0 && KW > 0);
     IC_CHECK_ARG((out_mean == nullptr) == (out_std == nullptr));
@@ -155,5 +155,6 @@ extern "C" int ic_deconv2d_bn_act_f32(const float* x, const float* w, const floa
     a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.y = y;
     a.out_mean = out_mean; a.out_std = out_std;
     a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.KH = KH; a.KW = KW; a.relu = relu;
+    a.tune = flags & 0xff;                                   // IC_EDGE_TILES_PER_WG(n)
     return icx_conv2d(a, true, (hipStream_t)stream);
 }

@@ -603,15 +603,14 @@ __global__ __launch_bounds__(256) void deconv5_cout3_mfma_kernel(const ConvArgs 
 #endif
 }
 
-static int g_h13_tpw = 0;     // tuning override (tools): tiles per work-group, 0 = automatic
+// tiles per work-group: automatic unless the caller asks for a run length (ConvArgs::tune, from the per-call flags
+// IC_EDGE_TILES_PER_WG(n) of ic_deconv2d_bn_act_f32 -- tests); the stamp buffer exists in -DH13_PROF builds only.
+#ifdef H13_PROF
 static unsigned long long* g_h13_prof = nullptr;
-// tuning only: key 0 = h13 tiles per work-group; keys 1 / 2 = low / high half of a device buffer for H13_PROF builds
-extern "C" void ic_edge_set_tuning(int key, int value) {
-    static unsigned long long bits = 0;
-    if (key == 0) g_h13_tpw = value;
-    if (key == 1) bits = (bits & 0xffffffff00000000ull) | (unsigned)value;
-    if (key == 2) { bits = (bits & 0xffffffffull) | ((unsigned long long)(unsigned)value << 32); g_h13_prof = (unsigned long long*)bits; }
-}
+extern "C" void ic_edge_debug_set_prof_buffer(void* p) { g_h13_prof = (unsigned long long*)p; }
+#else
+static constexpr unsigned long long* g_h13_prof = nullptr;
+#endif
 
 int icx_deconv5_cout3_mfma(const ConvArgs& a, hipStream_t st) {
     if (a.KH != 5 || a.KW != 5 || a.Cout > 4 || a.Cin != 64 || a.pt != 1 || a.pl != 1 || a.res1 || a.res2 || a.in_mean ||
@@ -621,7 +620,7 @@ int icx_deconv5_cout3_mfma(const ConvArgs& a, hipStream_t st) {
     const int tiles_x = ic_cdiv(a.W, H13_TC), tiles_y = ic_cdiv(a.H, H13_TR);
     // runs of x-adjacent tiles per work-group amortise the prologue (filter gather, first HBM round trip); the run
     // length is chosen by a small occupancy model: two work-groups fit a CU (LDS) and then share its matrix pipes
-    int tpw = g_h13_tpw;
+    int tpw = a.tune;
     if (tpw <= 0) {
         const double Pa = 6, Ta = 13, Pc = 12, Tc = 26;       // prologue / tile cost alone on a CU and co-resident (k clocks)
         double best = 1e30;

@@ -8,6 +8,7 @@ struct ConvArgs {
     const float* in_mean; const float* in_std; const float* out_mean; const float* out_std;
     int N, Cin, H, W, Cout, OH, OW, KH, KW, stride, pt, pl, relu;
     int w_sci, w_sco;   // filter strides (in floats) of the ci and co axes inside one tap
+    int tune;           // h13 kernel: tiles per work-group (0 = automatic); from the caller's per-call flags
     int builtin_norm;   // bit 0: normalise the input with the reference's fixed image statistics,
                         // bit 1: de-normalise + clip the output with them (autoencoder.py:136-169), bit 2: clip only
 };

@@ -8,7 +8,7 @@
 // ---- residual stack shared by encoder and decoder (autoencoder.py:224-234 / :252-262) ----
 // tab: 3 pointers {packed filter (both forms, ic_pack_conv3x3_c128_both_f32), scale, shift} per conv, 6B+2 convs.  bufs[0] holds the stack input
 // (kept for the global skip), bufs[4] is the temporary.  Returns the buffer index holding the output.
-static int res_stack(const void* const* tab, int B, float* const bufs[5], int N, int H, int W,
+static int res_stack(const void* const* tab, int B, float* const bufs[5], int N, int H, int W, int flags,
                      hipStream_t st, int* out_idx) {
     int cur = 0, li = 0, rc;
     float* T = bufs[4];
@@ -19,10 +19,10 @@ static int res_stack(const void* const* tab, int B, float* const bufs[5], int N,
             while (O == G || O == cur) ++O;              // one of {1,2,3} is always free
             const float* const* l1 = (const float* const*)tab + 3 * li;
             const float* const* l2 = l1 + 3;
-            if ((rc = ic_conv3x3_c128_auto_f32(bufs[cur], l1[0], l1[1], l1[2], nullptr, nullptr, T, N, H, W, 1, st)))
+            if ((rc = ic_conv3x3_c128_auto_f32(bufs[cur], l1[0], l1[1], l1[2], nullptr, nullptr, T, N, H, W, 1, flags, st)))
                 return rc;
             if ((rc = ic_conv3x3_c128_auto_f32(T, l2[0], l2[1], l2[2], bufs[cur], i == 2 ? bufs[G] : nullptr,
-                                                 bufs[O], N, H, W, 0, st)))
+                                                 bufs[O], N, H, W, 0, flags, st)))
                 return rc;
             cur = O; li += 2;
         }
@@ -33,9 +33,9 @@ static int res_stack(const void* const* tab, int B, float* const bufs[5], int N,
         while (O == cur) ++O;
         const float* const* l1 = (const float* const*)tab + 3 * li;
         const float* const* l2 = l1 + 3;
-        if ((rc = ic_conv3x3_c128_auto_f32(bufs[cur], l1[0], l1[1], l1[2], nullptr, nullptr, T, N, H, W, 0, st)))
+        if ((rc = ic_conv3x3_c128_auto_f32(bufs[cur], l1[0], l1[1], l1[2], nullptr, nullptr, T, N, H, W, 0, flags, st)))
             return rc;
-        if ((rc = ic_conv3x3_c128_auto_f32(T, l2[0], l2[1], l2[2], bufs[cur], bufs[0], bufs[O], N, H, W, 0, st)))
+        if ((rc = ic_conv3x3_c128_auto_f32(T, l2[0], l2[1], l2[2], bufs[cur], bufs[0], bufs[O], N, H, W, 0, flags, st)))
             return rc;
         cur = O;
     }
@@ -65,7 +65,7 @@ static void carve(void* ws, int N, int H, int W, float* bufs[5], float** half, f
 extern "C" int ic_ae_encode_f32(const float* x, const void* const* tab, int B, int C, int L, int heatmap_on,
                                 int normalize_on, float* heatmap, float* z, float* qsoft, float* qhard, float* qbar,
                                 int64_t* symbols, int N, int H, int W,
-                                void* workspace, size_t workspace_bytes, ic_stream_t stream) {
+                                void* workspace, size_t workspace_bytes, int flags, ic_stream_t stream) {
     IC_CHECK_ARG(x && tab && workspace && N > 0 && H > 0 && W > 0 && B >= 0 && C > 0 && L > 0);
     if (H % 8 || W % 8) return IC_ERR_UNSUPPORTED;          // callers pad to the subsampling factor (val.py:157)
     if (workspace_bytes < ic_ae_workspace_bytes(N, H, W, C)) return IC_ERR_WORKSPACE;
@@ -86,7 +86,7 @@ extern "C" int ic_ae_encode_f32(const float* x, const void* const* tab, int B, i
     if ((rc = ic_conv2d_mfma_bn_act_f32(half, t[3], t[4], t[5], bufs[0], N, 64, H / 2, W / 2, 128, 5, 5, 2, 0, 1, st)))
         return rc;
     int o;
-    if ((rc = res_stack(tab + 6, B, bufs, N, H / 4, W / 4, st, &o))) return rc;
+    if ((rc = res_stack(tab + 6, B, bufs, N, H / 4, W / 4, flags, st, &o))) return rc;
     // to_bn: 128 -> C(+1), 5x5 / 2, BN, linear
     const float* const* tb = t + 6 + 3 * nconv;
     const int Cb = C + (heatmap_on ? 1 : 0);
@@ -108,7 +108,7 @@ extern "C" int ic_ae_encode_f32(const float* x, const void* const* tab, int B, i
 
 extern "C" int ic_ae_decode_f32(const float* q, const void* const* tab, int B, int C, int normalize_on,
                                 float* x_out, int N, int H, int W,
-                                void* workspace, size_t workspace_bytes, ic_stream_t stream) {
+                                void* workspace, size_t workspace_bytes, int flags, ic_stream_t stream) {
     IC_CHECK_ARG(q && tab && x_out && workspace && N > 0 && H > 0 && W > 0 && B >= 0 && C > 0);
     if (H % 8 || W % 8) return IC_ERR_UNSUPPORTED;
     if (workspace_bytes < ic_ae_workspace_bytes(N, H, W, C)) return IC_ERR_WORKSPACE;
@@ -125,7 +125,7 @@ extern "C" int ic_ae_decode_f32(const float* q, const void* const* tab, int B, i
     a.N = N; a.Cin = C; a.H = H / 8; a.W = W / 8; a.Cout = 128; a.KH = 3; a.KW = 3; a.relu = 1;
     if ((rc = icx_conv2d(a, true, st))) return rc;
     int o;
-    if ((rc = res_stack(tab + 3, B, bufs, N, H / 4, W / 4, st, &o))) return rc;
+    if ((rc = res_stack(tab + 3, B, bufs, N, H / 4, W / 4, flags, st, &o))) return rc;
     const float* const* th = t + 3 + 3 * nconv;
     // h12: 128 -> 64, 5x5 transposed / 2, BN, ReLU
     if ((rc = ic_conv2d_mfma_bn_act_f32(bufs[o], th[0], th[1], th[2], half, N, 128, H / 4, W / 4, 64, 5, 5, 2, 1, 1, st)))

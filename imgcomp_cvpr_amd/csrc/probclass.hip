@@ -214,7 +214,9 @@ void pc_mfma_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
     // + a scalar plane offset, and the LDS address is plane * DS + tid.  (The first version derived (ci, kd, row, col)
     // from a flat element index per load: 10 vector instructions per MFMA, mostly that index arithmetic.)  VALID conv:
     // positions past the volume get an out-of-range offset -> the buffer load returns 0.
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xin, 0, (int)(((size_t)CIN * cstride - (size_t)od * HW) * 4), 0x00020000);
+    // one descriptor per KC-channel chunk (based at the chunk's first channel): byte offsets stay below 2^31 for any volume
+    // whose KC-channel slab does -- the whole feature volume may be larger (res_shallow_64 on a 4K tile: 2.3 GB per layer)
+    const int xr_bytes = (int)(((size_t)KC * cstride - (size_t)od * HW) * 4);
     unsigned loff;
     {
         const int rr = tid / S, cc = tid - rr * S;
@@ -253,9 +255,10 @@ void pc_mfma_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
     for (int c = 0; c < NCH; ++c) {
         if (c > 0) __syncthreads();                       // everyone done reading the previous brick
         float stv[2 * KC];                                 // all loads first, then the writes under ONE predicate
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(xin + (size_t)c * KC * cstride), 0, xr_bytes, 0x00020000);
 #pragma unroll
         for (int p = 0; p < 2 * KC; ++p) {
-            const int so = (int)((((size_t)(c * KC + p / 2)) * cstride + (size_t)(p & 1) * HW) * 4);      // scalar: plane (ci, kd)
+            const int so = (int)((((size_t)(p / 2)) * cstride + (size_t)(p & 1) * HW) * 4);      // scalar: plane (ci, kd) of the chunk
             stv[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, loff, so, 0));
         }
         // unpredicated writes (a predicate per write makes the compiler pair every load with its own wait + branch): the
@@ -443,8 +446,10 @@ static int pc_forward(const float* q, int prepadded, const int64_t* symbols, con
     a.qC = C; a.qh = h; a.qw = w; a.relu = 1;
     // all k output channels of a voxel in one lane when k = 24: the input brick is read once instead of three times
     if ((rc = (k == 24 ? launch_pc<24, true, false, true>(a, st) : launch_pc<8, true, false>(a, st)))) return rc;
-    // (the matrix-core kernels address one image's feature volume with 31-bit byte offsets)
-    const bool use_mfma = pc_mfma_supported(k, L) && (size_t)k * (C + 3) * (h + 6) * (w + 6) * 4 < (1ull << 31);
+    // (they address one KC-channel slab of an image's feature volume with 31-bit byte offsets; KC = 24 for k = 24, 16 for k = 64.
+    // The same path must serve the parallel pass and the sequential decoder -- their logits have to agree bit for bit --
+    // so the limit is the slab, not the volume: every volume a 288 GB device can hold stays on the matrix cores.)
+    const bool use_mfma = pc_mfma_supported(k, L) && (size_t)(k == 24 ? 24 : 16) * (C + 3) * (h + 6) * (w + 6) * 4 < (1ull << 31);
     float* pk1 = b2 + (size_t)N * k * (C + 1) * (h + 2) * (w + 2);
     float* pk2 = pk1 + pc_packed_floats(k, k);
     float* pk3 = pk2 + pc_packed_floats(k, k);
@@ -937,9 +942,6 @@ __global__ __launch_bounds__(256) void pc_dec_fused_kernel(const PcFusedArgs f) 
 #endif
 }
 
-static int g_pc_dec_mode = 0;      // 0: automatic, 1: always the launch-per-layer loop (tests)
-extern "C" int ic_pc_decode_set_mode(int mode) { const int prev = g_pc_dec_mode; g_pc_dec_mode = mode; return prev; }
-
 static size_t pc_dec_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
 extern "C" size_t ic_pc_decode_workspace_bytes(int C, int h, int w, int k) {
@@ -950,7 +952,7 @@ extern "C" size_t ic_pc_decode_workspace_bytes(int C, int h, int w, int k) {
 
 extern "C" int ic_pc_decode_f32(const uint8_t* bitstream, long long nbytes, int first_sym, const float* const* wtab_host,
                                 const float* centers, int k, int L, float resolution, int64_t* symbols, int* status,
-                                int C, int h, int w, void* workspace, size_t workspace_bytes, ic_stream_t stream) {
+                                int C, int h, int w, void* workspace, size_t workspace_bytes, int flags, ic_stream_t stream) {
     IC_CHECK_ARG(bitstream && wtab_host && centers && symbols && status && workspace);
     IC_CHECK_ARG(nbytes >= 0 && C > 0 && h > 0 && w > 0 && k > 0 && L > 0 && first_sym >= 0 && first_sym < L);
     if (L > 16) return IC_ERR_UNSUPPORTED;
@@ -984,7 +986,7 @@ extern "C" int ic_pc_decode_f32(const uint8_t* bitstream, long long nbytes, int 
         hipLaunchKernelGGL(pc_pack3_kernel, dim3(ic_cdiv(t1 > t3 ? t1 : t3, 256), 3), dim3(256), 0, st, pa, k);
     }
     hipLaunchKernelGGL(pc_dec_fill_kernel, dim3((unsigned)((nvol + 255) / 256)), dim3(256), 0, st, a.vol, nvol, centers);
-    if (use_mfma && k == 24 && g_pc_dec_mode == 0) {
+    if (use_mfma && k == 24 && !(flags & IC_PC_DECODE_PER_LAYER)) {
         PcFusedArgs f{};
         f.d = a;
         float* pk1 = (float*)pcws + (size_t)k * (4 * 7 * 7 + 3 * 5 * 5 + 2 * 3 * 3);
@@ -1014,24 +1016,27 @@ extern "C" int ic_pc_decode_f32(const uint8_t* bitstream, long long nbytes, int 
     if (n - 1 >= 2 * PC_DEC_GRAPH) {
         // capture is not allowed on the legacy default stream (torch's current stream by default): the loop runs on a
         // private stream ordered after / before the caller's by events
-        static hipStream_t own = nullptr;
-        static hipEvent_t ev_in = nullptr, ev_out = nullptr;
-        bool ok = true;
-        if (!own) {
-            ok = hipStreamCreateWithFlags(&own, hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&ev_out, hipEventDisableTiming) == hipSuccess;
-            if (!ok) { own = nullptr; (void)hipGetLastError(); }
-        }
+        // (created per call and destroyed before returning: the library keeps no per-process or per-device objects)
+        hipStream_t own = nullptr;
+        hipEvent_t ev_in = nullptr, ev_out = nullptr;
+        bool ok = hipStreamCreateWithFlags(&own, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&ev_out, hipEventDisableTiming) == hipSuccess;
+        auto release = [&]() {
+            if (ev_in) (void)hipEventDestroy(ev_in);
+            if (ev_out) (void)hipEventDestroy(ev_out);
+            if (own) (void)hipStreamDestroy(own);
+        };
+        if (!ok) { release(); own = nullptr; (void)hipGetLastError(); }
         if (ok) {
             const hipStream_t caller = st;
             ok = hipEventRecord(ev_in, caller) == hipSuccess && hipStreamWaitEvent(own, ev_in, 0) == hipSuccess;
             if (ok) {
                 st = own;
+                int rc = IC_OK;
                 hipGraph_t graph = nullptr;
                 hipGraphExec_t exec = nullptr;
                 if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess) {
-                    int rc = IC_OK;
                     for (int j = 0; j < PC_DEC_GRAPH && rc == IC_OK; ++j) rc = one_symbol();
                     const hipError_t e = hipStreamEndCapture(st, &graph);
                     if (rc == IC_OK && e == hipSuccess && graph &&
@@ -1041,20 +1046,20 @@ extern "C" int ic_pc_decode_f32(const uint8_t* bitstream, long long nbytes, int 
                         // the executable graph must outlive its last launch: wait before destroying it
                         (void)hipStreamSynchronize(st);
                         (void)hipGraphExecDestroy(exec);
-                        if (!launched) { (void)hipGraphDestroy(graph); return IC_ERR_ARG; }
+                        if (!launched) rc = IC_ERR_ARG;
                     }
                     if (graph) (void)hipGraphDestroy(graph);
                 }
                 (void)hipGetLastError();
-                for (; i < n; ++i) {
-                    int rc = one_symbol();
-                    if (rc) return rc;
-                }
-                if (hipMemcpyAsync(status, &a.st->error, sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess) return IC_ERR_ARG;
-                if (hipEventRecord(ev_out, own) != hipSuccess || hipStreamWaitEvent(caller, ev_out, 0) != hipSuccess) return IC_ERR_ARG;
-                IC_LAUNCH_CHECK();
-                return IC_OK;
+                for (; rc == IC_OK && i < n; ++i) rc = one_symbol();
+                if (rc == IC_OK && hipMemcpyAsync(status, &a.st->error, sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess) rc = IC_ERR_ARG;
+                // the caller's stream continues after everything queued on the private one (also on the error paths)
+                if (hipEventRecord(ev_out, own) != hipSuccess || hipStreamWaitEvent(caller, ev_out, 0) != hipSuccess) rc = rc ? rc : IC_ERR_ARG;
+                if (rc == IC_OK) { const hipError_t e2 = hipGetLastError(); if (e2 != hipSuccess) rc = (int)e2; }
+                release();           // destruction is deferred by the runtime until the queued work has drained
+                return rc;
             }
+            release();
         }
     }
     for (; i < n; ++i) {

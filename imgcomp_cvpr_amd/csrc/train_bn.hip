@@ -119,8 +119,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs a, long 
     }
 }
 
+#ifdef IC_TUNING
 static int g_bn_per_chunk = 1024;
-extern "C" int ic_bn_set_tuning(int elems_per_chunk) { const int p = g_bn_per_chunk; if (elems_per_chunk > 0) g_bn_per_chunk = elems_per_chunk; return p; }
+extern "C" int ic_bn_debug_set_tuning(int elems_per_chunk) { const int p = g_bn_per_chunk; if (elems_per_chunk > 0) g_bn_per_chunk = elems_per_chunk; return p; }
+#else
+static constexpr int g_bn_per_chunk = 1024;      // elements of a channel each stage-1 reduction block covers
+#endif
 static int bn_nchunks(int N, int HW) {
     long long n = ((long long)N * HW) / g_bn_per_chunk;
     return (int)(n < 1 ? 1 : (n > BN_CHUNKS ? BN_CHUNKS : n));

@@ -1,0 +1,48 @@
+// Declarations shared by the Winograd F(2x2,3x3) kernels of the 128 -> 128 channel 3x3 layer (conv3x3_wino.hip: 32 x 32 jobs,
+// K-split, 16 x 16 jobs; conv3x3_wino_tn.hip: 16 channels x NB x 16 tiles per wave).  reference: code/autoencoder.py:274-287.
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define WN_C 128
+#define WN_FRAG_FLOATS (16 * WN_C * WN_C)          // one layout of the transformed filter
+#define WN_PACKED_FLOATS (2 * WN_FRAG_FLOATS)      // [32-channel-tile fragments | 16-channel-tile fragments]
+#define WN_OOB 0x80000000u        // byte offset beyond any image (128 H W 4 < 2^31): the buffer load returns 0, a store is dropped
+
+struct WnArgs {
+    const float* x; const float* wp; const float* scale; const float* shift;
+    const float* res1; const float* res2; float* y;
+    int N, H, W, grows, gcols, relu;
+    int xcd_runs;               // 1 = contiguous runs of tile groups per XCD
+    int g0;                     // first tile group of this launch (a shape may be split into launches of different forms)
+    int ngroups;                // tile groups of this launch (the NB-segment kernels: 2 segments per group)
+    unsigned long long* prof;   // profiling builds (WN_PROF) only
+};
+
+#ifdef __HIPCC__
+// A tile row of 16 tiles is 16 lanes = one DPP row.
+__device__ __forceinline__ float dpp_from_left(float edge, float v) {    // lane i <- v of lane i-1; row lane 0 keeps edge
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x111, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_right(float edge, float v) {   // lane i <- v of lane i+1; row lane 15 keeps edge
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x101, 0xf, 0xf, false));
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#endif
+
+// conv3x3_wino_tn.hip: launches the NB-segment kernel over tile groups [a.g0, a.g0 + a.ngroups); nb in {1, 2, 3}
+int icx_wino_tn_launch(const WnArgs& a, int nb, int scalar_transform, hipStream_t st);

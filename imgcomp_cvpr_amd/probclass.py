@@ -126,10 +126,15 @@ class _Network3D(object):
 
     # -- forward --
 
-    @staticmethod
-    def _pad_value_as_float(pad_value):
+    def _pad_value_as_float(self, pad_value):
+        """The C ABI takes the pad value by value.  A tensor (centers[0], reference probclass.py:59-61) is fetched from the
+        device ONCE per distinct storage + version: a .item() per image would stall the host until everything queued on
+        the stream -- the whole encoder -- has finished, before the decoder could be enqueued."""
         if torch.is_tensor(pad_value):
-            return float(pad_value.item())
+            key = (pad_value.data_ptr(), pad_value._version)
+            if getattr(self, '_pad_cache', (None, None))[0] != key:
+                self._pad_cache = (key, float(pad_value.item()))
+            return self._pad_cache[1]
         return float(pad_value)
 
     def bitcost(self, q, target_symbols, is_training, pad_value=0):
@@ -289,7 +294,7 @@ class PredictionNetwork(object):
         """(pr, freqs), each (num_contexts, L), contexts in the order of iter_over_blocks."""
         return self._tables(symbols_padded)
 
-    def decode_stream(self, stream_bytes, symbols_shape, first_sym):
+    def decode_stream(self, stream_bytes, symbols_shape, first_sym, flags=0):
         """Row N3: the whole sequential decode on the device (ic_pc_decode_f32) -- per symbol the same context-model
         kernels as get_freqs, the table, the arithmetic-decoder step and the gather of the next context are enqueued
         back to back without a host round trip.  stream_bytes: what the encoder wrote; symbols_shape: un-padded
@@ -304,7 +309,7 @@ class PredictionNetwork(object):
         centers = self.centers.contiguous().float()
         check(lib.ic_pc_decode_f32(ptr(data), len(stream_bytes), int(first_sym), self.pc._tab, ptr(centers), self.pc._k,
                                    self.pc.L, self.freqs_resolution, ptr(out), ptr(status), C, h, w, ptr(ws), need,
-                                   _lib.current_stream(dev)), 'ic_pc_decode_f32')
+                                   int(flags), _lib.current_stream(dev)), 'ic_pc_decode_f32')
         if int(status.item()) != 0:
             raise ValueError('Cannot decode symbol because total is too large')
         return out.cpu().numpy()

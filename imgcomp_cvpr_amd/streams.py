@@ -13,10 +13,12 @@ context model completely (tools/bench_cumask.py: 3.15 -> 2.98 ms per Kodak image
         side = bs.context_model_stream(N, H, W)
         side.wait_stream(bs.main)
         with torch.cuda.stream(side): ... pc.bitcost(...)
-        bs.reserve_idle_cus(side is not bs._plain)
-        x_out = ae.decode(enc.qhard)
-        bs.reserve_idle_cus(False)
+        x_out = ae.decode(enc.qhard, False, plan_flags=bs.decode_flags(side))     # per-call: no library state is touched
         bs.main.wait_stream(side)
+
+Which arrangement is used is a constructor argument (`share`): 'cu_range' as above, or 'full_chip' -- the decoder's 3x3
+launches take the form that fills the chip (NB-segment jobs) and the context model runs on a plain second stream, filling
+whatever the decoder's launch boundaries leave.
 """
 import ctypes
 
@@ -25,10 +27,16 @@ import torch
 from . import _lib
 
 
+DEFAULT_SHARE = 'cu_range'
+
+
 class BranchStreams(object):
     MIN_CUS = 32          # fewer than this and the context model becomes the critical path of a Kodak-sized image
 
-    def __init__(self, device):
+    def __init__(self, device, share=None):
+        share = share or DEFAULT_SHARE
+        assert share in ('cu_range', 'full_chip')
+        self.share = share
         self.device = torch.device(device)
         self.main = torch.cuda.Stream(device=self.device)
         self._plain = torch.cuda.Stream(device=self.device)
@@ -38,9 +46,10 @@ class BranchStreams(object):
 
     def idle_cus(self, N, H, W):
         """CUs the decoder's 3x3 launches leave idle for an (N, 3, H, W) image, rounded down to whole CUs per XCD."""
-        _lib.lib.ic_wino3x3_c128_set_tuning(7, 1)          # the plan the decoder runs when it leaves its idle CUs alone
-        wgs = int(_lib.lib.ic_wino3x3_c128_workgroups(N, H // 4, W // 4))
-        _lib.lib.ic_wino3x3_c128_set_tuning(7, 0)
+        if self.share != 'cu_range':
+            return 0
+        # the plan the decoder runs when it is asked to leave its idle CUs alone
+        wgs = int(_lib.lib.ic_wino3x3_c128_workgroups(N, H // 4, W // 4, _lib.CONV3_LEAVE_IDLE_CUS))
         if wgs <= 0 or wgs >= self.n_cus:
             return 0
         return min((self.n_cus - wgs) // 8 * 8, self.n_cus // 2)
@@ -60,10 +69,10 @@ class BranchStreams(object):
                 self._ranged[n] = torch.cuda.ExternalStream(h.value, device=self.device)
         return self._ranged[n]
 
-    def reserve_idle_cus(self, on):
-        """Around the launches of the branch that shares the chip with a CU-range stream: its partly filled 3x3 rounds stay
-        whole-K (one work-group per CU, the idle CUs untouched) instead of being spread over every CU as 16 x 16 jobs."""
-        _lib.lib.ic_wino3x3_c128_set_tuning(7, 1 if on else 0)
+    def decode_flags(self, side):
+        """plan flags for the ae.decode call that shares the chip with `side`: next to a CU-range stream its partly filled 3x3
+        rounds stay one work-group per CU (the idle CUs untouched) instead of being spread over every CU."""
+        return _lib.CONV3_LEAVE_IDLE_CUS if side is not self._plain else 0
 
     def close(self):
         for h in self._handles:

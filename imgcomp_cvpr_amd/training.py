@@ -150,7 +150,7 @@ class TrainGraph(object):
         """Winograd fragments of every 3x3 filter, forward and adjoint, in two launches (the filters change every step).
         No-op when the shape runs the direct form."""
         self._wino_pk = None
-        if lib.ic_conv3x3_c128_pick_algo(N, H, W) != 1:
+        if lib.ic_conv3x3_c128_pick_algo(N, H, W, 0) != 1:
             return
         if not hasattr(self, '_w3_names'):
             self._w3_names = [l.scope + '/weights' for l in self.layers.values()
@@ -171,20 +171,20 @@ class TrainGraph(object):
         y = self._new(N, 128, H, W)
         st = self._st()
         w_tf = self.params[name] if isinstance(name, str) else name
-        if lib.ic_conv3x3_c128_pick_algo(N, H, W) == 1:
+        if lib.ic_conv3x3_c128_pick_algo(N, H, W, 0) == 1:
             if isinstance(name, str) and getattr(self, '_wino_pk', None) is not None:
                 wp = self._wino_pk[int(backward), self._w3_index[name]]
             else:
                 wp = self._new(lib.ic_wino3x3_c128_packed_floats())
                 check(lib.ic_pack_wino3x3_c128_f32(ptr(w_tf), ptr(wp), int(backward), st))
             check(lib.ic_wino3x3_c128_bn_act_f32(ptr(x), ptr(wp), ptr(self.ones), ptr(self.zeros), None, None, ptr(y),
-                                                 N, H, W, 0, st), 'conv3x3 (winograd)')
+                                                 N, H, W, 0, 0, st), 'conv3x3 (winograd)')
         else:
             wp = self._new(lib.ic_conv3x3_c128_packed_floats())
             f = lib.ic_pack_conv3x3_c128_bwd_f32 if backward else lib.ic_pack_conv3x3_c128_f32
             check(f(ptr(w_tf), ptr(wp), st))
             check(lib.ic_conv3x3_c128_bn_act_f32(ptr(x), ptr(wp), ptr(self.ones), ptr(self.zeros), None, None, ptr(y),
-                                                 N, H, W, 0, st), 'conv3x3')
+                                                 N, H, W, 0, 0, st), 'conv3x3')
         return y
 
     def _conv_s(self, x, w_tf, kh, kw, cin, cout, stride):
@@ -214,7 +214,7 @@ class TrainGraph(object):
                                                 cout, kh, kw, 2, 1, 0, self._st()), 'deconv mfma')
         else:
             check(lib.ic_deconv2d_bn_act_f32(ptr(x), ptr(w_tf), ptr(self.ones), ptr(self.zeros), ptr(y), N, cin, H, W,
-                                             cout, kh, kw, 0, None, None, self._st()), 'deconv direct')
+                                             cout, kh, kw, 0, None, None, 0, self._st()), 'deconv direct')
         return y
 
     def _raw_forward(self, l, x):

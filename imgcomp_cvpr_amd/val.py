@@ -192,9 +192,7 @@ class Fetcher(object):
         with torch.cuda.stream(side):
             bc = self.pc.bitcost(enc.qbar, enc.symbols, is_training=False, pad_value=self.pc.auto_pad_value(self.ae))
             bpp = bits.bitcost_to_bpp(bc, x)
-        self._streams.reserve_idle_cus(side is not self._streams._plain)
-        x_out = self.ae.decode(enc.qhard, is_training=False)
-        self._streams.reserve_idle_cus(False)
+        x_out = self.ae.decode(enc.qhard, is_training=False, plan_flags=self._streams.decode_flags(side))
         cur.wait_stream(side)
         x_out_uint8_dev = x_out.to(torch.uint8)                    # tf.cast truncates (val.py:91)
         if self.host_metrics:

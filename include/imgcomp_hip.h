@@ -11,8 +11,12 @@
  *  - all pointers are DEVICE pointers unless the name ends in _host; the caller owns every
  *    buffer including workspaces; the library never allocates device memory;
  *  - tensors are dense fp32 NCHW, symbols are int64 (reference: quantizer.py:46);
- *  - `stream` is a hipStream_t passed as void*; calls are asynchronous on it and re-entrant
- *    (no global mutable state);
+ *  - `stream` is a hipStream_t passed as void*; calls are asynchronous on it and re-entrant: the library keeps NO
+ *    process-wide mutable state.  Everything that selects a kernel form, a launch plan or a test-only code path is a
+ *    bit of the per-call `flags` argument of the entry point concerned (IC_CONV3_*, IC_EDGE_*, IC_PC_*; 0 = automatic),
+ *    so two host threads may drive two pipelines through the library concurrently.  (Profiling builds of single
+ *    translation units -- -DWN_PROF, -DH13_PROF, -DIC_TUNING -- add ic_*_debug_* setters; they are not part of this ABI
+ *    and not compiled into libimgcomp_hip.so.);
  *  - return value: 0 = ok, < 0 = argument error (IC_ERR_*), > 0 = hipError_t of a failed launch;
  *  - weights use the reference's TF variable layouts unless a function says "packed".
  */
@@ -26,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IC_ABI_VERSION 1
+#define IC_ABI_VERSION 2
 
 #define IC_OK 0
 #define IC_ERR_ARG (-1)          /* null pointer / non-positive extent */
@@ -34,6 +38,33 @@ extern "C" {
 #define IC_ERR_WORKSPACE (-3)    /* workspace too small */
 
 typedef void* ic_stream_t;
+
+/* ---- per-call plan flags ------------------------------------------------------------------------------------------
+ * 3x3 128->128 layer (ic_conv3x3_c128_bn_act_f32, ic_wino3x3_c128_bn_act_f32, ic_conv3x3_c128_auto_f32,
+ * ic_wino3x3_c128_workgroups, ic_conv3x3_c128_pick_algo, and passed through by ic_ae_encode_f32 / ic_ae_decode_f32).
+ * Bits 0-3: the form.  0 = automatic (from the shape: Winograd wherever 31-bit offsets reach, decomposition by the cost
+ * model of conv3x3_wino.hip:wino_plan); the others force one form for the whole launch (tests, benchmarks). */
+#define IC_CONV3_FORM_MASK        0x0f
+#define IC_CONV3_AUTO             0x00
+#define IC_CONV3_DIRECT           0x01   /* implicit-GEMM direct form (needs the `both` blob or the direct packing) */
+#define IC_CONV3_WINO             0x02   /* Winograd, decomposition automatic */
+#define IC_CONV3_WINO_WHOLEK      0x03   /* 32x32 jobs, 4 channel tiles per work-group, input transform shared through LDS */
+#define IC_CONV3_WINO_WHOLEK_PW   0x04   /* the same with a per-wave input transform (the whole-K form of odd widths) */
+#define IC_CONV3_WINO_KSPLIT      0x05   /* one channel tile per work-group, 4 K-quarters summed through LDS */
+#define IC_CONV3_WINO_T16         0x06   /* 16x16 jobs, two-slot ring (round-1 kernel; even widths) */
+#define IC_CONV3_WINO_SEG1        0x07   /* 16 channels x NB segments of 16 tiles per wave, NB = 1 / 2 / 3 (even widths) */
+#define IC_CONV3_WINO_SEG2        0x08
+#define IC_CONV3_WINO_SEG3        0x09
+/* partly filled rounds stay one-work-group-per-CU and the CUs beyond the tile groups stay free: a caller's independent
+ * branch runs there on a CU-range stream (ic_stream_create_cu_range; imgcomp_cvpr_amd/streams.py) */
+#define IC_CONV3_LEAVE_IDLE_CUS   0x10
+#define IC_CONV3_NO_XCD_RUNS      0x20   /* natural tile order instead of contiguous runs of tiles per XCD (A/B runs) */
+#define IC_CONV3_PACKED_TRANSFORM 0x40   /* NB-segment kernels: input transform on v_pk_add_f32 instead of single adds (A/B) */
+#define IC_CONV3_DIRECT_VARIANT(v) ((((v) + 1) & 0xf) << 8)   /* direct form: force tile variant v (0..9); tests */
+/* h13 (ic_deconv2d_bn_act_f32, 5x5/2 transposed, 64 -> <= 4): tiles per work-group, 0 = automatic; tests */
+#define IC_EDGE_TILES_PER_WG(n)   ((n) & 0xff)
+/* ic_pc_decode_f32: always the launch-per-layer loop, also for k = 24 (tests) */
+#define IC_PC_DECODE_PER_LAYER    0x01
 
 int ic_abi_version(void);
 /* static string for a return code of this library (hipGetErrorString for codes > 0) */
@@ -68,12 +99,11 @@ int ic_conv2d_bn_act_f32(const float* x, const float* w, const float* scale, con
  */
 int ic_deconv2d_bn_act_f32(const float* x, const float* w, const float* scale, const float* shift,
                            float* y, int N, int Cin, int H, int W, int Cout, int KH, int KW, int relu,
-                           const float* out_mean, const float* out_std, ic_stream_t stream);
+                           const float* out_mean, const float* out_std, int flags, ic_stream_t stream);
 /* The three edge layers of the autoencoder run on the matrix cores inside the two entry points above, straight
  * from the TF filter layouts: h1 (conv 5x5/2, 3 -> 64, :222), from_bn (deconv 3x3/2, C = 32|64 -> 128, :251) and
  * h13 (deconv 5x5/2, 64 -> <= 4, :265).  Every other shape takes the generic direct kernels.
- * tuning only: key 0 = tiles per work-group of the h13 kernel (0 = automatic, the default) */
-void ic_edge_set_tuning(int key, int value);
+ * flags: IC_EDGE_TILES_PER_WG(n) for the h13 kernel, 0 = automatic. */
 
 /* ---------------------------------------------------------------------------------------------
  * MFMA fast path for the 64 residual 3x3 convs (128 -> 128 channels, stride 1):
@@ -86,16 +116,7 @@ size_t ic_conv3x3_c128_packed_floats(void);
 int ic_pack_conv3x3_c128_f32(const float* w_tf, float* w_packed, ic_stream_t stream);
 int ic_conv3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale,
                                const float* shift, const float* res1, const float* res2, float* y,
-                               int N, int H, int W, int relu, ic_stream_t stream);
-/* tile variant override for tuning/tests: -1 = automatic (default).  Returns previous value.
- * Process-wide knob read at launch time; not part of the data path contract. */
-int ic_conv3x3_c128_set_variant(int variant);
-/* tuning knobs (not part of the data-path contract): key 0 = tile variant, 1 = extra dynamic LDS bytes
- * per work-group, 2 = inner-loop schedule (0 compiler, 1 explicit register double buffer). Returns previous. */
-int ic_conv3x3_c128_set_tuning(int key, int value);
-/* tuning only: device buffer of 4 x u64 per work-group receiving shader-clock stamps
- * {start, prologue done, main loop done, end}; NULL disables (default). */
-void ic_conv3x3_c128_set_debug_buffer(void* dev_u64);
+                               int N, int H, int W, int relu, int flags, ic_stream_t stream);
 
 /* The same layer (3x3, stride 1, 128 -> 128, autoencoder.py:274-287) in Winograd F(2x2,3x3) form: 16/36 of the
  * multiply-adds of the direct form; input transforms in registers, shared between the waves of a work-group through LDS.
@@ -112,32 +133,28 @@ int ic_pack_wino3x3_c128_batch_f32(const float* const* w_tf_table_dev, float* w_
                                    ic_stream_t stream);
 int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale,
                                const float* shift, const float* res1, const float* res2, float* y,
-                               int N, int H, int W, int relu, ic_stream_t stream);
-/* tuning / tests: key 2 = work decomposition (-1 automatic, 0 whole-K waves: 4 output-channel tiles per work-group,
- * 1 K-split: one channel tile per work-group, 4 quarters of the input channels summed through LDS after the output
- * transform).  Automatic: full rounds of 256 tile groups whole-K, a remainder of <= 128 groups as a second, K-split launch;
- * key 3 = cost of a whole-K round in K-split rounds x 100 (default 270) for that choice; key 4 = whole-K input transform
- * shared through LDS (default 1); key 5 = XCD-contiguous tile order (default 1); key 6 = 16 x 16 jobs on
- * v_mfma_f32_16x16x4_f32 (-1 automatic: a last whole-K round that would leave >= 1/4 of the CUs idle; 0 never; 1 always);
- * key 7 = 1: leave those CUs idle (a caller's concurrent branch runs there, ic_stream_create_cu_range); keys 0, 1: profiling
- * builds. */
-void ic_wino3x3_c128_set_tuning(int key, int value);
-/* work-groups of the launch above for this shape; each occupies one whole CU (what a caller sizing a CU-range stream
- * for an independent branch needs to know, see ic_stream_create_cu_range) */
-long long ic_wino3x3_c128_workgroups(int N, int H, int W);
+                               int N, int H, int W, int relu, int flags, ic_stream_t stream);
+/* Launch plan (conv3x3_wino.hip:wino_plan; flags = 0): the form is chosen per call from the number of tile groups
+ * (4 x 32 output pixels each) by a cost model in matrix-pipe clocks -- full rounds of 256 whole-K work-groups, a small
+ * remainder as K-split work-groups, or the whole map as NB-segment jobs (NB = 1, 2, 3) when that fills the chip more
+ * evenly (a Kodak map: 384 segments = 256 work-groups of NB = 3, one wave-job per SIMD).
+ * ic_wino3x3_c128_workgroups: CUs the launch(es) for this shape and these flags keep busy at a time (>= 256: the whole
+ * chip, in rounds) -- what a caller sizing a CU-range stream for an independent branch needs to know. */
+long long ic_wino3x3_c128_workgroups(int N, int H, int W, int flags);
+/* the plan itself (host arithmetic only): tile groups given to each form,
+ * plan_out = {whole-K, NB-segment jobs, NB of those jobs, 16x16 two-slot, K-split} */
+int ic_wino3x3_c128_plan(int N, int H, int W, int flags, long long plan_out[5]);
 
 /* Both forms behind ONE packed filter [direct fragments | Winograd fragments]; this is what ic_ae_encode_f32 /
  * ic_ae_decode_f32 expect in their tables for the 3x3 layers and what the training step uses (backward != 0: adjoint).
- * ic_conv3x3_c128_auto_f32 picks the form per launch from (N, H, W) -- ic_conv3x3_c128_pick_algo returns the choice
- * (0 direct, 1 Winograd); ic_conv3x3_c128_set_algo(-1 | 0 | 1) overrides it process-wide (tests, benchmarks) and
- * returns the previous setting. */
+ * ic_conv3x3_c128_auto_f32 picks the form per launch from (N, H, W) and the caller's flags -- ic_conv3x3_c128_pick_algo
+ * returns the choice (0 direct, 1 Winograd). */
 size_t ic_conv3x3_c128_both_packed_floats(void);
 int ic_pack_conv3x3_c128_both_f32(const float* w_tf, float* w_packed, int backward, ic_stream_t stream);
-int ic_conv3x3_c128_pick_algo(int N, int H, int W);
-int ic_conv3x3_c128_set_algo(int algo);
+int ic_conv3x3_c128_pick_algo(int N, int H, int W, int flags);
 int ic_conv3x3_c128_auto_f32(const float* x, const float* w_both, const float* scale, const float* shift,
                              const float* res1, const float* res2, float* y, int N, int H, int W, int relu,
-                             ic_stream_t stream);
+                             int flags, ic_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * MFMA path for the strided 5x5 layers around the residual stacks: h2 (autoencoder.py:223, conv 64->128),
@@ -215,11 +232,10 @@ int ic_pc_logits_to_freqs_f32(const float* logits, long long count, int L, float
  *   symbols: out, device int64 (C,h,w);  status: out, device int (0 ok, 1 = a table's total exceeded the coder's range)
  *   wtab_host / k / L as ic_pc_logits_f32.  workspace: ic_pc_decode_workspace_bytes(C, h, w, k). */
 size_t ic_pc_decode_workspace_bytes(int C, int h, int w, int k);
-/* tests: 1 forces the launch-per-layer loop, 0 (default) lets k = 24 run as one persistent work-group; returns previous */
-int ic_pc_decode_set_mode(int mode);
+/* flags: IC_PC_DECODE_PER_LAYER forces the launch-per-layer loop (tests); 0 lets k = 24 run as one persistent work-group */
 int ic_pc_decode_f32(const uint8_t* bitstream, long long nbytes, int first_sym, const float* const* wtab_host,
                      const float* centers, int k, int L, float resolution, int64_t* symbols, int* status,
-                     int C, int h, int w, void* workspace, size_t workspace_bytes, ic_stream_t stream);
+                     int C, int h, int w, void* workspace, size_t workspace_bytes, int flags, ic_stream_t stream);
 /* bits -> sum(bits) (bits.py:4-14 numerator); deterministic two-stage reduction.
  * partial: >= 1024 floats of scratch.  out_sum: 1 float. */
 int ic_sum_f32(const float* v, long long count, float* partial, float* out_sum, ic_stream_t stream);
@@ -237,15 +253,17 @@ int ic_sum_f32(const float* v, long long count, float* partial, float* out_sum, 
  * B = arch_param_B (5).  C = num_chan_bn.  x: (N,3,H,W) float 0..255, H and W multiples of 8.
  * Outputs of encode (each nullable except symbols/qhard): heatmap,z,qsoft,qhard,qbar (N,C,H/8,W/8),
  * symbols int64.  decode: q (N,C,H/8,W/8) -> x_out (N,3,H,W) clipped to [0,255].
+ * flags: IC_CONV3_* for the 64 3x3 launches of the call (e.g. IC_CONV3_LEAVE_IDLE_CUS while an independent branch runs
+ * on the CUs a partly filled round leaves free).
  */
 size_t ic_ae_workspace_bytes(int N, int H, int W, int C);
 int ic_ae_encode_f32(const float* x, const void* const* enc_tab_host, int B, int C, int L, int heatmap_on,
                      int normalize_on, float* heatmap, float* z, float* qsoft, float* qhard, float* qbar,
                      int64_t* symbols, int N, int H, int W,
-                     void* workspace, size_t workspace_bytes, ic_stream_t stream);
+                     void* workspace, size_t workspace_bytes, int flags, ic_stream_t stream);
 int ic_ae_decode_f32(const float* q, const void* const* dec_tab_host, int B, int C, int normalize_on,
                      float* x_out, int N, int H, int W,
-                     void* workspace, size_t workspace_bytes, ic_stream_t stream);
+                     void* workspace, size_t workspace_bytes, int flags, ic_stream_t stream);
 
 /* ic_bn_stats_f32 plus everything the training loop folds from it, in the same two launches:
  *   mean, invstd = 1/sqrt(var + eps), scale = gamma * invstd, shift = beta - mean * scale   (all [C], outputs)
@@ -267,8 +285,6 @@ size_t ic_bn_workspace_bytes(int C);
 /* batch mean and BIASED variance per channel of x (N,C,HW) (autoencoder.py:114-125, is_training=True) */
 int ic_bn_stats_f32(const float* x, float* mean, float* var, int N, int C, int HW, void* workspace, ic_stream_t stream);
 /* y = act(x * scale[c] + shift[c]) + res1 + res2 */
-/* tuning only: elements of a channel each stage-1 reduction block covers (default 1024); returns the previous value */
-int ic_bn_set_tuning(int elems_per_chunk);
 int ic_bn_apply_f32(const float* x, const float* scale, const float* shift, const float* res1, const float* res2,
                     float* y, int N, int C, int HW, int relu, ic_stream_t stream);
 /* BN(+ReLU) backward: g = dy * [x*scale+shift > 0 if relu]; dbeta = sum g; dgamma = sum g*xhat;

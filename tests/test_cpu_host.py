@@ -169,7 +169,14 @@ def test_abi_header_bindings_and_exports_agree():
     out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
     exported = set(re.findall(r' T (ic_[a-z0-9_]+)', out))
     assert names <= exported, names - exported
-    assert _lib.lib.ic_abi_version() == 1
+    assert _lib.lib.ic_abi_version() == 2
+    # re-entrant, no global mutable state -- the product library exports no setter of any kind (the
+    # ic_*_debug_* hooks of profiling builds are compiled out), and the python mirror of the per-call flags matches the header
+    assert not [n for n in exported if 'set_' in n or 'debug' in n], [n for n in exported if 'set_' in n or 'debug' in n]
+    hdr = open(os.path.join(ROOT, 'include', 'imgcomp_hip.h')).read()
+    for name, val in re.findall(r'#define IC_(CONV3_[A-Z0-9_]+|PC_DECODE_PER_LAYER)\s+(0x[0-9a-f]+)', hdr):
+        assert getattr(_lib, name) == int(val, 16), name
+    assert _lib.conv3_direct_variant(3) == 0x400 and _lib.edge_tiles_per_wg(3) == 3
     assert _lib.lib.ic_strerror(-3) == b'workspace too small'
     assert _lib.lib.ic_conv3x3_c128_packed_floats() == 9 * 128 * 128
     # size queries are pure host arithmetic

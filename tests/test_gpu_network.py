@@ -20,13 +20,16 @@ def nets(cuda, configs, syn_weights):
     return ae, pc
 
 
-@pytest.fixture(params=[0, 1], ids=['direct3x3', 'winograd3x3'])
-def algo(request):
-    """force one form of the 3x3 layers for the whole network (the default picks per launch from the shape)."""
+@pytest.fixture(params=['direct3x3', 'winograd3x3', 'wino_seg3', 'wino_seg2'])
+def algo(request, nets):
+    """force one form of the 3x3 layers for the whole network (the default picks per launch from the shape): a per-object
+    plan flag that every encode / decode call of THIS autoencoder passes down -- the library has no process-wide switch."""
     from imgcomp_cvpr_amd import _lib
-    prev = _lib.lib.ic_conv3x3_c128_set_algo(request.param)
+    ae, _ = nets
+    ae.plan_flags = {'direct3x3': _lib.CONV3_DIRECT, 'winograd3x3': _lib.CONV3_WINO, 'wino_seg3': _lib.CONV3_WINO_SEG3,
+                     'wino_seg2': _lib.CONV3_WINO_SEG2}[request.param]
     yield request.param
-    _lib.lib.ic_conv3x3_c128_set_algo(prev)
+    ae.plan_flags = 0
 
 
 def _boundary_margin(z64, centers):
@@ -124,12 +127,17 @@ def test_full_size_properties(cuda, configs, syn_weights, nets, algo):
     z1, s1 = e1.z.clone(), e1.symbols.clone()
     e2 = ae.encode(x, False)
     assert torch.equal(z1, e2.z) and torch.equal(s1, e2.symbols), 'encode is not deterministic'
-    prev = _lib.lib.ic_conv3x3_c128_set_variant(0)
-    try:
-        e3 = ae.encode(x, False)
-    finally:
-        _lib.lib.ic_conv3x3_c128_set_variant(prev)
-    assert torch.equal(z1, e3.z), 'result depends on the MFMA tile variant'
+    if algo == 'direct3x3':
+        e3 = ae.encode(x, False, plan_flags=_lib.conv3_direct_variant(0))
+        assert torch.equal(z1, e3.z), 'result depends on the MFMA tile variant'
+    elif algo == 'winograd3x3':
+        # every Winograd decomposition performs the same operations per output: bit-identical
+        for form in (_lib.CONV3_WINO_WHOLEK, _lib.CONV3_WINO_T16, _lib.CONV3_WINO_SEG1, _lib.CONV3_WINO_SEG2, _lib.CONV3_WINO_SEG3,
+                     _lib.CONV3_WINO_SEG3 | _lib.CONV3_PACKED_TRANSFORM):
+            ae.plan_flags = form
+            e3 = ae.encode(x, False)
+            assert torch.equal(z1, e3.z), 'Winograd form {:#x} differs'.format(form)
+        ae.plan_flags = _lib.CONV3_WINO
     xo = ae.decode(e1.qhard, False)
     assert xo.shape == x.shape and float(xo.min()) >= 0 and float(xo.max()) <= 255
     bc = pc.bitcost(e1.qbar, e1.symbols, False, pad_value=pc.auto_pad_value(ae))
@@ -190,11 +198,7 @@ def test_device_decoder_stream(cuda, configs, syn_weights, nets, tmp_path):
     out = pred.decode_stream(data, sym.shape, first)                        # k = 24: one persistent work-group
     assert out.dtype == np.int64 and np.array_equal(out, sym)
     from imgcomp_cvpr_amd import _lib
-    prev = _lib.lib.ic_pc_decode_set_mode(1)                                # the launch-per-layer loop (any k)
-    try:
-        out2 = pred.decode_stream(data, sym.shape, first)
-    finally:
-        _lib.lib.ic_pc_decode_set_mode(prev)
+    out2 = pred.decode_stream(data, sym.shape, first, flags=_lib.PC_DECODE_PER_LAYER)      # the launch-per-layer loop (any k)
     assert np.array_equal(out2, sym)
     ref = pred.undo_pad_symbols_volume(bit_counter._decode(path, padded.shape, pred.input_ctx_shape, first, pred.get_freqs))
     assert np.array_equal(ref, sym)
@@ -332,10 +336,8 @@ def test_branch_streams_cu_range(cuda, configs, syn_weights, nets):
     bs = streams.BranchStreams(cuda)
     try:
         # Kodak: 192 whole-K work-groups -> on a 256-CU MI355X a quarter of the chip is idle; 4K: the decoder fills every round
-        assert int(_lib.lib.ic_wino3x3_c128_workgroups(1, 128, 192)) >= 256      # alone, the layer is spread over the whole chip
-        bs.reserve_idle_cus(True)
-        wgs = int(_lib.lib.ic_wino3x3_c128_workgroups(1, 128, 192))             # next to a CU-range stream it stays whole-K
-        bs.reserve_idle_cus(False)
+        assert int(_lib.lib.ic_wino3x3_c128_workgroups(1, 128, 192, 0)) >= 256   # alone, the layer is spread over the whole chip
+        wgs = int(_lib.lib.ic_wino3x3_c128_workgroups(1, 128, 192, _lib.CONV3_LEAVE_IDLE_CUS))   # next to a CU-range stream it stays whole-K
         assert wgs == 192
         expect = min((bs.n_cus - wgs) // 8 * 8, bs.n_cus // 2) if wgs < bs.n_cus else 0
         assert bs.idle_cus(1, 512, 768) == expect
@@ -348,7 +350,7 @@ def test_branch_streams_cu_range(cuda, configs, syn_weights, nets):
         x = dev(W.synthetic_image((1, 3, 128, 192), 'natural', seed=5), cuda)
         pad = pc.auto_pad_value(ae)
         enc = ae.encode(x, False)
-        ref_out = ae.decode(enc.qhard, False)
+        ref_out = ae.decode(enc.qhard, False, plan_flags=_lib.CONV3_WINO_WHOLEK)
         ref_bpp = float(bits.bitcost_to_bpp(pc.bitcost(enc.qbar, enc.symbols, False, pad_value=pad), x))
         torch.cuda.synchronize()
         outer = torch.cuda.current_stream(cuda)
@@ -359,9 +361,7 @@ def test_branch_streams_cu_range(cuda, configs, syn_weights, nets):
                 side.wait_stream(bs.main)
                 with torch.cuda.stream(side):
                     bpp = bits.bitcost_to_bpp(pc.bitcost(enc.qbar, enc.symbols, False, pad_value=pad), x)
-                bs.reserve_idle_cus(True)
-                out = ae.decode(enc.qhard, False)
-                bs.reserve_idle_cus(False)
+                out = ae.decode(enc.qhard, False, plan_flags=bs.decode_flags(side))
                 bs.main.wait_stream(side)
         outer.wait_stream(bs.main)
         torch.cuda.synchronize()

@@ -92,7 +92,7 @@ def test_deconv2d(cuda, name, N, Cin, H, W, Cout, K, relu, denorm):
     tens = [d(x), d(w), d(scale), d(shift)]
     m_d, s_d = (d(mean.flatten()), d(std.flatten())) if denorm else (None, None)
     L.check(L.lib.ic_deconv2d_bn_act_f32(L.ptr(tens[0]), L.ptr(tens[1]), L.ptr(tens[2]), L.ptr(tens[3]), L.ptr(y),
-                                         N, Cin, H, W, Cout, K, K, relu, L.ptr(m_d), L.ptr(s_d), L.current_stream()))
+                                         N, Cin, H, W, Cout, K, K, relu, L.ptr(m_d), L.ptr(s_d), 0, L.current_stream()))
     torch.cuda.synchronize()
     ref = _ref_conv(x, w, scale, shift, 2, relu, transposed=True, denorm=denorm)
     assert_close(y, ref, 'deconv2d ' + name)
@@ -155,22 +155,19 @@ def test_conv3x3_c128_mfma(cuda, variant, N, H, W):
     xd, wd, sd, hd, r1d, r2d = d(x), d(w), d(scale), d(shift), d(r1), d(r2)
     wp = torch.empty(L.lib.ic_conv3x3_c128_packed_floats(), device=cuda)
     L.check(L.lib.ic_pack_conv3x3_c128_f32(L.ptr(wd), L.ptr(wp), L.current_stream()))
-    prev = L.lib.ic_conv3x3_c128_set_variant(variant)
-    try:
-        for relu, res in ((1, ()), (0, (r1d,)), (0, (r1d, r2d))):
-            y = torch.full((N, 128, H, W), float('nan'), device=cuda)
-            L.check(L.lib.ic_conv3x3_c128_bn_act_f32(
-                L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(res[0]) if len(res) > 0 else None,
-                L.ptr(res[1]) if len(res) > 1 else None, L.ptr(y), N, H, W, relu, L.current_stream()))
-            torch.cuda.synchronize()
-            ref = _ref_conv(x, w, scale, shift, 1, relu, res=[r.cpu().numpy() for r in res])
-            assert_close(y, ref, 'conv3x3 mfma variant {} relu {} nres {}'.format(variant, relu, len(res)))
-    finally:
-        L.lib.ic_conv3x3_c128_set_variant(prev)
+    flags = L.conv3_direct_variant(variant) if variant >= 0 else 0
+    for relu, res in ((1, ()), (0, (r1d,)), (0, (r1d, r2d))):
+        y = torch.full((N, 128, H, W), float('nan'), device=cuda)
+        L.check(L.lib.ic_conv3x3_c128_bn_act_f32(
+            L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(res[0]) if len(res) > 0 else None,
+            L.ptr(res[1]) if len(res) > 1 else None, L.ptr(y), N, H, W, relu, flags, L.current_stream()))
+        torch.cuda.synchronize()
+        ref = _ref_conv(x, w, scale, shift, 1, relu, res=[r.cpu().numpy() for r in res])
+        assert_close(y, ref, 'conv3x3 mfma variant {} relu {} nres {}'.format(variant, relu, len(res)))
 
 
-@pytest.mark.parametrize('shape', [-1, 0, 1])
-@pytest.mark.parametrize('N,H,W', [(1, 16, 64), (2, 13, 21), (1, 7, 5), (1, 40, 72)])
+@pytest.mark.parametrize('shape', ['auto', 'wholek', 'wholek_pw', 'ksplit', 't16', 'seg1', 'seg2', 'seg3', 'seg3_pk'])
+@pytest.mark.parametrize('N,H,W', [(1, 16, 64), (2, 13, 21), (1, 7, 5), (1, 40, 72), (3, 10, 34)])
 def test_conv3x3_c128_winograd(cuda, shape, N, H, W):
     """the Winograd F(2x2,3x3) form of the same layer: interior and border groups, odd sizes, ReLU / residuals,
     and the adjoint packing (data gradient) against the adjoint of the oracle's conv."""
@@ -185,29 +182,29 @@ def test_conv3x3_c128_winograd(cuda, shape, N, H, W):
     xd, wd, sd, hd, r1d, r2d = d(x), d(w), d(scale), d(shift), d(r1), d(r2)
     wp = torch.empty(L.lib.ic_wino3x3_c128_packed_floats(), device=cuda)
     L.check(L.lib.ic_pack_wino3x3_c128_f32(L.ptr(wd), L.ptr(wp), 0, L.current_stream()))
-    # `shape` doubles as the K-split switch: -1 automatic, 0 whole-K waves, 1 four K-quarters per work-group
-    L.lib.ic_wino3x3_c128_set_tuning(2, shape)
-    try:
-        for relu, res in ((1, ()), (0, (r1d,)), (0, (r1d, r2d))):
-            y = torch.full((N, 128, H, W), float('nan'), device=cuda)
-            L.check(L.lib.ic_wino3x3_c128_bn_act_f32(
-                L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(res[0]) if len(res) > 0 else None,
-                L.ptr(res[1]) if len(res) > 1 else None, L.ptr(y), N, H, W, relu, L.current_stream()))
-            torch.cuda.synchronize()
-            ref = _ref_conv(x, w, scale, shift, 1, relu, res=[r.cpu().numpy() for r in res])
-            assert_close(y, ref, 'winograd shape {} relu {} nres {}'.format(shape, relu, len(res)))
-        # adjoint packing: conv with the flipped, channel-swapped filter
-        L.check(L.lib.ic_pack_wino3x3_c128_f32(L.ptr(wd), L.ptr(wp), 1, L.current_stream()))
-        ones, zeros = torch.ones(128, device=cuda), torch.zeros(128, device=cuda)
+    # the decomposition is a per-call flag (odd widths have the per-wave whole-K and the K-split kernels: the even-width
+    # forms fall back to whole-K there, which the library does by itself)
+    flags = {'auto': 0, 'wholek': L.CONV3_WINO_WHOLEK, 'wholek_pw': L.CONV3_WINO_WHOLEK_PW, 'ksplit': L.CONV3_WINO_KSPLIT,
+             't16': L.CONV3_WINO_T16, 'seg1': L.CONV3_WINO_SEG1, 'seg2': L.CONV3_WINO_SEG2, 'seg3': L.CONV3_WINO_SEG3,
+             'seg3_pk': L.CONV3_WINO_SEG3 | L.CONV3_PACKED_TRANSFORM}[shape]
+    for relu, res in ((1, ()), (0, (r1d,)), (0, (r1d, r2d))):
         y = torch.full((N, 128, H, W), float('nan'), device=cuda)
-        L.check(L.lib.ic_wino3x3_c128_bn_act_f32(L.ptr(xd), L.ptr(wp), L.ptr(ones), L.ptr(zeros), None, None, L.ptr(y),
-                                                 N, H, W, 0, L.current_stream()))
+        L.check(L.lib.ic_wino3x3_c128_bn_act_f32(
+            L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(res[0]) if len(res) > 0 else None,
+            L.ptr(res[1]) if len(res) > 1 else None, L.ptr(y), N, H, W, relu, flags, L.current_stream()))
         torch.cuda.synchronize()
-        w_adj = np.ascontiguousarray(w[::-1, ::-1].transpose(0, 1, 3, 2))
-        ref = _ref_conv(x, w_adj, np.ones(128, np.float32), np.zeros(128, np.float32), 1, 0)
-        assert_close(y, ref, 'winograd adjoint shape {}'.format(shape))
-    finally:
-        L.lib.ic_wino3x3_c128_set_tuning(2, -1)
+        ref = _ref_conv(x, w, scale, shift, 1, relu, res=[r.cpu().numpy() for r in res])
+        assert_close(y, ref, 'winograd shape {} relu {} nres {}'.format(shape, relu, len(res)))
+    # adjoint packing: conv with the flipped, channel-swapped filter
+    L.check(L.lib.ic_pack_wino3x3_c128_f32(L.ptr(wd), L.ptr(wp), 1, L.current_stream()))
+    ones, zeros = torch.ones(128, device=cuda), torch.zeros(128, device=cuda)
+    y = torch.full((N, 128, H, W), float('nan'), device=cuda)
+    L.check(L.lib.ic_wino3x3_c128_bn_act_f32(L.ptr(xd), L.ptr(wp), L.ptr(ones), L.ptr(zeros), None, None, L.ptr(y),
+                                             N, H, W, 0, flags, L.current_stream()))
+    torch.cuda.synchronize()
+    w_adj = np.ascontiguousarray(w[::-1, ::-1].transpose(0, 1, 3, 2))
+    ref = _ref_conv(x, w_adj, np.ones(128, np.float32), np.zeros(128, np.float32), 1, 0)
+    assert_close(y, ref, 'winograd adjoint shape {}'.format(shape))
 
 
 def test_conv3x3_c128_auto_selection(cuda):
@@ -216,10 +213,11 @@ def test_conv3x3_c128_auto_selection(cuda):
     L = _lib()
     # direct fragments + the Winograd fragments in both layouts (32-channel tiles | 16-channel tiles)
     assert L.lib.ic_conv3x3_c128_both_packed_floats() == 9 * 128 * 128 + 2 * 16 * 128 * 128
-    assert L.lib.ic_conv3x3_c128_pick_algo(1, 16, 16) == 1              # K-split work-groups serve small maps
-    assert L.lib.ic_conv3x3_c128_pick_algo(1, 128, 192) == 1
-    assert L.lib.ic_conv3x3_c128_pick_algo(32, 32, 32) == 1
-    assert L.lib.ic_conv3x3_c128_pick_algo(1, 4096, 2048) == 0          # beyond 31-bit offsets: direct form
+    assert L.lib.ic_conv3x3_c128_pick_algo(1, 16, 16, 0) == 1              # K-split work-groups serve small maps
+    assert L.lib.ic_conv3x3_c128_pick_algo(1, 128, 192, 0) == 1
+    assert L.lib.ic_conv3x3_c128_pick_algo(32, 32, 32, 0) == 1
+    assert L.lib.ic_conv3x3_c128_pick_algo(1, 4096, 2048, 0) == 0          # beyond 31-bit offsets: direct form
+    assert L.lib.ic_conv3x3_c128_pick_algo(1, 4096, 2048, L.CONV3_WINO) == 0
     N, H, W = 1, 24, 40
     rs = np.random.RandomState(7)
     x = rs.normal(0, 1, (N, 128, H, W)).astype(np.float32)
@@ -230,19 +228,15 @@ def test_conv3x3_c128_auto_selection(cuda):
     L.check(L.lib.ic_pack_conv3x3_c128_both_f32(L.ptr(wd), L.ptr(wp), 0, L.current_stream()))
     ref = _ref_conv(x, w, scale, shift, 1, 1)
     outs = []
-    for algo in (0, 1):
-        prev = L.lib.ic_conv3x3_c128_set_algo(algo)
-        try:
-            assert L.lib.ic_conv3x3_c128_pick_algo(N, H, W) == algo
-            y = torch.full((N, 128, H, W), float('nan'), device=cuda)
-            L.check(L.lib.ic_conv3x3_c128_auto_f32(L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), None, None, L.ptr(y),
-                                                   N, H, W, 1, L.current_stream()))
-            torch.cuda.synchronize()
-            assert_close(y, ref, 'auto entry, algo {}'.format(algo))
-            outs.append(y)
-        finally:
-            L.lib.ic_conv3x3_c128_set_algo(prev)
-    assert not torch.equal(outs[0], outs[1]), 'the override did not switch kernels'
+    for algo, flags in ((0, L.CONV3_DIRECT), (1, L.CONV3_WINO)):
+        assert L.lib.ic_conv3x3_c128_pick_algo(N, H, W, flags) == algo
+        y = torch.full((N, 128, H, W), float('nan'), device=cuda)
+        L.check(L.lib.ic_conv3x3_c128_auto_f32(L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), None, None, L.ptr(y),
+                                               N, H, W, 1, flags, L.current_stream()))
+        torch.cuda.synchronize()
+        assert_close(y, ref, 'auto entry, algo {}'.format(algo))
+        outs.append(y)
+    assert not torch.equal(outs[0], outs[1]), 'the per-call form flag did not switch kernels'
 
 
 def test_conv3x3_mfma_matches_direct_kernel(cuda):
@@ -259,7 +253,7 @@ def test_conv3x3_mfma_matches_direct_kernel(cuda):
     y1 = torch.empty((N, 128, H, W), device=cuda)
     y2 = torch.empty_like(y1)
     L.check(L.lib.ic_conv3x3_c128_bn_act_f32(L.ptr(x), L.ptr(wp), L.ptr(s), L.ptr(h), None, None, L.ptr(y1),
-                                             N, H, W, 1, L.current_stream()))
+                                             N, H, W, 1, 0, L.current_stream()))
     L.check(L.lib.ic_conv2d_bn_act_f32(L.ptr(x), L.ptr(w), L.ptr(s), L.ptr(h), None, None, L.ptr(y2),
                                        N, 128, H, W, 128, 3, 3, 1, 1, None, None, L.current_stream()))
     torch.cuda.synchronize()
@@ -407,8 +401,9 @@ def test_error_codes(cuda):
 
 
 def test_conv3x3_c128_forms_agree_on_random_shapes(cuda):
-    """fuzz: direct form, Winograd whole-K and Winograd K-split on 24 random (N, H, W) incl. odd and tiny maps, with ReLU and
-    one residual -- all three within fp32 rounding of each other (the oracle comparison of each form is done above)."""
+    """fuzz: direct form and every Winograd decomposition on 24 random (N, H, W) incl. odd and tiny maps, with ReLU and one
+    residual -- all within fp32 rounding of the direct form (the oracle comparison of each form is done above), and the
+    Winograd decompositions bit-identical to each other (the same operations per output, only the job shape differs)."""
     L = _lib()
     rs = np.random.RandomState(2024)
     w = rs.normal(0, 0.05, (3, 3, 128, 128)).astype(np.float32)
@@ -416,36 +411,30 @@ def test_conv3x3_c128_forms_agree_on_random_shapes(cuda):
     wd, sd, hd = dev(w, cuda), dev(scale, cuda), dev(shift, cuda)
     wp = torch.empty(L.lib.ic_conv3x3_c128_both_packed_floats(), device=cuda)
     L.check(L.lib.ic_pack_conv3x3_c128_both_f32(L.ptr(wd), L.ptr(wp), 0, L.current_stream()))
-    shapes = [(1, 1, 1), (1, 2, 3), (3, 5, 33), (1, 31, 65), (2, 4, 32)] + \
-             [(int(rs.randint(1, 4)), int(rs.randint(1, 70)), int(rs.randint(1, 100))) for _ in range(19)]
-    try:
-        for N, H, W in shapes:
-            x = torch.randn((N, 128, H, W), device=cuda)
-            r = torch.randn((N, 128, H, W), device=cuda)
-            outs = []
-            # direct, Winograd whole-K (transform shared through LDS / per wave), Winograd K-split, 16 x 16 jobs (even widths)
-            for algo, ks, share, t16 in ((0, -1, 1, 0), (1, 0, 1, 0), (1, 1, 1, 0), (1, 0, 0, 0), (1, -1, 1, 1)):
-                L.lib.ic_conv3x3_c128_set_algo(algo)
-                L.lib.ic_wino3x3_c128_set_tuning(2, ks)
-                L.lib.ic_wino3x3_c128_set_tuning(4, share)
-                L.lib.ic_wino3x3_c128_set_tuning(6, t16)
-                y = torch.full((N, 128, H, W), float('nan'), device=cuda)
-                L.check(L.lib.ic_conv3x3_c128_auto_f32(L.ptr(x), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(r), None, L.ptr(y),
-                                                       N, H, W, 1, L.current_stream()))
-                outs.append(y)
-            torch.cuda.synchronize()
-            scale_ = max(1.0, float(outs[0].abs().max()))
-            for k in (1, 2, 3, 4):
-                err = float((outs[k] - outs[0]).abs().max()) / scale_
-                assert err < 2e-5, 'shape {} form {}: {}'.format((N, H, W), k, err)
-            assert bool(torch.isfinite(outs[2]).all())
-            # sharing the transformed input between the waves changes no operation: bit-identical to the per-wave form
-            assert torch.equal(outs[1], outs[3]), 'shape {}'.format((N, H, W))
-    finally:
-        L.lib.ic_conv3x3_c128_set_algo(-1)
-        L.lib.ic_wino3x3_c128_set_tuning(2, -1)
-        L.lib.ic_wino3x3_c128_set_tuning(4, 1)
-        L.lib.ic_wino3x3_c128_set_tuning(6, 0)
+    shapes = [(1, 1, 1), (1, 2, 3), (3, 5, 33), (1, 31, 65), (2, 4, 32), (2, 7, 66), (5, 2, 34)] + \
+             [(int(rs.randint(1, 4)), int(rs.randint(1, 70)), int(rs.randint(1, 100))) for _ in range(17)]
+    forms = (L.CONV3_DIRECT, L.CONV3_WINO_WHOLEK, L.CONV3_WINO_KSPLIT, L.CONV3_WINO_WHOLEK_PW, L.CONV3_WINO_T16,
+             L.CONV3_WINO_SEG1, L.CONV3_WINO_SEG2, L.CONV3_WINO_SEG3, L.CONV3_WINO_SEG3 | L.CONV3_PACKED_TRANSFORM,
+             L.CONV3_WINO_SEG3 | L.CONV3_NO_XCD_RUNS, L.CONV3_AUTO)
+    for N, H, W in shapes:
+        x = torch.randn((N, 128, H, W), device=cuda)
+        r = torch.randn((N, 128, H, W), device=cuda)
+        outs = []
+        for flags in forms:
+            y = torch.full((N, 128, H, W), float('nan'), device=cuda)
+            L.check(L.lib.ic_conv3x3_c128_auto_f32(L.ptr(x), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(r), None, L.ptr(y),
+                                                   N, H, W, 1, flags, L.current_stream()))
+            outs.append(y)
+        torch.cuda.synchronize()
+        scale_ = max(1.0, float(outs[0].abs().max()))
+        for k in range(1, len(forms)):
+            assert bool(torch.isfinite(outs[k]).all()), 'shape {} form {:#x}'.format((N, H, W), forms[k])
+            err = float((outs[k] - outs[0]).abs().max()) / scale_
+            assert err < 2e-5, 'shape {} form {:#x}: {}'.format((N, H, W), forms[k], err)
+        for k in range(2, len(forms)):
+            if forms[k] == L.CONV3_WINO_KSPLIT:
+                continue                      # K-split sums four partial chains: same value up to fp32 rounding, not the same bits
+            assert torch.equal(outs[1], outs[k]), 'shape {} form {:#x} is not bit-identical to whole-K'.format((N, H, W), forms[k])
 
 
 def test_edge_layers_random_shapes(cuda):
@@ -477,7 +466,7 @@ def test_edge_layers_random_shapes(cuda):
         y = torch.full((N, 128, 2 * H, 2 * W), float('nan'), device=cuda)
         t = [d(x), d(w), d(sc), d(sh)]
         L.check(L.lib.ic_deconv2d_bn_act_f32(L.ptr(t[0]), L.ptr(t[1]), L.ptr(t[2]), L.ptr(t[3]), L.ptr(y), N, 32, H, W, 128, 3, 3, 1,
-                                             None, None, st))
+                                             None, None, 0, st))
         torch.cuda.synchronize()
         assert_close(y, _ref_conv(x, w, sc, sh, 2, 1, transposed=True), 'from_bn {}'.format((N, H, W)))
         # h13: 5x5 / 2 transposed conv 64 -> 3, de-normalise + clip
@@ -487,19 +476,18 @@ def test_edge_layers_random_shapes(cuda):
         y = torch.full((N, 3, 2 * H, 2 * W), float('nan'), device=cuda)
         t = [d(x), d(w), d(sc), d(sh)]
         for tpw in (0, 1, 3):
-            L.lib.ic_edge_set_tuning(0, tpw)
             y.fill_(float('nan'))
             L.check(L.lib.ic_deconv2d_bn_act_f32(L.ptr(t[0]), L.ptr(t[1]), L.ptr(t[2]), L.ptr(t[3]), L.ptr(y), N, 64, H, W, 3, 5, 5, 0,
-                                                 L.ptr(m_d), L.ptr(s_d), st))
+                                                 L.ptr(m_d), L.ptr(s_d), L.edge_tiles_per_wg(tpw), st))
             torch.cuda.synchronize()
             assert_close(y, _ref_conv(x, w, sc, sh, 2, 0, transposed=True, denorm=True), 'h13 {} tpw {}'.format((N, H, W), tpw))
-        L.lib.ic_edge_set_tuning(0, 0)
 
 
 @pytest.mark.parametrize('N,H,W', [(1, 136, 240), (2, 136, 240)])
 def test_winograd_hybrid_plan(cuda, N, H, W):
-    """272 / 544 tile groups: the full rounds of 256 run whole-K, the remainder (16 / 32 groups) K-split, in two launches of
-    one call; every output tile is written exactly once and agrees with the single-form launches."""
+    """272 / 544 tile groups next to a CU-range stream (IC_CONV3_LEAVE_IDLE_CUS): the full rounds of 256 run whole-K, the
+    remainder (16 / 32 groups) K-split, in two launches of one call; every output tile is written exactly once and agrees
+    with the single-form launches."""
     L = _lib()
     rs = np.random.RandomState(5)
     w = rs.normal(0, 0.05, (3, 3, 128, 128)).astype(np.float32)
@@ -511,24 +499,75 @@ def test_winograd_hybrid_plan(cuda, N, H, W):
     r = torch.randn((N, 128, H, W), device=cuda)
     groups = N * -(-H // 4) * -(-W // 32)
     assert groups % 256 in (16, 32)
-    assert int(L.lib.ic_wino3x3_c128_workgroups(N, H, W)) == groups - groups % 256 + 4 * (groups % 256)
+    assert int(L.lib.ic_wino3x3_c128_workgroups(N, H, W, L.CONV3_LEAVE_IDLE_CUS)) == groups - groups % 256 + 4 * (groups % 256)
     outs = []
-    try:
-        for ks in (-1, 0, 1):
-            L.lib.ic_wino3x3_c128_set_tuning(2, ks)
-            y = torch.full((N, 128, H, W), float('nan'), device=cuda)
-            L.check(L.lib.ic_wino3x3_c128_bn_act_f32(L.ptr(x), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(r), None, L.ptr(y), N, H, W, 1,
-                                                     L.current_stream()))
-            torch.cuda.synchronize()
-            assert bool(torch.isfinite(y).all())
-            outs.append(y)
-    finally:
-        L.lib.ic_wino3x3_c128_set_tuning(2, -1)
+    for flags in (L.CONV3_LEAVE_IDLE_CUS, L.CONV3_WINO_WHOLEK, L.CONV3_WINO_KSPLIT, L.CONV3_AUTO):
+        y = torch.full((N, 128, H, W), float('nan'), device=cuda)
+        L.check(L.lib.ic_wino3x3_c128_bn_act_f32(L.ptr(x), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(r), None, L.ptr(y), N, H, W, 1,
+                                                 flags, L.current_stream()))
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(y).all())
+        outs.append(y)
     scale_ = float(outs[1].abs().max())
     assert float((outs[0] - outs[1]).abs().max()) / scale_ < 2e-5
     assert float((outs[2] - outs[1]).abs().max()) / scale_ < 2e-5
+    assert float((outs[3] - outs[1]).abs().max()) / scale_ < 2e-5
     # the whole-K part of the hybrid launch is the whole-K launch's own output, bit for bit
     gw = groups - groups % 256
     rows_w = (gw // (-(-W // 32))) % (-(-H // 4))       # tile-group rows of the last image fully inside the whole-K part
     if N == 1:
         assert torch.equal(outs[0][:, :, :4 * rows_w], outs[1][:, :, :4 * rows_w])
+
+
+def test_two_host_threads_drive_the_library_concurrently(cuda):
+    """the C ABI is re-entrant and keeps no process-wide mutable state.  Two host threads, each with its own
+    stream and buffers, issue the same layer with DIFFERENT per-call plan flags at the same time; every result equals the
+    single-threaded result of the same flags bit for bit (a shared tuning variable would let one thread's form leak into the
+    other's launches: direct vs Winograd differ in the last bits)."""
+    import threading
+    L = _lib()
+    rs = np.random.RandomState(11)
+    w = rs.normal(0, 0.05, (3, 3, 128, 128)).astype(np.float32)
+    scale, shift = _bn(rs, 128)
+    wd, sd, hd = dev(w, cuda), dev(scale, cuda), dev(shift, cuda)
+    wp = torch.empty(L.lib.ic_conv3x3_c128_both_packed_floats(), device=cuda)
+    L.check(L.lib.ic_pack_conv3x3_c128_both_f32(L.ptr(wd), L.ptr(wp), 0, L.current_stream()))
+    N, H, W = 1, 40, 72
+    x = torch.randn((N, 128, H, W), device=cuda)
+    forms = [L.CONV3_DIRECT, L.CONV3_WINO_SEG3, L.CONV3_WINO_WHOLEK | L.CONV3_LEAVE_IDLE_CUS, L.CONV3_WINO_KSPLIT]
+    ref = []
+    for f in forms:
+        y = torch.empty_like(x)
+        L.check(L.lib.ic_conv3x3_c128_auto_f32(L.ptr(x), L.ptr(wp), L.ptr(sd), L.ptr(hd), None, None, L.ptr(y), N, H, W, 1, f,
+                                               L.current_stream()))
+        ref.append(y)
+    torch.cuda.synchronize()
+    assert not torch.equal(ref[0], ref[1])
+    errors = []
+
+    def worker(tid):
+        try:
+            st = torch.cuda.Stream(device=cuda)
+            ys = [torch.empty_like(x) for _ in forms]
+            for it in range(200):
+                k = (it + tid) % len(forms)
+                rc = L.lib.ic_conv3x3_c128_auto_f32(L.ptr(x), L.ptr(wp), L.ptr(sd), L.ptr(hd), None, None, L.ptr(ys[k]), N, H, W, 1,
+                                                    forms[k], st.cuda_stream)
+                if rc != 0:
+                    errors.append((tid, it, rc))
+                    return
+                if it % 50 == 49:
+                    st.synchronize()
+                    for j in range(len(forms)):
+                        if it >= len(forms) and not torch.equal(ys[j], ref[j]):
+                            errors.append((tid, it, 'form {:#x} differs'.format(forms[j])))
+                            return
+            st.synchronize()
+        except Exception as e:                                             # noqa: BLE001 -- reported through the list
+            errors.append((tid, repr(e)))
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
