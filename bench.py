@@ -54,7 +54,7 @@ def conv3_scopes(W, ae_cfg, which):
 class Pipeline(object):
     """encode -> (bitcost on the side stream || decode) of one batch, the val.py wiring."""
 
-    def __init__(self, dev, ae_config='low', share='cu_range', seed=0):
+    def __init__(self, dev, ae_config='low', share='cu_range', seed=0, idle_layers=None):
         import torch
         from imgcomp_cvpr_amd import autoencoder, probclass, config_parser as cp, weights as W, streams
         self.torch, self.dev, self.W = torch, dev, W
@@ -64,7 +64,7 @@ class Pipeline(object):
         self.ae = autoencoder.get_network_cls(self.ae_cfg)(self.ae_cfg).load_weights(self.wts, dev)
         self.pc = probclass.get_network_cls(self.pc_cfg)(self.pc_cfg, num_centers=self.ae_cfg.num_centers).load_weights(self.wts, dev)
         self.pad_value = float(self.wts['autoencoder/encoder/centers'][0])
-        self.branch = streams.BranchStreams(dev, share=share)
+        self.branch = streams.BranchStreams(dev, share=share, idle_layers=idle_layers)
         self.seed = seed
 
     def set_input(self, N, H, Wd):
@@ -102,6 +102,7 @@ def main():
     p.add_argument('--mode', default='infer', choices=['infer', 'train'])
     p.add_argument('--share', default='auto', choices=['auto', 'cu_range', 'full_chip'],
                    help='how decoder and context model share the chip (imgcomp_cvpr_amd/streams.py); auto = the package default')
+    p.add_argument('--idle_layers', type=int, default=None, help="cu_range sharing: 3x3 launches of the decoder that leave the side stream's CUs idle (0 = all)")
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--no_extras', action='store_true', help='headline only: no stage split, roofline, extra shapes (rocprofv3 runs)')
     p.add_argument('--pipelined', action='store_true', help='also run the informational three-pipelines-in-flight section')
@@ -125,7 +126,7 @@ def main():
     from imgcomp_cvpr_amd import weights as W, _lib, streams
     lib = _lib.lib
     share = streams.DEFAULT_SHARE if a.share == 'auto' else a.share
-    pipe = Pipeline(dev, a.ae_config, share, seed=rank).set_input(a.batch, a.height, a.width)
+    pipe = Pipeline(dev, a.ae_config, share, seed=rank, idle_layers=a.idle_layers).set_input(a.batch, a.height, a.width)
     ae, pc, ae_cfg = pipe.ae, pipe.pc, pipe.ae_cfg
     N, H, Wd = a.batch, a.height, a.width
     torch.cuda.synchronize(dev)
@@ -183,38 +184,28 @@ def main():
         extra.update({'ms_encode': round(ms_enc, 4), 'ms_pc_bitcost': round(ms_pc, 4), 'ms_decode': round(ms_dec, 4),
                       'ms_decode_with_step_flags': round(ms_dec_shared, 4)})
 
-        # ---- dominant kernel, in-step: the 32-layer residual stack with its own 32 filters, launch pattern of network.hip ----
+        # ---- dominant kernel, in-step: the 32-layer residual stack with its own 32 filters through the library's own launch
+        # sequence (ic_ae_res_stack_f32 = the res_stack of network.hip that encode / decode run), HIP events around it ----
         h4, w4 = H // 4, Wd // 4
-        bufs = [torch.randn((N, 128, h4, w4), device=dev) * 0.5 for _ in range(5)]
+        xin = torch.randn((N, 128, h4, w4), device=dev) * 0.5
+        yout = torch.empty_like(xin)
+        rs_need = lib.ic_ae_res_stack_workspace_bytes(N, h4, w4)
+        rs_ws = torch.empty(rs_need, dtype=torch.uint8, device=dev)
 
         def res_stack(which, flags):
-            plan = [ae._plan[s] for s in conv3_scopes(W, ae_cfg, which)]
+            tens = []
+            for sname in conv3_scopes(W, ae_cfg, which):
+                tens += list(ae._plan[sname])
+            tab = _lib.ptr_table(tens)
             B = int(ae_cfg.arch_param_B)
 
-            def conv(src, li, r1, r2, dst, relu):
-                wpk, sc, sh = plan[li]
-                _lib.check(lib.ic_conv3x3_c128_auto_f32(_lib.ptr(bufs[src]), _lib.ptr(wpk), _lib.ptr(sc), _lib.ptr(sh),
-                                                        _lib.ptr(bufs[r1]) if r1 is not None else None,
-                                                        _lib.ptr(bufs[r2]) if r2 is not None else None,
-                                                        _lib.ptr(bufs[dst]), N, h4, w4, relu, flags, st))
-
             def go():
-                cur, li = 0, 0
-                for b in range(B):
-                    G = cur
-                    for i in range(3):
-                        O = next(o for o in (1, 2, 3) if o != G and o != cur)
-                        conv(cur, li, None, None, 4, 1)
-                        conv(4, li + 1, cur, G if i == 2 else None, O, 0)
-                        cur, li = O, li + 2
-                O = next(o for o in (1, 2, 3) if o != cur)
-                conv(cur, li, None, None, 4, 0)
-                conv(4, li + 1, cur, 0, O, 0)
-            return go, len(plan)
+                _lib.check(lib.ic_ae_res_stack_f32(_lib.ptr(xin), tab, B, _lib.ptr(yout), N, h4, w4, _lib.ptr(rs_ws), rs_need, flags, st))
+            return go, len(tens) // 3
 
         def layer_entry(which, flags):
             go, nl = res_stack(which, flags)
-            ms = timed(go, 6) / nl
+            ms = timed(go, 10) / nl
             flop_direct = CONV3_FLOP_PER_OUT_PX * N * h4 * w4
             wino = lib.ic_conv3x3_c128_pick_algo(N, h4, w4, flags) == 1
             executed = flop_direct * (16.0 / 36.0 if wino else 1.0)

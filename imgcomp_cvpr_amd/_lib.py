@@ -28,6 +28,10 @@ CONV3_PACKED_TRANSFORM = 0x40
 PC_DECODE_PER_LAYER = 0x01
 
 
+def conv3_leave_idle_layers(n):
+    return (n & 0x7f) << 12
+
+
 def conv3_direct_variant(v):
     return ((v + 1) & 0xf) << 8
 
@@ -81,6 +85,8 @@ PROTOTYPES = {
                          [c_int] * 3 + [c_void_p, c_size_t, c_int, c_void_p]),
     'ic_ae_decode_f32': (c_int, [c_void_p, POINTER(c_void_p)] + [c_int] * 3 + [c_void_p] +
                          [c_int] * 3 + [c_void_p, c_size_t, c_int, c_void_p]),
+    'ic_ae_res_stack_workspace_bytes': (c_size_t, [c_int] * 3),
+    'ic_ae_res_stack_f32': (c_int, [c_void_p, POINTER(c_void_p), c_int, c_void_p] + [c_int] * 3 + [c_void_p, c_size_t, c_int, c_void_p]),
     'ic_bn_workspace_bytes': (c_size_t, [c_int]),
     'ic_bn_stats_f32': (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p, c_void_p]),
     'ic_bn_train_stats_f32': (c_int, [c_void_p] * 5 + [c_float] * 2 + [c_void_p] * 4 + [c_int] * 3 + [c_void_p, c_void_p]),

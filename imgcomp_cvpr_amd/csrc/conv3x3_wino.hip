@@ -846,19 +846,25 @@ struct WinoPlan {
     int seg_nb;
 };
 
-// Cost model, in thousands of shader clocks per CU (MI355X measurements):
-//   whole-K round (256 groups, one work-group per CU): 92 (38.4 us) partly filled, 100 (42 us) full;
-//   K-split round (64 groups): 100 / 2.7;
-//   NB-segment job: 16.4 NB of matrix pipe + ~10 of prologue / epilogue, one work-group per CU for NB >= 2; NB = 1 keeps two
-//   work-groups per CU (prologue of one under the k-loop of the other).
+// Cost model in microseconds per launch, from tools/kbench.py conv3 on the MI355X (round 2; every form, 7 shapes, interleaved):
+//   whole-K round (<= 256 tile groups, one work-group per CU): 37.5 partly filled, 38.6 full, 39.8 per round in a long launch;
+//   K-split round (<= 64 tile groups): 13.6, + 1.4 for the launch;
+//   NB-segment jobs, one work-group per CU (NB = 3: 30.0 + 2.5 per round of 256 work-groups; NB = 2: 21 + 2.5);
+//   NB = 1: two work-groups per CU, 10 per work-group a CU runs + 4.5.
+// Kodak (192 groups): NB = 3 in one round 32.5 (whole-K 37.5, NB = 1 34.5, K-split 40.8); 256 groups: whole-K 38.6 (NB = 1 44);
+// 272: whole-K + K-split 52.8; 4K (4050): whole-K 630 (NB = 3 716); 32 groups: NB = 1 14.3 (K-split 15.0).
 static double seg_cost(long long groups, int nb) {
+    if (groups <= 0) return 0.0;
     const long long wgs = 2 * ((2 * groups + nb - 1) / nb);
-    if (nb == 1) {
-        const long long per_cu = (wgs + 255) / 256;                  // 16.4 k clocks each, two at a time share the pipes
-        return 17.5 * per_cu + 10.0 * ((per_cu + 1) / 2);
-    }
-    return (double)((wgs + 255) / 256) * (17.5 * nb + 10.0);
+    if (nb == 1) return 10.0 * (double)((wgs + 255) / 256) + 4.5;
+    return (double)((wgs + 255) / 256) * (nb == 3 ? 30.0 : 21.0) + 2.5;
 }
+static double whole_cost(long long groups) {
+    if (groups <= 0) return 0.0;
+    const long long rounds = (groups + 255) / 256;
+    return rounds == 1 ? (groups == 256 ? 38.6 : 37.5) : 39.8 * rounds;
+}
+static double ksplit_cost(long long groups) { return groups <= 0 ? 0.0 : 13.6 * (double)((groups + 63) / 64) + 1.4; }
 
 static WinoPlan wino_plan(long long groups, bool even_w, int flags) {
     WinoPlan p{0, 0, 0, 0, 0};
@@ -873,21 +879,20 @@ static WinoPlan wino_plan(long long groups, bool even_w, int flags) {
             return p;
         default: break;
     }
-    // automatic.  Odd widths have the per-wave whole-K kernel and K-split only.
+    // automatic: the full rounds of 256 tile groups run whole-K; the remainder r takes the cheapest of {whole-K, K-split,
+    // NB-segment jobs as a second launch}.  Odd widths have the per-wave whole-K kernel and K-split only; next to a caller's
+    // CU-range stream (leave_idle) only the one-work-group-per-CU forms whose work-groups stay below 256 qualify.
     const long long r = groups % 256, full = groups - r;
-    const bool rem_ksplit = r > 0 && 100 * ((r + 63) / 64) < 270;
-    if (!even_w || leave_idle) {
-        // one work-group per CU, CUs beyond the tile groups stay free (a caller's concurrent branch runs there)
-        p.ksplit = rem_ksplit ? r : 0;
-        p.whole = groups - p.ksplit;
-        return p;
+    double best = whole_cost(r);
+    p.whole = groups;
+    if (r > 0 && ksplit_cost(r) < best && (!leave_idle || full > 0 || 4 * r <= 256)) {
+        best = ksplit_cost(r); p = WinoPlan{full, 0, 0, r, 0};
     }
-    double best = (full / 256) * 100.0 + (r == 0 ? 0.0 : rem_ksplit ? 37.0 * ((r + 63) / 64) : 92.0);
-    p.ksplit = rem_ksplit ? r : 0;
-    p.whole = groups - p.ksplit;
-    for (int nb = 1; nb <= 3; ++nb) {
-        const double c = seg_cost(groups, nb);
-        if (c < best) { best = c; p = WinoPlan{0, groups, 0, 0, nb}; }
+    if (r > 0 && even_w && !leave_idle) {
+        for (int nb = 1; nb <= 3; ++nb) {
+            const double c = seg_cost(r, nb) + (full > 0 ? 1.0 : 0.0);
+            if (c < best) { best = c; p = WinoPlan{full, r, 0, 0, nb}; }
+        }
     }
     return p;
 }

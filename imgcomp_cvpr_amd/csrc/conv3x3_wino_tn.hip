@@ -29,9 +29,31 @@
 #include "internal.h"
 
 #define TN_FST 4                  // filter ring: requested 3 k-steps ahead
+#ifndef TN_TR_AT
+#define TN_TR_AT 12               // the 40 vector instructions of a segment's input transform go behind MFMAs TN_TR_AT .. +TN_TR_N-1
+#define TN_TR_N 4                 // of its block as bursts (measured: 1 us per Kodak layer faster than 2-4 behind every MFMA)
+#endif
+#ifndef TN_SCHED
+#define TN_SCHED 0                // main-loop issue order: 0 = fillers spread over the MFMA gaps, 1 = clustered into bursts
+#endif
+#ifndef TN_P_FILT
+#define TN_P_FILT 0               // clustered schedule: the gap (MFMA index of the block) each burst goes behind
+#define TN_P_READ 4
+#define TN_P_TR 8
+#define TN_P_PUT 12
+#define TN_TR_GAPS 1              // transform burst in 1, 2 or 4 gaps
+#endif
+#ifndef TN_ABL
+#define TN_ABL 0                  // tuning builds: 1 no transform, 2 no patch re-requests, 4 no filter requests, 8 no B reads, 16 no ring writes, 32 no barrier
+#endif
 
+#ifdef TN_INT_OPS       // tuning builds: integer adds instead of fp32 adds (wrong results; is the cost the FP32 ALU or the issue slot?)
+__device__ __forceinline__ float tn_add(float x, float y) { float r; asm("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ float tn_sub(float x, float y) { float r; asm("v_sub_u32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+#else
 __device__ __forceinline__ float tn_add(float x, float y) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
 __device__ __forceinline__ float tn_sub(float x, float y) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+#endif
 
 // PK: input transform on packed-fp32 adds (v_pk_add_f32: 16 instructions instead of 32); PK = false keeps every add a
 // single-issue v_add_f32 / v_sub_f32 (inline asm, so that the SLP vectoriser does not re-pack them) -- packed fp32 next to
@@ -230,7 +252,7 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void wino3x3_c128_tn_kernel(c
                 const int tr_seg = NB == 1 ? 0 : st;
                 const int fs = (st + TN_FST - 1) % TN_FST;                                  // filter slot freed by k-step st - 1
                 const int fso = (ct * 32 + (kf + st < NKS ? kf + st : NKS - 1)) * 4096;
-                if (blk == LAST) {
+                if (blk == LAST && !(TN_ABL & 32)) {
                     // every wave has written its k-step of the next slot; the slot this iteration reads stays untouched until
                     // the barrier of the NEXT iteration has been passed
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -241,27 +263,75 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void wino3x3_c128_tn_kernel(c
 #pragma unroll
                 for (int p = 0; p < 16; ++p) {
                     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[i][p]) : "v"(fl[st][p >> 2][p & 3]), "v"(bq[blk & 1][p >> 2][p & 3]));
-                    if (i == 0 && p < 4)                                                    // the k-step's filter request
+#if TN_SCHED == 0
+                    // spread: one memory / LDS instruction and 2-4 vector instructions behind each MFMA
+                    if (i == 0 && p < 4 && !(TN_ABL & 4))                                   // the k-step's filter request
                         fl[fs][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(fr, fo + p * 1024u, fso, 0));
-                    if (p >= 4 && p < 8) bq[(blk + 1) & 1][p - 4] = nsl[(p - 4) * 64];     // 1 LDS read
-                    if (do_tr) tr_step(tr_seg, p, vt);
-                    if (do_put && p >= 4 && p < 8) {                                        // 1 LDS write
+                    if (p >= 4 && p < 8 && !(TN_ABL & 8)) bq[(blk + 1) & 1][p - 4] = nsl[(p - 4) * 64];     // 1 LDS read
+                    if (do_tr && !(TN_ABL & 1) && p >= TN_TR_AT && p < TN_TR_AT + TN_TR_N) {
+#pragma unroll
+                        for (int s2 = (p - TN_TR_AT) * (16 / TN_TR_N); s2 < (p - TN_TR_AT + 1) * (16 / TN_TR_N); ++s2) tr_step(tr_seg, s2, vt);
+                    }
+                    if (do_put && p >= 4 && p < 8 && !(TN_ABL & 16)) {                      // 1 LDS write
                         const int q = p - 4;
                         const f32x4 tq = {vt[4 * q], vt[4 * q + 1], vt[4 * q + 2], vt[4 * q + 3]};
                         wr[((wave * NB + tr_seg) * 4 + q) * 64] = tq;
                     }
-                    if (do_put && p >= 8) {                                                 // patch re-request, 1 load per MFMA
+                    if (do_put && p >= 8 && !(TN_ABL & 2)) {                                // patch re-request, 1 load per MFMA
                         const int q = (p - 8) >> 1, so = kp * 4 * HW * 4;
                         if ((p & 1) == 0) pp[tr_seg][q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr[tr_seg], o0[tr_seg][q], so, 0));
                         else pe[tr_seg][q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr[tr_seg], oe[tr_seg][q], so, 0));
                     }
+#else
+                    // clustered: everything that is not an MFMA goes into a few gaps as bursts (the first extra instruction in a
+                    // gap between two MFMAs is the expensive one, MI355X_MICROARCH.md "one EXTRA issue slot")
+                    if (i == 0 && p == TN_P_FILT && !(TN_ABL & 4)) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            fl[fs][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(fr, fo + q * 1024u, fso, 0));
+                    }
+                    if (p == TN_P_READ && !(TN_ABL & 8)) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) bq[(blk + 1) & 1][q] = nsl[q * 64];
+                    }
+                    if (do_tr && !(TN_ABL & 1)) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 16; ++s2)
+                            if (TN_TR_GAPS == 1 ? p == TN_P_TR : (TN_TR_GAPS == 2 ? p == TN_P_TR + 4 * (s2 >> 3) : p == TN_P_TR + 2 * (s2 >> 2))) tr_step(tr_seg, s2, vt);
+                    }
+                    if (do_put && p == TN_P_PUT) {
+                        if (!(TN_ABL & 16)) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const f32x4 tq = {vt[4 * q], vt[4 * q + 1], vt[4 * q + 2], vt[4 * q + 3]};
+                                wr[((wave * NB + tr_seg) * 4 + q) * 64] = tq;
+                            }
+                        }
+                        if (!(TN_ABL & 2)) {
+                            const int so = kp * 4 * HW * 4;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                pp[tr_seg][q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr[tr_seg], o0[tr_seg][q], so, 0));
+                                pe[tr_seg][q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr[tr_seg], oe[tr_seg][q], so, 0));
+                            }
+                        }
+                    }
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
         f32x4* const t = rd; rd = wr; wr = fr3; fr3 = t;
     }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results are read by compiler code below (asm is opaque to the hazard recogniser)
+    // The last MFMAs' results are read by compiler code below, and inline asm is opaque to the hazard recogniser: left
+    // alone it schedules v_accvgpr_read right behind the last MFMA with one wait state (measured: wrong outputs in the
+    // NB = 2 build).  Volatile asm statements keep their order, and every accumulator passes through an empty one AFTER
+    // the pad, so no read of an accumulator can be scheduled above it.
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int p = 0; p < 16; ++p) asm volatile("" : "+a"(acc[i][p]));
 #ifdef WN_PROF
     const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -314,8 +384,17 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void wino3x3_c128_tn_kernel(c
             q0 += ra0[i][r]; q1 += ra1[i][r];
             q0 += rb0v[i][r]; q1 += rb1v[i][r];
             const int so = (16 * ct + r) * HW * 4;
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q0), yr[i], lo0[i], so, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q1), yr[i], lo1[i], so, 0);
+            // Single-round launches store write-through (sc1): nothing is left dirty in the L2s for the kernel boundary to
+            // write back, which shortens the gap to the next layer's launch (Kodak layer 33.5 -> 32.5 us, A/B'd); launches
+            // of several rounds keep plain stores (4K map: write-through 1.5 % slower -- later rounds re-read their neighbours'
+            // rows from L2).
+            if (a.store_wt) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q0), yr[i], lo0[i], so, 16);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q1), yr[i], lo1[i], so, 16);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q0), yr[i], lo0[i], so, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q1), yr[i], lo1[i], so, 0);
+            }
         }
     }
 #ifdef WN_PROF
@@ -326,11 +405,13 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void wino3x3_c128_tn_kernel(c
 #endif
 }
 
-int icx_wino_tn_launch(const WnArgs& a, int nb, int scalar_transform, hipStream_t st) {
-    if (a.ngroups <= 0) return IC_OK;
-    if (nb < 1 || nb > 3 || (a.W & 1)) return IC_ERR_UNSUPPORTED;
-    const unsigned jobs = (unsigned)((2 * a.ngroups + nb - 1) / nb);
+int icx_wino_tn_launch(const WnArgs& a_in, int nb, int scalar_transform, hipStream_t st) {
+    if (a_in.ngroups <= 0) return IC_OK;
+    if (nb < 1 || nb > 3 || (a_in.W & 1)) return IC_ERR_UNSUPPORTED;
+    const unsigned jobs = (unsigned)((2 * a_in.ngroups + nb - 1) / nb);
     const dim3 grid(2 * jobs), block(256);
+    WnArgs a = a_in;
+    a.store_wt = 2 * jobs <= (nb == 1 ? 512u : 256u) ? 1 : 0;       // everything resident at once: one round
 #define TN_GO(NB_, PK_) hipLaunchKernelGGL((wino3x3_c128_tn_kernel<NB_, PK_>), grid, block, 0, st, a)
     if (scalar_transform) {
         if (nb == 1) TN_GO(1, false); else if (nb == 2) TN_GO(2, false); else TN_GO(3, false);

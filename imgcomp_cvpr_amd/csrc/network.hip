@@ -8,6 +8,15 @@
 // ---- residual stack shared by encoder and decoder (autoencoder.py:224-234 / :252-262) ----
 // tab: 3 pointers {packed filter (both forms, ic_pack_conv3x3_c128_both_f32), scale, shift} per conv, 6B+2 convs.  bufs[0] holds the stack input
 // (kept for the global skip), bufs[4] is the temporary.  Returns the buffer index holding the output.
+// flags: IC_CONV3_* for every launch; IC_CONV3_LEAVE_IDLE_LAYERS(n) limits IC_CONV3_LEAVE_IDLE_CUS to the first n launches
+// (a caller's side branch that needs its CUs for less than the whole stack).
+static inline int layer_flags(int flags, int li) {
+    const int n = (flags >> 12) & 0x7f;
+    int f = flags & 0xfff;
+    if (n > 0 && li >= n) f &= ~IC_CONV3_LEAVE_IDLE_CUS;
+    return f;
+}
+
 static int res_stack(const void* const* tab, int B, float* const bufs[5], int N, int H, int W, int flags,
                      hipStream_t st, int* out_idx) {
     int cur = 0, li = 0, rc;
@@ -19,10 +28,10 @@ static int res_stack(const void* const* tab, int B, float* const bufs[5], int N,
             while (O == G || O == cur) ++O;              // one of {1,2,3} is always free
             const float* const* l1 = (const float* const*)tab + 3 * li;
             const float* const* l2 = l1 + 3;
-            if ((rc = ic_conv3x3_c128_auto_f32(bufs[cur], l1[0], l1[1], l1[2], nullptr, nullptr, T, N, H, W, 1, flags, st)))
+            if ((rc = ic_conv3x3_c128_auto_f32(bufs[cur], l1[0], l1[1], l1[2], nullptr, nullptr, T, N, H, W, 1, layer_flags(flags, li), st)))
                 return rc;
             if ((rc = ic_conv3x3_c128_auto_f32(T, l2[0], l2[1], l2[2], bufs[cur], i == 2 ? bufs[G] : nullptr,
-                                                 bufs[O], N, H, W, 0, flags, st)))
+                                                 bufs[O], N, H, W, 0, layer_flags(flags, li + 1), st)))
                 return rc;
             cur = O; li += 2;
         }
@@ -33,9 +42,9 @@ static int res_stack(const void* const* tab, int B, float* const bufs[5], int N,
         while (O == cur) ++O;
         const float* const* l1 = (const float* const*)tab + 3 * li;
         const float* const* l2 = l1 + 3;
-        if ((rc = ic_conv3x3_c128_auto_f32(bufs[cur], l1[0], l1[1], l1[2], nullptr, nullptr, T, N, H, W, 0, flags, st)))
+        if ((rc = ic_conv3x3_c128_auto_f32(bufs[cur], l1[0], l1[1], l1[2], nullptr, nullptr, T, N, H, W, 0, layer_flags(flags, li), st)))
             return rc;
-        if ((rc = ic_conv3x3_c128_auto_f32(T, l2[0], l2[1], l2[2], bufs[cur], bufs[0], bufs[O], N, H, W, 0, flags, st)))
+        if ((rc = ic_conv3x3_c128_auto_f32(T, l2[0], l2[1], l2[2], bufs[cur], bufs[0], bufs[O], N, H, W, 0, layer_flags(flags, li + 1), st)))
             return rc;
         cur = O;
     }
@@ -60,6 +69,29 @@ static void carve(void* ws, int N, int H, int W, float* bufs[5], float** half, f
     for (int i = 0; i < 5; ++i) { bufs[i] = p; p += (size_t)N * 8 * hw; }
     *half = p; p += (size_t)N * 16 * hw;
     *bott = p;
+}
+
+// The residual stack alone (autoencoder.py:224-234 / :252-262): x (N,128,H,W) -> y (N,128,H,W), 6B+2 convs.  tab as in
+// ic_ae_encode_f32 for these layers only (3 pointers per conv).  Used by bench.py to time the dominant kernel in-step and by
+// tests; workspace: 5 x N x 128 x H x W floats (bufs[0] receives a copy of x).
+extern "C" size_t ic_ae_res_stack_workspace_bytes(int N, int H, int W) {
+    return N > 0 && H > 0 && W > 0 ? (size_t)5 * N * 128 * H * W * sizeof(float) : 0;
+}
+extern "C" int ic_ae_res_stack_f32(const float* x, const void* const* tab, int B, float* y, int N, int H, int W,
+                                   void* workspace, size_t workspace_bytes, int flags, ic_stream_t stream) {
+    IC_CHECK_ARG(x && tab && y && workspace && N > 0 && H > 0 && W > 0 && B >= 0);
+    if (workspace_bytes < ic_ae_res_stack_workspace_bytes(N, H, W)) return IC_ERR_WORKSPACE;
+    for (int i = 0; i < 3 * (6 * B + 2); ++i) IC_CHECK_ARG(tab[i] != nullptr);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)N * 128 * H * W;
+    float* bufs[5];
+    for (int i = 0; i < 5; ++i) bufs[i] = (float*)workspace + i * n;
+    hipError_t e = hipMemcpyAsync(bufs[0], x, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    int o, rc;
+    if ((rc = res_stack(tab, B, bufs, N, H, W, flags, st, &o))) return rc;
+    e = hipMemcpyAsync(y, bufs[o], n * sizeof(float), hipMemcpyDeviceToDevice, st);
+    return e == hipSuccess ? IC_OK : (int)e;
 }
 
 extern "C" int ic_ae_encode_f32(const float* x, const void* const* tab, int B, int C, int L, int heatmap_on,

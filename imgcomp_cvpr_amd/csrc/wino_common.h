@@ -21,6 +21,7 @@ struct WnArgs {
     int xcd_runs;               // 1 = contiguous runs of tile groups per XCD
     int g0;                     // first tile group of this launch (a shape may be split into launches of different forms)
     int ngroups;                // tile groups of this launch (the NB-segment kernels: 2 segments per group)
+    int store_wt;               // NB-segment kernels: 1 = write-through output stores (single-round launches)
     unsigned long long* prof;   // profiling builds (WN_PROF) only
 };
 

@@ -58,6 +58,9 @@ typedef void* ic_stream_t;
 /* partly filled rounds stay one-work-group-per-CU and the CUs beyond the tile groups stay free: a caller's independent
  * branch runs there on a CU-range stream (ic_stream_create_cu_range; imgcomp_cvpr_amd/streams.py) */
 #define IC_CONV3_LEAVE_IDLE_CUS   0x10
+/* whole-network calls (ic_ae_*): IC_CONV3_LEAVE_IDLE_CUS applies to the first n 3x3 launches of the call only (0 = all):
+ * a side branch that needs its CUs for less than the whole residual stack */
+#define IC_CONV3_LEAVE_IDLE_LAYERS(n) (((n) & 0x7f) << 12)
 #define IC_CONV3_NO_XCD_RUNS      0x20   /* natural tile order instead of contiguous runs of tiles per XCD (A/B runs) */
 #define IC_CONV3_PACKED_TRANSFORM 0x40   /* NB-segment kernels: input transform on v_pk_add_f32 instead of single adds (A/B) */
 #define IC_CONV3_DIRECT_VARIANT(v) ((((v) + 1) & 0xf) << 8)   /* direct form: force tile variant v (0..9); tests */
@@ -264,6 +267,12 @@ int ic_ae_encode_f32(const float* x, const void* const* enc_tab_host, int B, int
 int ic_ae_decode_f32(const float* q, const void* const* dec_tab_host, int B, int C, int normalize_on,
                      float* x_out, int N, int H, int W,
                      void* workspace, size_t workspace_bytes, int flags, ic_stream_t stream);
+/* the residual stack alone (autoencoder.py:224-234 / :252-262): x (N,128,H,W) -> y, the 6B+2 3x3 layers of one table
+ * (3 pointers per layer, as above); what bench.py times the dominant kernel with, in its real launch sequence.
+ * workspace: ic_ae_res_stack_workspace_bytes(N, H, W). */
+size_t ic_ae_res_stack_workspace_bytes(int N, int H, int W);
+int ic_ae_res_stack_f32(const float* x, const void* const* tab_host, int B, float* y, int N, int H, int W,
+                        void* workspace, size_t workspace_bytes, int flags, ic_stream_t stream);
 
 /* ic_bn_stats_f32 plus everything the training loop folds from it, in the same two launches:
  *   mean, invstd = 1/sqrt(var + eps), scale = gamma * invstd, shift = beta - mean * scale   (all [C], outputs)

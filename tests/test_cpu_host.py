@@ -176,7 +176,7 @@ def test_abi_header_bindings_and_exports_agree():
     hdr = open(os.path.join(ROOT, 'include', 'imgcomp_hip.h')).read()
     for name, val in re.findall(r'#define IC_(CONV3_[A-Z0-9_]+|PC_DECODE_PER_LAYER)\s+(0x[0-9a-f]+)', hdr):
         assert getattr(_lib, name) == int(val, 16), name
-    assert _lib.conv3_direct_variant(3) == 0x400 and _lib.edge_tiles_per_wg(3) == 3
+    assert _lib.conv3_direct_variant(3) == 0x400 and _lib.edge_tiles_per_wg(3) == 3 and _lib.conv3_leave_idle_layers(5) == 0x5000
     assert _lib.lib.ic_strerror(-3) == b'workspace too small'
     assert _lib.lib.ic_conv3x3_c128_packed_floats() == 9 * 128 * 128
     # size queries are pure host arithmetic

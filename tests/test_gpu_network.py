@@ -350,7 +350,7 @@ def test_branch_streams_cu_range(cuda, configs, syn_weights, nets):
         x = dev(W.synthetic_image((1, 3, 128, 192), 'natural', seed=5), cuda)
         pad = pc.auto_pad_value(ae)
         enc = ae.encode(x, False)
-        ref_out = ae.decode(enc.qhard, False, plan_flags=_lib.CONV3_WINO_WHOLEK)
+        ref_out = ae.decode(enc.qhard, False, plan_flags=bs.decode_flags(side))      # the serial schedule, same launch plan
         ref_bpp = float(bits.bitcost_to_bpp(pc.bitcost(enc.qbar, enc.symbols, False, pad_value=pad), x))
         torch.cuda.synchronize()
         outer = torch.cuda.current_stream(cuda)
