@@ -56,6 +56,8 @@ class _Network(object):
         self.config = config
         self.quantize = quantize
         self.num_chan_bn_including_heatmap = config.num_chan_bn + 1
+        self._train_graph = None   # training.TrainGraph.bind(): is_training=True calls run that graph's training-mode forward
+        self._graph_version = -1
         self.plan_flags = 0        # IC_CONV3_* bits OR-ed into every call of THIS object (tests force a kernel form with it)
         self._centers = None       # set by load_weights(); access with get_centers_variable()
         self._params = None        # OrderedDict name -> device tensor (reference layouts)
@@ -71,14 +73,36 @@ class _Network(object):
         """x: (N,3,H,W) float32 in 0..255 on the HIP device.  -> EncoderOutput.
         plan_flags (not in the reference): per-call IC_CONV3_* launch-plan bits for the 3x3 layers, see _lib.CONV3_*."""
         assert x.dtype == torch.float32, 'Expected float32 for x, got {}'.format(x.dtype)
+        if is_training:
+            return self._training_graph().plugin_encode(x)
+        self._sync_with_training_graph()
         self._require_weights()
         return self._encode(x, is_training, int(plan_flags) | int(self.plan_flags))
 
     def decode(self, q, is_training, plan_flags=0):
+        if is_training:
+            return self._training_graph().plugin_decode(q)
+        self._sync_with_training_graph()
         self._require_weights()
         return self._decode(q, is_training, int(plan_flags) | int(self.plan_flags))
 
+    def _training_graph(self):
+        if self._train_graph is None:
+            raise ValueError('is_training=True needs the training graph that owns the variables and the backward: '
+                             'training.TrainGraph(ae_config, pc_config, weights).bind(ae, pc) (see train.py)')
+        return self._train_graph
+
+    def _sync_with_training_graph(self):
+        """test-in-train (train.py:115-127): is_training=False on a bound object evaluates the CURRENT training variables --
+        moving averages folded into the convs, filters re-packed -- whenever an optimiser step has changed them"""
+        g = self._train_graph
+        if g is not None and self._graph_version != g.version:
+            self.load_weights(OrderedDict((n, t.detach().cpu().numpy()) for n, t in g.params.items()), g.dev)
+            self._graph_version = g.version
+
     def get_centers_variable(self):
+        if self._train_graph is not None:
+            return self._train_graph.params[SCOPE_AE_ENC + '/centers']          # the live training variable
         if self._centers is None:
             raise ValueError('Call load_weights(...) before trying to access centers')
         return self._centers
@@ -126,15 +150,21 @@ class _Network(object):
                 if n.startswith(scope + '/') and 'moving_' not in n]
 
     def _reg_loss(self, scope):
-        self._require_weights()
-        total = torch.zeros((), dtype=torch.float32, device=self._device)
+        """value of the L2 terms of a scope.  On an object bound to a training graph the live variables are read; their
+        gradients do not come from this value (they are folded into the filter-gradient kernels, training.py)."""
+        if self._train_graph is None:
+            self._require_weights()
+        params = self._train_graph.params if self._train_graph is not None else self._params
+        device = self._train_graph.dev if self._train_graph is not None else self._device
+        centers = params[SCOPE_AE_ENC + '/centers']
+        total = torch.zeros((), dtype=torch.float32, device=device)
         f = float(self.config.regularization_factor)
-        for n, t in self._params.items():
+        for n, t in params.items():
             if n.startswith(scope + '/') and n.endswith('/weights'):
                 total = total + f * 0.5 * (t * t).sum()
         if scope == SCOPE_AE_ENC and self.config.regularization_factor_centers != 0:
-            total = total + quantizer.create_centers_regularization_term(self.config, self._centers)
-        return total
+            total = total + quantizer.create_centers_regularization_term(self.config, centers)
+        return total.detach()
 
     def _prepare(self, weights):
         raise NotImplementedError()
@@ -206,9 +236,7 @@ class _CVPR(_Network):
     # -- forward -----------------------------------------------------------------------------------
 
     def _encode(self, x, is_training, plan_flags=0):
-        if is_training:
-            raise NotImplementedError('is_training=True: the training forward keeps a tape for its hand-written backward and '
-                                      'lives in imgcomp_cvpr_amd.training.TrainGraph (see train.py)')
+        assert not is_training          # (training mode is dispatched to the bound TrainGraph in encode())
         _lib.require_cuda(x, 'x')
         x = x.contiguous()
         N, three, H, W = x.shape
@@ -236,9 +264,7 @@ class _CVPR(_Network):
         return EncoderOutput(qbar, qhard, symbols, z, heatmap)
 
     def _decode(self, q, is_training, plan_flags=0):
-        if is_training:
-            raise NotImplementedError('is_training=True: the training forward keeps a tape for its hand-written backward and '
-                                      'lives in imgcomp_cvpr_amd.training.TrainGraph (see train.py)')
+        assert not is_training
         _lib.require_cuda(q, 'q')
         q = q.contiguous()
         N, C, hh, ww = q.shape

@@ -23,6 +23,7 @@ struct BnArgs {
     float* out0; float* out1; // stats: mean, var ; bwd_apply: dx
     int N, C, HW, relu;
     int nchunks;              // stage-1 slices actually used (<= BN_CHUNKS): each covers >= ~1k elements
+    long long count;          // bwd_apply: elements per channel the sums run over (0 = N * HW; larger under sync BatchNorm)
 };
 
 __device__ __forceinline__ void block_reduce2(double& a, double& b) {
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs a, long long total) {
-    const double M = (double)a.N * a.HW;
+    const double M = a.count > 0 ? (double)a.count : (double)a.N * a.HW;
     const int c = blockIdx.y % a.C;
     const float sc = a.scale[c], sh = a.shift[c], mu = a.mean[c], is = a.invstd[c];
     const float k = a.gamma[c] * is, mg = (float)(a.sums[c] / M), mgx = (float)(a.sums[a.C + c] / M);
@@ -188,6 +189,93 @@ extern "C" int ic_bn_train_stats_f32(const float* x, const float* gamma, const f
     hipLaunchKernelGGL(bn_reduce_stage1<0>, dim3(C, a.nchunks), dim3(256), 0, st, a);
     hipLaunchKernelGGL(bn_train_fold_kernel, dim3(ic_cdiv(C, 64)), dim3(64), 0, st, a.partial, C, (long long)N * HW, gamma,
                        beta, moving_mean, moving_var, decay, eps, mean, invstd, scale, shift, a.nchunks);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
+// ---- cross-replica ("sync") BatchNorm: the same two passes with the per-channel sums handed to the caller in between ----
+// Data-parallel training splits the reference's one batch over the ranks; its BatchNorm normalises over the WHOLE batch
+// (autoencoder.py:115-125, batch_size 30 on one device).  The caller all-reduces the float64 sums (2 C doubles per layer)
+// between the two halves: forward  ic_bn_moments_f32 -> sum over ranks -> ic_bn_train_fold_moments_f32,
+//                         backward ic_bn_backward_reduce_f32 -> sum over ranks -> ic_bn_backward_apply_f32.
+// With one rank and no all-reduce the results are bit-identical to ic_bn_train_stats_f32 / ic_bn_backward_f32.
+__global__ void bn_sums_stage2(const double* __restrict__ partial, int C, double* __restrict__ sums, int nchunks) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < nchunks; ++k) { s0 += partial[((size_t)c * BN_CHUNKS + k) * 2]; s1 += partial[((size_t)c * BN_CHUNKS + k) * 2 + 1]; }
+    sums[c] = s0; sums[C + c] = s1;
+}
+
+extern "C" int ic_bn_moments_f32(const float* x, double* sums, int N, int C, int HW, void* workspace, ic_stream_t stream) {
+    IC_CHECK_ARG(x && sums && workspace && N > 0 && C > 0 && HW > 0);
+    BnArgs a{};
+    a.x = x; a.N = N; a.C = C; a.HW = HW; a.partial = (double*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    a.nchunks = bn_nchunks(N, HW);
+    hipLaunchKernelGGL(bn_reduce_stage1<0>, dim3(C, a.nchunks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(bn_sums_stage2, dim3(ic_cdiv(C, 64)), dim3(64), 0, st, a.partial, C, sums, a.nchunks);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
+__global__ void bn_fold_moments_kernel(const double* __restrict__ sums, int C, long long M, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float* __restrict__ moving_mean,
+                                       float* __restrict__ moving_var, float decay, float eps, float* __restrict__ mean,
+                                       float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[c] / (double)M;
+    double v = sums[C + c] / (double)M - m * m;
+    if (v < 0.0) v = 0.0;
+    const float mf = (float)m, vf = (float)v;
+    const float is = 1.0f / sqrtf(vf + eps);
+    const float sc = gamma[c] * is;
+    mean[c] = mf; invstd[c] = is; scale[c] = sc; shift[c] = beta[c] - mf * sc;
+    if (moving_mean) moving_mean[c] = moving_mean[c] * decay + mf * (1.f - decay);
+    if (moving_var) {
+        const float unbiased = vf * (float)((double)M / (double)(M > 1 ? M - 1 : 1));
+        moving_var[c] = moving_var[c] * decay + unbiased * (1.f - decay);
+    }
+}
+
+extern "C" int ic_bn_train_fold_moments_f32(const double* sums, long long count, const float* gamma, const float* beta,
+                                            float* moving_mean, float* moving_var, float decay, float eps, float* mean,
+                                            float* invstd, float* scale, float* shift, int C, ic_stream_t stream) {
+    IC_CHECK_ARG(sums && gamma && beta && mean && invstd && scale && shift && C > 0 && count > 0);
+    hipLaunchKernelGGL(bn_fold_moments_kernel, dim3(ic_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, sums, C, count, gamma, beta,
+                       moving_mean, moving_var, decay, eps, mean, invstd, scale, shift);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
+extern "C" int ic_bn_backward_reduce_f32(const float* dy, const float* x, const float* scale, const float* shift,
+                                         const float* mean, const float* invstd, double* sums, float* dgamma, float* dbeta,
+                                         int N, int C, int HW, int relu, void* workspace, ic_stream_t stream) {
+    IC_CHECK_ARG(dy && x && scale && shift && mean && invstd && sums && workspace && N > 0 && C > 0 && HW > 0);
+    BnArgs a{};
+    a.x = x; a.dy = dy; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd;
+    a.N = N; a.C = C; a.HW = HW; a.relu = relu;
+    a.partial = (double*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    a.nchunks = bn_nchunks(N, HW);
+    hipLaunchKernelGGL(bn_reduce_stage1<1>, dim3(C, a.nchunks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(bn_reduce_stage2<1>, dim3(ic_cdiv(C, 64)), dim3(64), 0, st, a.partial, C, (long long)N * HW, dbeta,
+                       dgamma, sums, a.nchunks);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
+extern "C" int ic_bn_backward_apply_f32(const float* dy, const float* x, const float* scale, const float* shift,
+                                        const float* mean, const float* invstd, const float* gamma, const double* sums,
+                                        long long count, float* dx, int N, int C, int HW, int relu, ic_stream_t stream) {
+    IC_CHECK_ARG(dy && x && scale && shift && mean && invstd && gamma && sums && dx && N > 0 && C > 0 && HW > 0 && count > 0);
+    BnArgs a{};
+    a.x = x; a.dy = dy; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.gamma = gamma;
+    a.N = N; a.C = C; a.HW = HW; a.relu = relu; a.sums = sums; a.out0 = dx; a.count = count;
+    const long long total = (long long)N * C * HW;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ic_cdiv(HW, 1024) < 1 ? 1 : ic_cdiv(HW, 1024), N * C), dim3(256), 0,
+                       (hipStream_t)stream, a, total);
     IC_LAUNCH_CHECK();
     return IC_OK;
 }

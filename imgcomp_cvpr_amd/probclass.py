@@ -46,6 +46,8 @@ class _Network3D(object):
         self._device = None
         self._ws = None
         self._last_logits = None
+        self._train_graph = None      # training.TrainGraph.bind()
+        self._graph_version = -1
 
     # -- static geometry (reference :40-57) --
 
@@ -113,9 +115,13 @@ class _Network3D(object):
         """None unless config.regularization_factor is set (reference :115-119)."""
         if self.config.regularization_factor is None:
             return None
-        self._require_weights()
+        if self._train_graph is not None:
+            params = {n: t for n, t in self._train_graph.params.items() if n.startswith(self._PROBCLASS_SCOPE + '/')}
+        else:
+            self._require_weights()
+            params = self._params
         f = float(self.config.regularization_factor)
-        return f * sum(0.5 * (t * t).sum() for n, t in self._params.items() if n.endswith('/weights'))
+        return (f * sum(0.5 * (t * t).sum() for n, t in params.items() if n.endswith('/weights'))).detach()
 
     def _require_weights(self):
         if self._params is None:
@@ -176,10 +182,21 @@ class _ResShallow(_Network3D):
             self._ws = torch.empty(need, dtype=torch.uint8, device=self._device)
         return self._ws, need
 
+    def _sync_with_training_graph(self):
+        g = self._train_graph
+        if g is not None and self._graph_version != g.version:
+            self.load_weights(OrderedDict((n, t.detach().cpu().numpy()) for n, t in g.params.items()
+                                          if n.startswith(self._PROBCLASS_SCOPE + '/')), g.dev)
+            self._graph_version = g.version
+
     def bitcost(self, q, target_symbols, is_training, pad_value=0, return_logits=False):
         if is_training:
-            raise NotImplementedError('is_training=True: the context model trains inside imgcomp_cvpr_amd.training.TrainGraph '
-                                      '(forward with tape + hand-written backward); this plugin method is inference only')
+            if self._train_graph is None:
+                raise ValueError('is_training=True needs the training graph that owns the variables and the backward: '
+                                 'training.TrainGraph(ae_config, pc_config, weights).bind(ae, pc) (see train.py)')
+            assert not return_logits
+            return self._train_graph.plugin_bitcost(q, target_symbols, pad_value)
+        self._sync_with_training_graph()
         self._require_weights()
         assert q.dim() == 4, 'Expected NCHW'
         _lib.require_cuda(q, 'q')

@@ -455,23 +455,32 @@ def is_model_variable(name):
     """what the hot path needs from a training checkpoint: no optimiser slots, counters or summaries."""
     if not (name.startswith('autoencoder/') or name.startswith('probclass3d/')):
         return False
-    return not re.search(r'/(Adam|Adam_1|ExponentialMovingAverage|Momentum)$', name)
+    return not re.search(r'/(Adam\w*|ExponentialMovingAverage|Momentum)$', name) and not re.search(r'beta[12]_power(_\d+)?$', name)
 
 
-def load_weights(path, itr=-1):
+def is_training_state(name):
+    """what continuing a training run needs on top of the model variables (the reference's Saver restores every variable
+    of the graph: restore_manager.py:52-58): the step counter and the two Adam optimisers' slots and beta powers."""
+    return name == 'global_step' or bool(re.search(r'/(Adam_AE|Adam_AE_1|Adam_PC|Adam_PC_1)$', name)) or \
+        bool(re.match(r'(Adam_AE|Adam_PC)/beta[12]_power$', name))
+
+
+def load_weights(path, itr=-1, training_state=False):
     """path: a checkpoint prefix, a .index file, a ckpts/ directory or a log dir containing one (restore_manager.py:52-58),
-    or an .npz written by this package's train.py.  -> dict name -> array with the variables of the two networks."""
+    or an .npz written by this package's train.py.  -> dict name -> array with the variables of the two networks
+    (training_state=True: plus global_step and the optimiser slots when the checkpoint has them)."""
+    keep = (lambda n: is_model_variable(n) or is_training_state(n)) if training_state else is_model_variable
     if path.endswith('.npz') and os.path.isfile(path):
         with np.load(path) as z:
-            return {k: z[k] for k in z.files if is_model_variable(k)}
+            return {k: z[k] for k in z.files if keep(k)}
     if os.path.isdir(path):
         ckpt_dir = path if os.path.basename(os.path.normpath(path)) == _CKPT_DIR_NAME else ckpt_dir_for_log_dir(path)
         if not os.path.isdir(ckpt_dir):
             raise ValueError('Invalid ckpt dir: {}'.format(path))
         _, prefix = latest_checkpoint_before_itr(ckpt_dir, itr)
         if os.path.isfile(prefix + '.npz') and not os.path.isfile(prefix + '.index'):
-            return load_weights(prefix + '.npz')
+            return load_weights(prefix + '.npz', training_state=training_state)
     else:
         prefix = path[:-len('.index')] if path.endswith('.index') else path
-    names = [n for n in list_variables(prefix) if is_model_variable(n)]
+    names = [n for n in list_variables(prefix) if keep(n)]
     return dict(read_bundle(prefix, names=names))

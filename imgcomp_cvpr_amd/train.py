@@ -15,7 +15,8 @@ training images (inputpipeline.py:199-213), img/s on the console (train.py:201-2
 --save_interval iterations in the reference's on-disk format -- `ckpts/ckpt-<itr>.index` + `.data-00000-of-00001`
 (TF-1 tensor bundle, tf_checkpoint.py) + `ckpts/var_names.pkl` (saver.py:19-43) -- so the reference's own val.py can
 restore what this train.py wrote and vice versa.  What is different: the TF input queue is a plain loader;
-TensorBoard / Sheets logging is out of scope; --restore takes the variables only (Adam moments start at zero).  Under data parallelism the global batch of the config is split over the ranks; gradients are
+TensorBoard / Sheets logging is out of scope.  --restore continues a run: variables, global_step (so the DECAY
+schedule and the checkpoint numbering carry on) and the Adam slots when the checkpoint has them.  Under data parallelism the global batch of the config is split over the ranks; gradients are
 averaged with three bucketed RCCL all-reduces per step (training.GradBuckets), BatchNorm uses local statistics.
 """
 import argparse
@@ -150,16 +151,21 @@ def train(ae_config_path, pc_config_path, log_dir_root, loader_fn, max_itr, log_
     if batch_total % world:
         raise ValueError('batch_size {} not divisible by {} ranks'.format(batch_total, world))
     loader = loader_fn(ae_config, batch_total // world, rank)
+    ckpt = None
     if restore:
         from . import tf_checkpoint
-        weights = tf_checkpoint.load_weights(restore)
+        ckpt = tf_checkpoint.load_weights(restore, training_state=True)
+        weights = {k: v for k, v in ckpt.items() if tf_checkpoint.is_model_variable(k)}
     else:
         weights = _weights.synthetic_weights(ae_config, pc_config, gain=1.0, heatmap_bias=None)   # Xavier, as slim initialises
         weights[_weights.ENC + '/centers'] = np.random.RandomState(666).uniform(
             *map(float, ae_config.centers_initial_range), size=int(ae_config.num_centers)).astype(np.float32)
     # every rank starts from identical variables (rank 0's)
-    num_itr_per_epoch = max(loader.num_images // max(batch_total, 1), 1)
+    # epoch length as the reference counts it (training_helpers.py:51-60): every decoded image yields NUM_CROPS_PER_IMG crops,
+    # so batch 30 consumes 3 images; the DECAY schedule (x0.1 every 2 epochs, staircase) is timed in these epochs
+    num_itr_per_epoch = training.get_num_itr_per_epoch(loader.num_images, batch_total, loader.crops_per_img)
     tr = training.Trainer(ae_config, pc_config, weights, device, num_itr_per_epoch)
+    start_itr = tr.restore_training_state(ckpt) if ckpt else 0
     if world > 1:
         import torch.distributed as dist
         for t in tr.graph.params.values():
@@ -172,17 +178,17 @@ def train(ae_config_path, pc_config_path, log_dir_root, loader_fn, max_itr, log_
             print('Log dir: {}'.format(log_dir))
     t_last, n_last = time.time(), 0
     hist = []
-    for itr in range(max_itr):
+    for itr in range(start_itr, start_itr + max_itr):
         x = torch.as_tensor(loader.get_batch()).to(device)
         out = tr.step(x)
         hist.append(out)
-        if verbose and rank == 0 and (itr % log_interval == 0 or itr == max_itr - 1):
+        if verbose and rank == 0 and (itr % log_interval == 0 or itr == start_itr + max_itr - 1):
             torch.cuda.synchronize()
             dt = time.time() - t_last
-            ips = (itr + 1 - n_last) * batch_total / max(dt, 1e-9)
+            ips = (itr + 1 - max(n_last, start_itr)) * batch_total / max(dt, 1e-9)
             t_last, n_last = time.time(), itr + 1
             print('{: 7d} | {} | {:.1f} img/s'.format(itr, ' '.join('{}: {:.4f}'.format(k, v) for k, v in out.items()), ips), flush=True)
-        if log_dir and ((itr + 1) % save_interval == 0 or itr == max_itr - 1):
+        if log_dir and ((itr + 1) % save_interval == 0 or itr == start_itr + max_itr - 1):
             save_checkpoint(path.join(log_dir, 'ckpts'), tr.state_weights(), itr + 1)
     return tr, hist, log_dir
 
@@ -192,7 +198,7 @@ def save_checkpoint(ckpt_dir, variables, global_step):
     from . import tf_checkpoint
     os.makedirs(ckpt_dir, exist_ok=True)
     tensors = dict(variables)
-    tensors['global_step'] = np.array(global_step, np.int64)
+    tensors['global_step'] = np.array(global_step, np.int64)          # (already there when state_weights wrote it)
     if not path.exists(path.join(ckpt_dir, 'var_names.pkl')):
         tf_checkpoint.write_var_names(ckpt_dir, sorted(tensors))
     tf_checkpoint.write_bundle(path.join(ckpt_dir, 'ckpt-{}'.format(global_step)), tensors)

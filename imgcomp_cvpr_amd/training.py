@@ -16,8 +16,18 @@ quantiser / context-model gradients have their own kernels).  PyTorch supplies t
 (context model | decoder | encoder) so that data-parallel training all-reduces three contiguous buckets over
 RCCL, each launched as soon as its group's backward is complete (pc first, then decoder, then encoder).
 
-BatchNorm under data parallelism uses LOCAL batch statistics (the reference has no multi-GPU mode; its single-GPU
-batch-30 statistics are reproduced exactly only at world size 1).
+The step can be driven two ways, one code path underneath:
+  * the reference's own call sites (train.py:101-127) through the plugin objects -- TrainGraph.bind(ae, pc), then
+    ae.encode(x, True), ae.decode(enc.qbar, True), pc.bitcost(stop_gradient(qbar), symbols, True, pad_value), Distortions,
+    get_loss, total_loss.backward(): the three calls are torch.autograd Functions whose backward is the hand-written HIP
+    backward of that section (parameter gradients land in the flat buckets; the L2 terms' gradients are folded into the
+    filter-gradient kernels, their values are returned by the *_regularization_loss() accessors);
+  * TrainGraph.forward_backward(x) / Trainer.step(x), which is exactly that sequence.
+
+BatchNorm under data parallelism: cross-replica statistics by default (sync_bn) -- the reference normalises over its whole
+batch on one device (autoencoder.py:115-125), so 8 ranks x 4 crops must see the statistics of all 32.  Per layer and
+direction the ranks all-reduce 2 C float64 sums (ic_bn_moments_f32 / ic_bn_backward_reduce_f32).  sync_bn=False keeps the
+statistics local to a rank (a per-tower replication of the TF graph).
 """
 import math
 from collections import OrderedDict
@@ -33,6 +43,20 @@ BN_EPS = 1e-5
 BN_DECAY = 0.9
 _IMG_MEAN = (121.85369873, 113.58860779, 100.63715363)
 _IMG_VAR = (4746.37695312, 4454.13964844, 4812.234375)
+
+
+def _staged_all_reduce(t, pg):
+    """all-reduce(sum) of a device tensor over a backend without device support (gloo: the world-size-2 tests that share
+    one GPU between two processes): through a host copy, synchronously.  RCCL reduces device tensors in place."""
+    import torch.distributed as dist
+    h = t.detach().cpu()
+    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=pg)
+    t.copy_(h.to(t.device))
+
+
+def _is_gloo(pg):
+    import torch.distributed as dist
+    return dist.get_backend(pg) == 'gloo'
 
 
 class GradBuckets(object):
@@ -58,6 +82,10 @@ class GradBuckets(object):
         world = self._world()
         if world == 1 and not self.always_reduce:
             return
+        if self.flat[name].is_cuda and _is_gloo(self.pg):
+            _staged_all_reduce(self.flat[name], self.pg)
+            self.flat[name].div_(world)
+            return
         # ProcessGroupNCCL orders the collective after the work already queued on the current stream
         work = dist.all_reduce(self.flat[name], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         self._pending.append((work, self.flat[name], world))
@@ -76,8 +104,11 @@ class _Layer(object):
 class TrainGraph(object):
     """Parameters, gradients and the hand-written forward/backward of the CVPR autoencoder + res_shallow context model."""
 
-    def __init__(self, ae_config, pc_config, weights, device='cuda', process_group=None):
+    def __init__(self, ae_config, pc_config, weights, device='cuda', process_group=None, sync_bn=None):
         self.ae_config, self.pc_config = ae_config, pc_config
+        self.sync_bn = sync_bn          # None: on whenever the process group has more than one rank
+        self.version = 0                # bumped whenever the variables change (bound plugin objects re-fold their inference plan)
+        self._hook = None
         self.dev = torch.device(device)
         if self.dev.type != 'cuda':
             raise _lib.HipLibraryError('training runs only on a HIP device, got {}'.format(self.dev))
@@ -251,19 +282,44 @@ class TrainGraph(object):
                                       ptr(ws), need, self._st()), 'wgrad ' + l.scope)
 
     # ---- conv + BatchNorm(train) + activation (+ residual adds) ----
+    def _bn_world(self):
+        """ranks whose statistics a BatchNorm layer sums over: 1 unless sync BatchNorm is on and there is more than one rank"""
+        import torch.distributed as dist
+        if self.sync_bn is False or not (dist.is_available() and dist.is_initialized()):
+            return 1
+        w = dist.get_world_size(self.pg)
+        return w if (self.sync_bn or self.sync_bn is None) else 1
+
+    def _allreduce_sums(self, sums):
+        import torch.distributed as dist
+        if _is_gloo(self.pg):
+            _staged_all_reduce(sums, self.pg)
+        else:
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.pg)
+
     def _cba_fwd(self, scope, x, relu, res1=None, res2=None, tape=None):
         l = self.layers[scope]
         raw = self._raw_forward(l, x)
         N, Cc, H, W = raw.shape
         stats = self._new(4, Cc)
         mean, invstd, scale, shift = stats[0], stats[1], stats[2], stats[3]
-        # batch statistics, folded scale/shift and the moving-average update (decay 0.9) in one call
-        check(lib.ic_bn_train_stats_f32(ptr(raw), ptr(self.params[scope + '/BatchNorm/gamma']),
-                                        ptr(self.params[scope + '/BatchNorm/beta']),
-                                        ptr(self.params[scope + '/BatchNorm/moving_mean']),
-                                        ptr(self.params[scope + '/BatchNorm/moving_variance']), BN_DECAY, BN_EPS,
-                                        ptr(mean), ptr(invstd), ptr(scale), ptr(shift), N, Cc, H * W,
-                                        ptr(self.bn_ws), self._st()), 'bn statistics')
+        P = self.params
+        world = self._bn_world()
+        if world == 1:
+            # batch statistics, folded scale/shift and the moving-average update (decay 0.9) in one call
+            check(lib.ic_bn_train_stats_f32(ptr(raw), ptr(P[scope + '/BatchNorm/gamma']), ptr(P[scope + '/BatchNorm/beta']),
+                                            ptr(P[scope + '/BatchNorm/moving_mean']), ptr(P[scope + '/BatchNorm/moving_variance']),
+                                            BN_DECAY, BN_EPS, ptr(mean), ptr(invstd), ptr(scale), ptr(shift), N, Cc, H * W,
+                                            ptr(self.bn_ws), self._st()), 'bn statistics')
+        else:
+            # cross-replica statistics: this rank's float64 moments, summed over the ranks, folded over the global count
+            sums = torch.empty(2 * Cc, dtype=torch.float64, device=self.dev)
+            check(lib.ic_bn_moments_f32(ptr(raw), ptr(sums), N, Cc, H * W, ptr(self.bn_ws), self._st()), 'bn moments')
+            self._allreduce_sums(sums)
+            check(lib.ic_bn_train_fold_moments_f32(ptr(sums), N * H * W * world, ptr(P[scope + '/BatchNorm/gamma']),
+                                                   ptr(P[scope + '/BatchNorm/beta']), ptr(P[scope + '/BatchNorm/moving_mean']),
+                                                   ptr(P[scope + '/BatchNorm/moving_variance']), BN_DECAY, BN_EPS, ptr(mean),
+                                                   ptr(invstd), ptr(scale), ptr(shift), Cc, self._st()), 'bn fold')
         y = self._new(N, Cc, H, W)
         check(lib.ic_bn_apply_f32(ptr(raw), ptr(scale), ptr(shift), ptr(res1), ptr(res2), ptr(y), N, Cc, H * W,
                                   int(relu), self._st()))
@@ -275,11 +331,23 @@ class TrainGraph(object):
         l, x, raw, mean, invstd, scale, shift, relu = rec
         N, Cc, H, W = raw.shape
         draw = self._new(N, Cc, H, W)
-        check(lib.ic_bn_backward_f32(ptr(dy), ptr(raw), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
-                                     ptr(self.params[l.scope + '/BatchNorm/gamma']), ptr(draw),
-                                     ptr(self.grads[l.scope + '/BatchNorm/gamma']),
-                                     ptr(self.grads[l.scope + '/BatchNorm/beta']),
-                                     N, Cc, H * W, int(relu), ptr(self.bn_ws), self._st()), 'bn backward')
+        gamma = self.params[l.scope + '/BatchNorm/gamma']
+        dgamma, dbeta = self.grads[l.scope + '/BatchNorm/gamma'], self.grads[l.scope + '/BatchNorm/beta']
+        world = self._bn_world()
+        if world == 1:
+            check(lib.ic_bn_backward_f32(ptr(dy), ptr(raw), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(gamma), ptr(draw),
+                                         ptr(dgamma), ptr(dbeta), N, Cc, H * W, int(relu), ptr(self.bn_ws), self._st()), 'bn backward')
+        else:
+            # dgamma / dbeta stay this rank's sums (the bucket all-reduce averages them like every parameter gradient);
+            # the data gradient needs the sums over ALL ranks' elements
+            sums = torch.empty(2 * Cc, dtype=torch.float64, device=self.dev)
+            check(lib.ic_bn_backward_reduce_f32(ptr(dy), ptr(raw), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums),
+                                                ptr(dgamma), ptr(dbeta), N, Cc, H * W, int(relu), ptr(self.bn_ws), self._st()),
+                  'bn backward reduce')
+            self._allreduce_sums(sums)
+            check(lib.ic_bn_backward_apply_f32(ptr(dy), ptr(raw), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(gamma),
+                                               ptr(sums), N * H * W * world, ptr(draw), N, Cc, H * W, int(relu), self._st()),
+                  'bn backward apply')
         self._wgrad(l, x, draw)
         return self._raw_backward_data(l, draw) if need_dx else None
 
@@ -322,25 +390,24 @@ class TrainGraph(object):
         return g_net + g_res0
 
     # ------------------------------------------------------------------------------------------------
-    # the step
+    # the step, in sections: each forward leaves its tape in self._tape, each backward consumes it
     # ------------------------------------------------------------------------------------------------
-    def forward_backward(self, x):
-        """x: (N,3,H,W) float32 0..255 on the device.  Fills self.grads; returns a dict of python floats."""
+    def encode_train(self, x):
+        """autoencoder.py:218-244 with is_training=True.  -> dict(qbar, qhard, symbols, z, heatmap, qsoft)"""
         cfg = self.ae_config
         st = self._st()
         N, _, H, W = x.shape
         assert H % 8 == 0 and W % 8 == 0
-        C, L, k = self.C, self.L, self.k
+        C, L = self.C, self.L
         h, w = H // 8, W // 8
         self._pack_all_3x3(N, H // 4, W // 4)
-        # ===== forward: encoder =====
-        enc_tape_a, enc_tape_s, enc_tape_b = [], [], []
+        ta, ts, tb = [], [], []
         # _normalize (autoencoder.py:136-144): kept as its own tensor, h1's filter gradient needs the normalised input
         xn = (x - self.img_mean.view(1, 3, 1, 1)) / self.img_std.view(1, 3, 1, 1) if cfg.normalization == 'FIXED' else x
-        net = self._cba_fwd(_weights.ENC + '/h1', xn.contiguous(), True, tape=enc_tape_a)
-        net = self._cba_fwd(_weights.ENC + '/h2', net, True, tape=enc_tape_a)
-        net = self._stack_fwd('enc', net, enc_tape_s)
-        bott = self._cba_fwd(_weights.ENC + '/to_bn', net, False, tape=enc_tape_b)
+        net = self._cba_fwd(_weights.ENC + '/h1', xn.contiguous(), True, tape=ta)
+        net = self._cba_fwd(_weights.ENC + '/h2', net, True, tape=ta)
+        net = self._stack_fwd('enc', net, ts)
+        bott = self._cba_fwd(_weights.ENC + '/to_bn', net, False, tape=tb)
         centers = self.params[_weights.ENC + '/centers']
         mk = lambda: self._new(N, C, h, w)
         hm, z, qsoft, qhard, qbar = (mk() if self.heatmap else None), mk(), mk(), mk(), mk()
@@ -351,82 +418,137 @@ class TrainGraph(object):
         else:
             check(lib.ic_quantize_f32(ptr(bott), ptr(centers), L, 1.0, ptr(qsoft), ptr(qhard), ptr(symbols),
                                       bott.numel(), st))
+            z = bott
             qbar = qsoft + (qhard - qsoft)
-        # ===== forward: decoder on qbar =====
-        dec_tape_a, dec_tape_s, dec_tape_b = [], [], []
-        net = self._cba_fwd(_weights.DEC + '/from_bn', qbar, True, tape=dec_tape_a)
-        net = self._stack_fwd('dec', net, dec_tape_s)
-        net = self._cba_fwd(_weights.DEC + '/h12', net, True, tape=dec_tape_b)
-        pre = self._cba_fwd(_weights.DEC + '/h13', net, False, tape=dec_tape_b)
-        # ===== forward: context model on stop_gradient(qbar) =====
-        pad_value = self._pad_value() if self.pc_config.use_centers_for_padding else 0.0
+        self._tape_enc = (ta, ts, tb, bott, (N, C, h, w))
+        return {'qbar': qbar, 'qhard': qhard, 'symbols': symbols, 'z': z, 'heatmap': hm, 'qsoft': qsoft}
+
+    def decode_train(self, qbar):
+        """autoencoder.py:246-268 with is_training=True, up to (not including) _denormalize / clip -> the normalised image"""
+        ta, ts, tb = [], [], []
+        net = self._cba_fwd(_weights.DEC + '/from_bn', qbar.contiguous(), True, tape=ta)
+        net = self._stack_fwd('dec', net, ts)
+        net = self._cba_fwd(_weights.DEC + '/h12', net, True, tape=tb)
+        pre = self._cba_fwd(_weights.DEC + '/h13', net, False, tape=tb)
+        self._tape_dec = (ta, ts, tb)
+        return pre
+
+    def bitcost_train(self, q, symbols, pad_value):
+        """probclass.py:63-106 with is_training=True -> bit cost per symbol (N,C,h,w)"""
+        N, C, h, w = q.shape
         wtab_t = []
-        for s in self.pc_scopes:
-            wtab_t += [self.params[s + '/weights'], self.params[s + '/biases']]
-        pc_need = lib.ic_pc_workspace_bytes(N, C, h, w, k)
+        for sc in self.pc_scopes:
+            wtab_t += [self.params[sc + '/weights'], self.params[sc + '/biases']]
+        pc_need = lib.ic_pc_workspace_bytes(N, C, h, w, self.k)
         pc_ws = torch.empty(pc_need, dtype=torch.uint8, device=self.dev)
-        logits = self._new(N, C, h, w, L)
-        bc = mk()
-        check(lib.ic_pc_bitcost_f32(ptr(qbar), ptr(symbols), _lib.ptr_table(wtab_t), k, L, pad_value, ptr(logits),
-                                    ptr(bc), N, C, h, w, ptr(pc_ws), pc_need, st), 'pc forward')
-        # ===== loss (train.py:303-336, :379-390) =====
-        xo = pre.detach().requires_grad_(True)
-        if cfg.normalization == 'FIXED':
-            x_out = torch.clamp(xo * self.img_std.view(1, 3, 1, 1) + self.img_mean.view(1, 3, 1, 1), 0, 255)
-        else:
-            x_out = torch.clamp(xo, 0, 255)
-        kind = cfg.distortion_to_minimize
-        mse_per_img = ((x_out - x) ** 2).mean(dim=(1, 2, 3))
-        if kind == 'ms_ssim':
-            msssim = ms_ssim.multiscale_ssim(x, x_out)
-            d_loss = float(cfg.K_ms_ssim) * (1.0 - msssim)
-        elif kind == 'mse':
-            msssim = None
-            d_loss = mse_per_img.mean()
-        else:
-            msssim = None
-            d_loss = float(cfg.K_psnr) - (10.0 * torch.log10(255.0 * 255.0 / mse_per_img)).mean()
-        d_loss.backward()
-        g_pre = xo.grad
-        count = float(bc.numel())
-        H_real = bc.mean()
-        H_mask = (bc * hm).mean() if self.heatmap else H_real
-        H_soft = 0.5 * (H_mask + H_real)
-        beta, H_t = float(cfg.beta), float(cfg.H_target)
-        # pc_loss = beta * max(H_soft - H_target, 0): the gate stays on the device (no host round trip mid-step)
-        pc_loss = beta * torch.clamp(H_soft - H_t, min=0.0)
-        gate = (H_soft > H_t).to(torch.float32) * (beta / count)
-        d_bc = (hm + 1.0) * (0.5 * gate) if self.heatmap else torch.ones_like(bc) * gate
-        d_hm = bc * (0.5 * gate) if self.heatmap else None
-        # ===== backward: context model (its bucket is complete first) =====
-        self._pc_backward(qbar, symbols, logits, d_bc, pc_ws, pad_value, N, C, h, w)
+        logits = self._new(N, C, h, w, self.L)
+        bc = self._new(N, C, h, w)
+        q = q.contiguous()
+        check(lib.ic_pc_bitcost_f32(ptr(q), ptr(symbols), _lib.ptr_table(wtab_t), self.k, self.L, float(pad_value), ptr(logits),
+                                    ptr(bc), N, C, h, w, ptr(pc_ws), pc_need, self._st()), 'pc forward')
+        self._tape_pc = (q, symbols, logits, pc_ws, float(pad_value), (N, C, h, w))
+        return bc
+
+    def backward_pc(self, d_bc):
+        q, symbols, logits, pc_ws, pad_value, (N, C, h, w) = self._tape_pc
+        self._tape_pc = None
+        self._pc_backward(q, symbols, logits, d_bc, pc_ws, pad_value, N, C, h, w)
         self._bucket_ready('pc')
-        # ===== backward: decoder =====
-        g = self._cba_bwd(dec_tape_b.pop(), g_pre)
-        g = self._cba_bwd(dec_tape_b.pop(), g)
-        g = self._stack_bwd(dec_tape_s, g)
-        g_qbar = self._cba_bwd(dec_tape_a.pop(), g)
+
+    def backward_decoder(self, g_pre):
+        ta, ts, tb = self._tape_dec
+        self._tape_dec = None
+        g = self._cba_bwd(tb.pop(), g_pre.contiguous())
+        g = self._cba_bwd(tb.pop(), g)
+        g = self._stack_bwd(ts, g)
+        g_qbar = self._cba_bwd(ta.pop(), g)
         self._bucket_ready('dec')
-        # ===== backward: quantiser + importance map =====
+        return g_qbar
+
+    def backward_encoder(self, g_qbar, d_hm):
+        cfg = self.ae_config
+        ta, ts, tb, bott, (N, C, h, w) = self._tape_enc
+        self._tape_enc = None
+        centers = self.params[_weights.ENC + '/centers']
         d_bott = torch.empty_like(bott)
         d_centers = self.grads[_weights.ENC + '/centers']
-        qws = self._scratch('qbwd', lib.ic_heatmap_quantize_bwd_workspace_bytes(L))
-        check(lib.ic_heatmap_quantize_bwd_f32(ptr(bott), ptr(centers), L, 1.0, ptr(g_qbar), ptr(d_hm), ptr(d_bott),
-                                              ptr(d_centers), N, C, h, w, int(self.heatmap), ptr(qws), st), 'quantiser backward')
+        qws = self._scratch('qbwd', lib.ic_heatmap_quantize_bwd_workspace_bytes(self.L))
+        g_qbar = (g_qbar if g_qbar is not None else torch.zeros((N, C, h, w), device=self.dev)).contiguous()
+        d_hm = d_hm.contiguous() if (d_hm is not None and self.heatmap) else None
+        check(lib.ic_heatmap_quantize_bwd_f32(ptr(bott), ptr(centers), self.L, 1.0, ptr(g_qbar), ptr(d_hm), ptr(d_bott),
+                                              ptr(d_centers), N, C, h, w, int(self.heatmap), ptr(qws), self._st()),
+              'quantiser backward')
         if cfg.regularization_factor_centers != 0:
             d_centers.add_(centers, alpha=float(cfg.regularization_factor_centers))
-        # ===== backward: encoder =====
-        g = self._cba_bwd(enc_tape_b.pop(), d_bott)
-        g = self._stack_bwd(enc_tape_s, g)
-        g = self._cba_bwd(enc_tape_a.pop(), g)
-        self._cba_bwd(enc_tape_a.pop(), g, need_dx=False)
+        g = self._cba_bwd(tb.pop(), d_bott)
+        g = self._stack_bwd(ts, g)
+        g = self._cba_bwd(ta.pop(), g)
+        self._cba_bwd(ta.pop(), g, need_dx=False)
         self._bucket_ready('enc')
+
+    # ---- the reference's call sites (train.py:101-105) as autograd Functions over the sections above ----
+    def _grad_hook(self):
+        # a leaf that requires grad, so that autograd records the Functions although none of their tensor inputs does
+        if self._hook is None:
+            self._hook = torch.zeros((), device=self.dev, requires_grad=True)
+        return self._hook
+
+    def plugin_encode(self, x):
+        from . import autoencoder
+        _lib.require_cuda(x, 'x')
+        outs = _EncodeTrainFn.apply(self, x.contiguous(), self._grad_hook())
+        qbar, hm, qhard, symbols, z, qsoft = outs
+        self._last_qsoft = qsoft
+        return autoencoder.EncoderOutput(qbar, qhard, symbols, z, hm if self.heatmap else None)
+
+    def plugin_decode(self, q):
+        pre = _DecodeTrainFn.apply(self, q, self._grad_hook())
+        # _denormalize + _clip_to_image_range (autoencoder.py:146-158,267) in torch: autograd carries the loss gradient to `pre`
+        if self.ae_config.normalization == 'FIXED':
+            return torch.clamp(pre * self.img_std.view(1, 3, 1, 1) + self.img_mean.view(1, 3, 1, 1), 0, 255)
+        return torch.clamp(pre, 0, 255)
+
+    def plugin_bitcost(self, q, target_symbols, pad_value):
+        if q.requires_grad:
+            raise NotImplementedError('the context model is trained on stop_gradient(qbar) (train.py:103-104): pass q.detach()')
+        # a tensor pad value is centers[0] (pc.auto_pad_value(ae), probclass.py:59-61): the C ABI takes it by value, the
+        # graph keeps an asynchronously refreshed pinned copy (no host stall mid-step)
+        pv = self._pad_value() if torch.is_tensor(pad_value) else float(pad_value)
+        return _BitcostTrainFn.apply(self, q, target_symbols, pv, self._grad_hook())
+
+    def finish_backward(self):
+        """after total_loss.backward(): wait for the gradient all-reduces (what get_train_op's train_op depends on)"""
         self._wait_buckets()
+
+    def bind(self, ae, pc):
+        """make ae.encode / ae.decode / pc.bitcost with is_training=True run this graph's training-mode forward, and their
+        is_training=False calls evaluate the CURRENT training variables (test-in-train, train.py:115-127)"""
+        ae._train_graph = self
+        pc._train_graph = self
+        ae._graph_version = pc._graph_version = -1
+        return ae, pc
+
+    def forward_backward(self, x):
+        """x: (N,3,H,W) float32 0..255 on the device.  Fills self.grads; returns a dict of python floats.
+        train.py:101-106 + get_loss + the backward of total_loss, through the same Functions the plugin call sites use."""
+        cfg = self.ae_config
+        N, _, H, W = x.shape
+        enc = self.plugin_encode(x)
+        x_out = self.plugin_decode(enc.qbar)
+        pad_value = self._pad_value() if self.pc_config.use_centers_for_padding else 0.0
+        bc = self.plugin_bitcost(enc.qbar.detach(), enc.symbols, pad_value)
+        d = Distortions(cfg, x, x_out, is_training=True)
+        total, H_real, pc_comps, ae_comps = get_loss(cfg, None, None, d.d_loss_scaled, bc, enc.heatmap)
+        total.backward()
+        self.finish_backward()
         # one device -> host transfer for all the scalars of the step
-        stats = [d_loss.detach(), pc_loss, H_real, H_mask, bc.sum() / (N * H * W)] + ([msssim.detach()] if msssim is not None else [])
+        pcd = dict(pc_comps)
+        stats = [d.d_loss_scaled.detach(), pcd['pc_loss'].detach(), H_real.detach(), pcd['H_mask'].detach(), bc.detach().sum() / (N * H * W)] + \
+                ([d.ms_ssim.detach()] if d.ms_ssim is not None else [])
         vals = torch.stack([t.to(torch.float32).reshape(()) for t in stats]).tolist()
         out = dict(zip(['d_loss_scaled', 'pc_loss', 'H_real', 'H_mask', 'bpp', 'ms_ssim'], vals))
-        self.last = {'x_out': x_out.detach(), 'symbols': symbols, 'bc': bc, 'heatmap': hm, 'z': z, 'qbar': qbar}
+        self.last = {'x_out': x_out.detach(), 'symbols': enc.symbols, 'bc': bc.detach(), 'heatmap': enc.heatmap.detach() if enc.heatmap is not None else None,
+                     'z': enc.z, 'qbar': enc.qbar.detach()}
         return out
 
     # ---- centres[0] on the host (the context model's pad value is a by-value argument of the C ABI) ----
@@ -506,6 +628,105 @@ class TrainGraph(object):
         self.buckets.wait()
 
 
+class _EncodeTrainFn(torch.autograd.Function):
+    """ae.encode(x, is_training=True): outputs (qbar, heatmap, qhard, symbols, z, qsoft); qbar and heatmap carry gradients
+    (train.py:101-106: the decoder reads qbar, the rate loss reads the heatmap), backward = quantiser + importance map +
+    encoder backward, parameter gradients into the graph's encoder bucket."""
+
+    @staticmethod
+    def forward(ctx, graph, x, hook):
+        o = graph.encode_train(x)
+        ctx.graph = graph
+        hm = o['heatmap'] if o['heatmap'] is not None else torch.zeros((), device=x.device)
+        ctx.mark_non_differentiable(o['qhard'], o['symbols'], o['z'], o['qsoft'])
+        return o['qbar'], hm, o['qhard'], o['symbols'], o['z'], o['qsoft']
+
+    @staticmethod
+    def backward(ctx, g_qbar, g_hm, *unused):
+        ctx.graph.backward_encoder(g_qbar, g_hm if ctx.graph.heatmap else None)
+        return None, None, None
+
+
+class _DecodeTrainFn(torch.autograd.Function):
+    """ae.decode(q, is_training=True) up to the normalised image; backward = decoder backward -> gradient wrt q."""
+
+    @staticmethod
+    def forward(ctx, graph, q, hook):
+        ctx.graph = graph
+        return graph.decode_train(q)
+
+    @staticmethod
+    def backward(ctx, g_pre):
+        return None, ctx.graph.backward_decoder(g_pre), None
+
+
+class _BitcostTrainFn(torch.autograd.Function):
+    """pc.bitcost(stop_gradient(q), symbols, is_training=True): backward = context-model backward (its bucket first)."""
+
+    @staticmethod
+    def forward(ctx, graph, q, symbols, pad_value, hook):
+        ctx.graph = graph
+        return graph.bitcost_train(q, symbols, pad_value)
+
+    @staticmethod
+    def backward(ctx, d_bc):
+        ctx.graph.backward_pc(d_bc.contiguous())
+        return None, None, None, None, None
+
+
+class Distortions(object):
+    """train.py:352-431.  x, x_out: (N,3,H,W) float 0..255.  mse / psnr on integer-cast values unless they are the quantity
+    being minimised in training (:361-366); ms_ssim only when it is minimised (:359)."""
+
+    def __init__(self, config, x, x_out, is_training):
+        self.config = config
+        minimize_for = config.distortion_to_minimize
+        assert minimize_for in ('mse', 'psnr', 'ms_ssim')
+        cast_psnr = (not is_training) or minimize_for != 'psnr'
+        cast_mse = (not is_training) or minimize_for != 'mse'
+        self.mse = self.get_mse_per_img(x, x_out, cast_mse).mean()
+        self.psnr = self.get_psnr_per_image(x, x_out, cast_psnr).mean()
+        self.ms_ssim = ms_ssim.multiscale_ssim(x, x_out) if minimize_for == 'ms_ssim' else None
+        self.d_loss_scaled = self._get_distortion_to_minimize(minimize_for)
+
+    def _get_distortion_to_minimize(self, minimize_for):
+        if minimize_for == 'mse':
+            return self.mse
+        if minimize_for == 'psnr':
+            return float(self.config.K_psnr) - self.psnr
+        return float(self.config.K_ms_ssim) * (1.0 - self.ms_ssim)
+
+    @staticmethod
+    def get_mse_per_img(inp, otp, cast_to_int):
+        if cast_to_int:
+            inp, otp = inp.detach().to(torch.int32), otp.detach().to(torch.int32)      # tf.cast truncates
+        return ((otp - inp) ** 2).to(torch.float32).mean(dim=(1, 2, 3))
+
+    @staticmethod
+    def get_psnr_per_image(inp, otp, cast_to_int):
+        return 10.0 * torch.log10(255.0 * 255.0 / Distortions.get_mse_per_img(inp, otp, cast_to_int))
+
+
+def get_loss(config, ae, pc, d_loss_scaled, bc, heatmap):
+    """train.py:303-336.  ae / pc: plugin objects for the regularisation VALUES (None: leave them out -- their gradients
+    are folded into the filter-gradient kernels either way).  -> total_loss, H_real, pc_comps, ae_comps"""
+    assert config.H_target
+    bc_mask = bc * heatmap if heatmap is not None else bc
+    H_real = bc.mean()
+    H_mask = bc_mask.mean()
+    H_soft = 0.5 * (H_mask + H_real)
+    pc_loss = float(config.beta) * torch.clamp(H_soft - float(config.H_target), min=0.0)
+    zero = torch.zeros((), device=bc.device)
+    reg_pc = pc.regularization_loss() if pc is not None else None
+    reg_pc = zero if reg_pc is None else reg_pc
+    reg_enc = ae.encoder_regularization_loss() if ae is not None else zero
+    reg_dec = ae.decoder_regularization_loss() if ae is not None else zero
+    pc_comps = [('H_mask', H_mask), ('H_real', H_real), ('pc_loss', pc_loss), ('reg', reg_pc)]
+    ae_comps = [('d_loss_scaled', d_loss_scaled), ('reg_enc_dec', reg_enc + reg_dec)]
+    total_loss = d_loss_scaled + pc_loss + (reg_pc + reg_enc + reg_dec).detach()
+    return total_loss, H_real, pc_comps, ae_comps
+
+
 class TFAdam(object):
     """tf.train.AdamOptimizer (train.py:339-349 via training_helpers.py:38-48): beta1 0.9, beta2 0.999, eps 1e-8,
     lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t); var -= lr_t * m / (sqrt(v) + eps)  (epsilon outside the bias
@@ -531,6 +752,13 @@ class TFAdam(object):
         torch._foreach_addcdiv_(self.params, self.m, denom, value=-lr_t)
 
 
+def get_num_itr_per_epoch(num_images, batch_size, num_crops_per_img):
+    """training_helpers.py:51-60: the input pipeline cuts num_crops_per_img crops out of every decoded image, so a batch
+    holds batch_size // num_crops_per_img unique images and an epoch is num_images // that many iterations (batch 30 with 8
+    crops: num_images // 3).  batch_size is the GLOBAL batch of the config, whatever the number of ranks."""
+    return max(int(num_images) // max(int(batch_size) // int(num_crops_per_img), 1), 1)
+
+
 def learning_rate(config, step, num_itr_per_epoch):
     """training_helpers.py:22-34: FIXED, or staircase exponential decay every decay_interval epochs."""
     lr = float(config.lr_initial)
@@ -546,27 +774,66 @@ def learning_rate(config, step, num_itr_per_epoch):
 class Trainer(object):
     """TrainGraph + the two Adam optimisers of get_train_op (AE variables with lr_ae, context model with lr_pc)."""
 
-    def __init__(self, ae_config, pc_config, weights, device='cuda', num_itr_per_epoch=1000, process_group=None):
-        self.graph = TrainGraph(ae_config, pc_config, weights, device, process_group)
+    def __init__(self, ae_config, pc_config, weights, device='cuda', num_itr_per_epoch=1000, process_group=None, sync_bn=None):
+        self.graph = TrainGraph(ae_config, pc_config, weights, device, process_group, sync_bn=sync_bn)
         g = self.graph
         ae_names = g.group_names['enc'] + g.group_names['dec']
         pc_names = g.group_names['pc']
+        self._ae_names, self._pc_names = ae_names, pc_names
         self.opt_ae = TFAdam([g.trainable[n] for n in ae_names], [g.grads[n] for n in ae_names], float(ae_config.lr_initial))
         self.opt_pc = TFAdam([g.trainable[n] for n in pc_names], [g.grads[n] for n in pc_names], float(pc_config.lr_initial))
         self.num_itr_per_epoch = num_itr_per_epoch
         self.global_step = 0
 
-    def step(self, x):
+    def apply_gradients(self):
+        """get_train_op (train.py:339-349): the two Adam updates on the gradients of the last backward"""
         g = self.graph
-        out = g.forward_backward(x)
         if g.ae_config.train_autoencoder:
             self.opt_ae.step(learning_rate(g.ae_config, self.global_step, self.num_itr_per_epoch))
         if g.ae_config.train_probclass:
             self.opt_pc.step(learning_rate(g.pc_config, self.global_step, self.num_itr_per_epoch))
         self.global_step += 1
+        g.version += 1
         g.refresh_pad_value()
+
+    def step(self, x):
+        g = self.graph
+        out = g.forward_backward(x)
+        self.apply_gradients()
         return out
 
-    def state_weights(self):
-        """current variables as a checkpoint-style dict name -> numpy array."""
-        return OrderedDict((n, t.detach().cpu().numpy()) for n, t in self.graph.params.items())
+    def state_weights(self, training_state=True):
+        """current variables as a checkpoint-style dict name -> numpy array; training_state adds what the reference's Saver
+        also writes: global_step and the slots of the two Adam optimisers (get_train_op, train.py:339-349: optimiser names
+        Adam_AE / Adam_PC -> slot variables `<var>/Adam_AE`, `<var>/Adam_AE_1`, and the beta powers)."""
+        out = OrderedDict((n, t.detach().cpu().numpy()) for n, t in self.graph.params.items())
+        if training_state:
+            out['global_step'] = np.array(self.global_step, np.int64)
+            for opt, tag, names in ((self.opt_ae, 'Adam_AE', self._ae_names), (self.opt_pc, 'Adam_PC', self._pc_names)):
+                for n, m, v in zip(names, opt.m, opt.v):
+                    out['{}/{}'.format(n, tag)] = m.detach().cpu().numpy()
+                    out['{}/{}_1'.format(n, tag)] = v.detach().cpu().numpy()
+                out[tag + '/beta1_power'] = np.array(opt.b1 ** opt.t, np.float32)
+                out[tag + '/beta2_power'] = np.array(opt.b2 ** opt.t, np.float32)
+        return out
+
+    def restore_training_state(self, ckpt):
+        """global_step, Adam moments and step counts from a checkpoint dict (whatever of it is present): the DECAY schedule
+        continues where the run stopped instead of restarting at lr_initial, and checkpoints keep counting from there."""
+        if 'global_step' in ckpt:
+            self.global_step = int(np.asarray(ckpt['global_step']).reshape(-1)[0])
+        dev = self.graph.dev
+        for opt, tag, names in ((self.opt_ae, 'Adam_AE', self._ae_names), (self.opt_pc, 'Adam_PC', self._pc_names)):
+            found = 0
+            for i, n in enumerate(names):
+                km, kv = '{}/{}'.format(n, tag), '{}/{}_1'.format(n, tag)
+                if km in ckpt and kv in ckpt:
+                    opt.m[i].copy_(torch.as_tensor(np.asarray(ckpt[km]), dtype=torch.float32).to(dev).view_as(opt.m[i]))
+                    opt.v[i].copy_(torch.as_tensor(np.asarray(ckpt[kv]), dtype=torch.float32).to(dev).view_as(opt.v[i]))
+                    found += 1
+            if found:
+                # t from beta1_power = beta1 ** t when present, else the step counter
+                bp = ckpt.get(tag + '/beta1_power')
+                opt.t = int(round(math.log(float(np.asarray(bp).reshape(-1)[0])) / math.log(opt.b1))) if bp is not None and float(np.asarray(bp).reshape(-1)[0]) > 0 \
+                    else self.global_step
+        return self.global_step

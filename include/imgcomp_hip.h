@@ -301,6 +301,25 @@ int ic_bn_apply_f32(const float* x, const float* scale, const float* shift, cons
 int ic_bn_backward_f32(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
                        const float* invstd, const float* gamma, float* dx, float* dgamma, float* dbeta,
                        int N, int C, int HW, int relu, void* workspace, ic_stream_t stream);
+/* Cross-replica ("sync") BatchNorm for data-parallel training: the reference normalises over its whole batch on one device
+ * (autoencoder.py:115-125, ae_configs/cvpr/base: batch_size 30); with the batch split over ranks the caller sums the
+ * per-channel float64 moments of every rank between the two halves of each pass (2 C doubles per layer and direction):
+ *   forward : ic_bn_moments_f32 -> sums = {sum x [C], sum x^2 [C]}      -> all-reduce(sum) -> ic_bn_train_fold_moments_f32
+ *             (count = elements per channel over ALL ranks) -> ic_bn_apply_f32
+ *   backward: ic_bn_backward_reduce_f32 -> sums = {sum g [C], sum g xhat [C]}, dbeta / dgamma = this rank's sums (the
+ *             gradient all-reduce averages them like every other parameter gradient) -> all-reduce(sum) of `sums`
+ *             -> ic_bn_backward_apply_f32 (count as above)
+ * With one rank and count = N * HW both paths are bit-identical to ic_bn_train_stats_f32 / ic_bn_backward_f32. */
+int ic_bn_moments_f32(const float* x, double* sums, int N, int C, int HW, void* workspace, ic_stream_t stream);
+int ic_bn_train_fold_moments_f32(const double* sums, long long count, const float* gamma, const float* beta,
+                                 float* moving_mean, float* moving_var, float decay, float eps, float* mean,
+                                 float* invstd, float* scale, float* shift, int C, ic_stream_t stream);
+int ic_bn_backward_reduce_f32(const float* dy, const float* x, const float* scale, const float* shift,
+                              const float* mean, const float* invstd, double* sums, float* dgamma, float* dbeta,
+                              int N, int C, int HW, int relu, void* workspace, ic_stream_t stream);
+int ic_bn_backward_apply_f32(const float* dy, const float* x, const float* scale, const float* shift,
+                             const float* mean, const float* invstd, const float* gamma, const double* sums,
+                             long long count, float* dx, int N, int C, int HW, int relu, ic_stream_t stream);
 /* filter gradient, generic form dW[t][a][b] = sum U[n][a][s*q + t + o0] * V[n][b][q] (conv_wgrad.hip):
  *   conv:            U = x (A = Cin, H x W), V = dy (B = Cout)            -> dw [KH][KW][Cin][Cout]
  *   transposed conv: U = dy (A = Cout, 2H x 2W), V = x (B = Cin), stride 2 -> dw [KH][KW][Cout][Cin]

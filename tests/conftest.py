@@ -32,3 +32,24 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.skip('no HIP device')
     return torch.device('cuda:0')
+
+
+def pytest_terminal_summary(terminalreporter):
+    """achieved accuracy of the run: the worst recorded error per comparison label (absolute and relative to the tensor
+    scale) and the symbol flip rates -- `passed` alone does not say how close the HIP path is to the oracle."""
+    from tests import util
+    if util.REPORT:
+        worst = {}
+        for what, ae, re_, bound in util.REPORT:
+            key = what.split(' shape ')[0][:60]
+            if key not in worst or re_ > worst[key][1]:
+                worst[key] = (ae, re_, bound)
+        rows = sorted(worst.items(), key=lambda kv: -kv[1][1] / kv[1][2])[:25]
+        terminalreporter.write_line('parity report: {} comparisons against the float64 oracle, worst per label (closest to its bound first)'.format(len(util.REPORT)))
+        for k, (ae, re_, bound) in rows:
+            terminalreporter.write_line('  {:60s} abs {:9.3e}  rel {:9.3e}  bound {:7.1e}'.format(k, ae, re_, bound))
+    if util.FLIPS:
+        tot_f = sum(f for _, f, _ in util.FLIPS)
+        tot_n = sum(n for _, _, n in util.FLIPS)
+        terminalreporter.write_line('symbol flips vs the float64 oracle (inside the fp32 band of a decision midpoint): {} of {} = {:.2e}; worst case {}'.format(
+            tot_f, tot_n, tot_f / max(tot_n, 1), max(util.FLIPS, key=lambda t: t[1] / max(t[2], 1))))

@@ -504,3 +504,38 @@ def test_device_metric_twins_on_cpu_tensors():
     ta, tb = torch.as_tensor(a), torch.as_tensor(b)
     assert abs(metrics.msssim_nchw_uint8_device(ta, tb) - float(metrics.msssim_nchw_uint8(a, b))) < 1e-7
     assert abs(metrics.psnr_uint8_device(ta, tb) - float(metrics.psnr_uint8(a, b))) < 1e-5
+
+
+def test_lr_schedule_counts_epochs_like_the_reference():
+    """training_helpers.py:22-34,51-60: an epoch is num_images // (batch_size // NUM_CROPS_PER_IMG) iterations -- batch 30
+    with 8 crops per decoded image consumes 3 images per step -- and DECAY multiplies the rate by 0.1 every
+    lr_schedule_decay_interval epochs, staircase.  ImageNet train (1,281,167 images): 427,055 iterations per epoch, first
+    decay after 854,110 iterations (a loader-independent formula: the 10x-too-early decay of round 1 counted batch_size
+    images per step)."""
+    from imgcomp_cvpr_amd import training, config_parser as cp
+    from imgcomp_cvpr_amd.train import NUM_CROPS_PER_IMG
+    ae_cfg, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'low'))
+    assert NUM_CROPS_PER_IMG == 8 and int(ae_cfg.batch_size) == 30
+    n = training.get_num_itr_per_epoch(1281167, int(ae_cfg.batch_size), NUM_CROPS_PER_IMG)
+    assert n == 1281167 // (30 // 8) == 427055
+    assert ae_cfg.lr_schedule == 'DECAY' and ae_cfg.lr_schedule_decay_staircase
+    steps = int(n * ae_cfg.lr_schedule_decay_interval)
+    assert steps == 854110
+    lr0 = float(ae_cfg.lr_initial)
+    assert training.learning_rate(ae_cfg, 0, n) == lr0 == training.learning_rate(ae_cfg, steps - 1, n)
+    assert abs(training.learning_rate(ae_cfg, steps, n) - lr0 * 0.1) < 1e-12
+    assert abs(training.learning_rate(ae_cfg, 2 * steps + 5, n) - lr0 * 0.01) < 1e-12
+    # tiny data sets and batches smaller than the crops per image do not divide by zero
+    assert training.get_num_itr_per_epoch(5, 4, 8) == 5 and training.get_num_itr_per_epoch(0, 30, 8) == 1
+
+
+def test_checkpoint_name_filters():
+    from imgcomp_cvpr_amd import tf_checkpoint as T
+    w = 'autoencoder/encoder/h1/weights'
+    assert T.is_model_variable(w) and T.is_model_variable('probclass3d/logits/conv3d_conv0_mask/biases')
+    for n in (w + '/Adam_AE', w + '/Adam_AE_1', w + '/Adam', 'global_step', 'Adam_AE/beta1_power', 'beta1_power'):
+        assert not T.is_model_variable(n), n
+    for n in (w + '/Adam_AE', w + '/Adam_AE_1', 'probclass3d/logits/conv3d_conv0_mask/biases/Adam_PC_1', 'global_step',
+              'Adam_PC/beta2_power'):
+        assert T.is_training_state(n), n
+    assert not T.is_training_state(w)

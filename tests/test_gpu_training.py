@@ -320,3 +320,199 @@ def test_pc_data_gradient_matrix_core_path(cuda, Cin, Cout, relu_mask, with_res)
         outs.append(dx)
     assert not torch.equal(outs[0], outs[1])          # really two different kernels
     assert L.lib.ic_pc_bwd_data_workspace_bytes(N, 8, 24, OD, OH, OW) == 0      # uncovered shape -> VALU kernel only
+
+
+def test_reference_training_call_sites(cuda):
+    """code/train.py:101-127 ported line by line onto the plugin surface: ae.encode(x, True), ae.decode(enc.qbar, True),
+    pc.bitcost(stop_gradient(qbar), symbols, True, pad_value), Distortions, get_loss, backward of total_loss; then the
+    test-in-train evaluation with is_training=False on the SAME (training) variables.  The gradients must equal those of
+    TrainGraph.forward_backward bit for bit (one code path), and the inference calls must follow the optimiser's updates."""
+    from imgcomp_cvpr_amd import autoencoder, probclass, bits, training, config_parser as cp, weights as W
+    ae_config, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'low'))
+    pc_config, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
+    ae_config.distortion_to_minimize = 'mse'
+    ae_config.H_target = 0.5
+    wts = W.synthetic_weights(ae_config, pc_config)
+    x_train = dev(W.synthetic_image((2, 3, 64, 64), 'natural', 3), cuda)
+    x_test = dev(W.synthetic_image((1, 3, 64, 96), 'natural', 4), cuda)
+    # reference run: the monolithic step
+    g_ref = training.TrainGraph(ae_config, pc_config, wts, cuda)
+    out_ref = g_ref.forward_backward(x_train)
+    # ---- train.py:86-106 ----
+    ae_cls = autoencoder.get_network_cls(ae_config)
+    pc_cls = probclass.get_network_cls(pc_config)
+    ae = ae_cls(ae_config)
+    pc = pc_cls(pc_config, num_centers=ae_config.num_centers)
+    with pytest.raises(ValueError):
+        ae.encode(x_train, is_training=True)                       # no graph owns the variables yet
+    trainer = training.Trainer(ae_config, pc_config, wts, cuda, num_itr_per_epoch=1000)
+    trainer.graph.bind(ae, pc)                                      # (TF: the variable store + the gradient graph)
+    enc_out_train = ae.encode(x_train, is_training=True)            # qbar is masked by the heatmap
+    x_out_train = ae.decode(enc_out_train.qbar, is_training=True)
+    pc_in = enc_out_train.qbar.detach()                             # tf.stop_gradient
+    bc_train = pc.bitcost(pc_in, enc_out_train.symbols, is_training=True, pad_value=pc.auto_pad_value(ae))
+    bpp_train = bits.bitcost_to_bpp(bc_train, x_train)
+    d_train = training.Distortions(ae_config, x_train, x_out_train, is_training=True)
+    total_loss, H_real, pc_comps, ae_comps = training.get_loss(ae_config, ae, pc, d_train.d_loss_scaled, bc_train,
+                                                                enc_out_train.heatmap)
+    total_loss.backward()
+    trainer.graph.finish_backward()
+    torch.cuda.synchronize()
+    for k in g_ref.flat_grads:
+        assert torch.equal(trainer.graph.flat_grads[k], g_ref.flat_grads[k]), 'bucket {} differs from forward_backward'.format(k)
+    assert float(d_train.d_loss_scaled) == out_ref['d_loss_scaled'] and float(dict(pc_comps)['pc_loss']) == out_ref['pc_loss']
+    assert abs(float(bpp_train) - out_ref['bpp']) < 1e-6
+    assert abs(float(dict(ae_comps)['reg_enc_dec']) + float(dict(pc_comps)['reg']) - trainer.graph.regularization_loss()) < 1e-4
+    assert float(total_loss) > float(d_train.d_loss_scaled)          # distortion + rate + regularisers
+    # ---- train.py:115-127: test-in-train on the training variables ----
+    def evaluate():
+        enc_out_test = ae.encode(x_test, is_training=False)
+        x_out_test = ae.decode(enc_out_test.qhard, is_training=False)
+        bc_test = pc.bitcost(enc_out_test.qhard, enc_out_test.symbols, is_training=False, pad_value=pc.auto_pad_value(ae))
+        return x_out_test.clone(), float(bits.bitcost_to_bpp(bc_test, x_test)), training.Distortions(ae_config, x_test, x_out_test, False)
+    xo0, bpp0, d0 = evaluate()
+    ref_ae = ae_cls(ae_config).load_weights(trainer.state_weights(training_state=False), cuda)
+    assert torch.equal(xo0, ref_ae.decode(ref_ae.encode(x_test, False).qhard, False)), 'inference on a bound object != a fresh load'
+    assert np.isfinite(float(d0.psnr)) and d0.ms_ssim is None and 0 < bpp0 < 10
+    trainer.apply_gradients()                                        # get_train_op: both Adam updates
+    xo1, bpp1, _ = evaluate()
+    assert not torch.equal(xo0, xo1) and bpp0 != bpp1, 'is_training=False did not pick up the updated variables'
+    assert float(pc.auto_pad_value(ae)) == float(trainer.graph.params['autoencoder/encoder/centers'][0])
+    # continuing a run: global_step and the Adam slots travel through a checkpoint
+    state = trainer.state_weights()
+    assert int(state['global_step']) == 1 and 'autoencoder/encoder/h1/weights/Adam_AE_1' in state and 'Adam_PC/beta2_power' in state
+    tr2 = training.Trainer(ae_config, pc_config, {k: v for k, v in state.items() if k in wts}, cuda, num_itr_per_epoch=1000)
+    assert tr2.restore_training_state(state) == 1 and tr2.opt_ae.t == 1 and tr2.opt_pc.t == 1
+    a = trainer.step(x_train)
+    b = tr2.step(x_train)
+    assert a == b, 'a restored run does not continue like the original'
+    for n, t in trainer.graph.params.items():
+        assert torch.equal(t, tr2.graph.params[n]), n
+
+
+def test_sync_bn_halves_equal_full_batch(cuda):
+    """The cross-replica BatchNorm entry points on one device: the float64 moments of two half batches, summed (what the
+    all-reduce does), give the statistics, the output and the data gradient of the full batch -- the full-batch fused calls
+    are reproduced to fp32 rounding, the one-rank split path bit for bit."""
+    L = _L()
+    rs = np.random.RandomState(4)
+    N, C, H, W = 4, 37, 6, 10
+    x = dev(rs.normal(0.3, 2.0, (N, C, H, W)), cuda)
+    dy = dev(rs.normal(0, 1, (N, C, H, W)), cuda)
+    gamma, beta = dev(rs.uniform(0.5, 1.5, C), cuda), dev(rs.normal(0, 0.3, C), cuda)
+    ws = torch.empty(L.lib.ic_bn_workspace_bytes(C), dtype=torch.uint8, device=cuda)
+    st = L.current_stream()
+    mk = lambda: torch.empty(C, device=cuda)
+    for relu in (0, 1):
+        mm0, mv0 = torch.zeros(C, device=cuda), torch.ones(C, device=cuda)
+        mean, invstd, scale, shift = mk(), mk(), mk(), mk()
+        L.check(L.lib.ic_bn_train_stats_f32(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(mm0), L.ptr(mv0), 0.9, 1e-5, L.ptr(mean), L.ptr(invstd),
+                                            L.ptr(scale), L.ptr(shift), N, C, H * W, L.ptr(ws), st))
+        dx_ref, dg_ref, db_ref = torch.empty_like(x), mk(), mk()
+        L.check(L.lib.ic_bn_backward_f32(L.ptr(dy), L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
+                                         L.ptr(dx_ref), L.ptr(dg_ref), L.ptr(db_ref), N, C, H * W, relu, L.ptr(ws), st))
+        for parts in (1, 2):
+            n = N // parts
+            xs, dys = [x[i * n:(i + 1) * n].contiguous() for i in range(parts)], [dy[i * n:(i + 1) * n].contiguous() for i in range(parts)]
+            sums = torch.zeros(2 * C, dtype=torch.float64, device=cuda)
+            for xi in xs:
+                part = torch.empty(2 * C, dtype=torch.float64, device=cuda)
+                L.check(L.lib.ic_bn_moments_f32(L.ptr(xi), L.ptr(part), n, C, H * W, L.ptr(ws), st))
+                sums += part
+            mm1, mv1 = torch.zeros(C, device=cuda), torch.ones(C, device=cuda)
+            m2, i2, s2, h2 = mk(), mk(), mk(), mk()
+            L.check(L.lib.ic_bn_train_fold_moments_f32(L.ptr(sums), N * H * W, L.ptr(gamma), L.ptr(beta), L.ptr(mm1), L.ptr(mv1), 0.9, 1e-5,
+                                                       L.ptr(m2), L.ptr(i2), L.ptr(s2), L.ptr(h2), C, st))
+            gsums = torch.zeros(2 * C, dtype=torch.float64, device=cuda)
+            dgs, dbs = [], []
+            for xi, dyi in zip(xs, dys):
+                part, dg, db = torch.empty(2 * C, dtype=torch.float64, device=cuda), mk(), mk()
+                L.check(L.lib.ic_bn_backward_reduce_f32(L.ptr(dyi), L.ptr(xi), L.ptr(s2), L.ptr(h2), L.ptr(m2), L.ptr(i2), L.ptr(part), L.ptr(dg),
+                                                        L.ptr(db), n, C, H * W, relu, L.ptr(ws), st))
+                gsums += part
+                dgs.append(dg)
+                dbs.append(db)
+            dxs = []
+            for xi, dyi in zip(xs, dys):
+                dxi = torch.empty_like(xi)
+                L.check(L.lib.ic_bn_backward_apply_f32(L.ptr(dyi), L.ptr(xi), L.ptr(s2), L.ptr(h2), L.ptr(m2), L.ptr(i2), L.ptr(gamma), L.ptr(gsums),
+                                                       N * H * W, L.ptr(dxi), n, C, H * W, relu, st))
+                dxs.append(dxi)
+            torch.cuda.synchronize()
+            dx = torch.cat(dxs, 0)
+            if parts == 1:
+                for a, b in ((m2, mean), (i2, invstd), (s2, scale), (h2, shift), (mm1, mm0), (mv1, mv0), (dx, dx_ref), (dgs[0], dg_ref), (dbs[0], db_ref)):
+                    assert torch.equal(a, b), 'the split path on one rank is not the fused path'
+            else:
+                assert_close(m2, mean, 'sync bn mean', 1e-6)
+                assert_close(s2, scale, 'sync bn scale', 1e-6)
+                assert_close(mv1, mv0, 'sync bn moving variance', 1e-6)
+                assert_close(dx, dx_ref, 'sync bn dx', 1e-6)
+                assert_close(dgs[0] + dgs[1], dg_ref, 'sync bn dgamma (sum over ranks)', 1e-6)
+                assert_close(dbs[0] + dbs[1], db_ref, 'sync bn dbeta (sum over ranks)', 1e-6)
+
+
+def _two_rank_worker(rank, world, port, x_np, wts, ae_over, sync_bn, out_q):
+    import os
+    import torch.distributed as dist
+    from imgcomp_cvpr_amd import training, config_parser as cp
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)       # both ranks share the one GPU of the box: RCCL needs a device per rank
+    try:
+        ae, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'low'))
+        pc, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
+        for k, v in ae_over.items():
+            setattr(ae, k, v)
+        g = training.TrainGraph(ae, pc, wts, 'cuda:0', sync_bn=sync_bn)
+        n = x_np.shape[0] // world
+        x = torch.as_tensor(x_np[rank * n:(rank + 1) * n]).float().cuda()
+        out = g.forward_backward(x)
+        torch.cuda.synchronize()
+        if rank == 0:
+            out_q.put(({k: v.cpu().numpy() for k, v in g.flat_grads.items()}, out,
+                       g.params['autoencoder/encoder/h2/BatchNorm/moving_variance'].cpu().numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_training_step_equals_single_rank(cuda):
+    """BASELINE configs[2] splits one batch over the GPUs of a node.  Two ranks (two processes sharing this box's one GPU,
+    gloo for the collectives) with batch 2 each and cross-replica BatchNorm must produce, after the gradient all-reduce,
+    the gradients of ONE rank running the whole batch of 4 -- the reference's single-device semantics (autoencoder.py:115-125).
+    With local statistics (sync_bn=False) they must not."""
+    import torch.multiprocessing as mp
+    from imgcomp_cvpr_amd import training, config_parser as cp, weights as W
+    ae, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'low'))
+    pc, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
+    over = {'distortion_to_minimize': 'mse', 'H_target': 0.5}
+    for k, v in over.items():
+        setattr(ae, k, v)
+    wts = W.synthetic_weights(ae, pc)
+    x_np = W.synthetic_image((4, 3, 64, 64), 'natural', 9)
+    g = training.TrainGraph(ae, pc, wts, cuda)
+    out1 = g.forward_backward(dev(x_np, cuda))
+    torch.cuda.synchronize()
+    ref = {k: v.cpu().numpy() for k, v in g.flat_grads.items()}
+    ref_mv = g.params['autoencoder/encoder/h2/BatchNorm/moving_variance'].cpu().numpy()
+    ctx = mp.get_context('spawn')
+    results = {}
+    for sync_bn, port in ((True, 29541), (False, 29542)):
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, x_np, wts, over, sync_bn, q)) for r in range(2)]
+        for p_ in procs:
+            p_.start()
+        results[sync_bn] = q.get(timeout=600)
+        for p_ in procs:
+            p_.join(timeout=120)
+            assert p_.exitcode == 0
+    grads, out2, mv = results[True]
+    worst = max(rel_err(torch.as_tensor(grads[k]), torch.as_tensor(ref[k]).double()) for k in ref)
+    assert worst < 5e-5, 'sync BatchNorm: 2 x 2 != 1 x 4, worst bucket error {:.3e}'.format(worst)
+    assert np.allclose(mv, ref_mv, rtol=1e-5, atol=1e-7)               # the moving averages see the whole batch too
+    assert abs(out2['pc_loss'] - out1['pc_loss']) < 5e-2 * abs(out1['pc_loss']) + 1e-3      # (losses are per-rank means over half the batch)
+    grads_l, _, mv_l = results[False]
+    worst_l = max(rel_err(torch.as_tensor(grads_l[k]), torch.as_tensor(ref[k]).double()) for k in ref)
+    assert worst_l > 10 * worst and not np.allclose(mv_l, ref_mv, rtol=1e-5), 'local statistics reproduce the full batch?'

@@ -2,9 +2,16 @@
 import numpy as np
 import torch
 
-# Parity bar (BASELINE.json north_star: "within 1e-4 fp32"): the HIP result must agree with the float64
-# evaluation of the oracle to 1e-4 relative to the tensor's scale, max(1, max|ref|).
-RTOL = 1e-4
+# Parity bar.  BASELINE.json north_star asks for "within 1e-4 fp32"; the kernels achieve far better, and an assert with
+# 10-100x of slack would hide a regression, so the default bound is what is measured with a 2x margin: the HIP result
+# must agree with the float64 evaluation of the oracle to 2e-5 relative to the tensor's scale, max(1, max|ref|)
+# (round-2 GPU runs: single ops <= 3e-6, whole-network z / x_out / bit cost <= 1e-5).  Every comparison is recorded --
+# absolute and relative maximum error -- and printed in the terminal summary (tests/conftest.py), so the log of a run shows
+# the achieved accuracy, not just "passed".
+RTOL = 2e-5
+NORTH_STAR_RTOL = 1e-4
+REPORT = []          # (label, max abs error, relative error, bound)
+FLIPS = []           # (label, flipped symbols, total symbols)
 
 
 def rel_err(got, ref64):
@@ -15,10 +22,26 @@ def rel_err(got, ref64):
     return float((got - ref64).abs().max()) / scale
 
 
+def abs_err(got, ref64):
+    got = got.detach().double().cpu() if torch.is_tensor(got) else torch.as_tensor(got).double()
+    ref64 = ref64.detach().double().cpu() if torch.is_tensor(ref64) else torch.as_tensor(ref64).double()
+    return float((got - ref64).abs().max())
+
+
 def assert_close(got, ref64, what, rtol=RTOL):
     e = rel_err(got, ref64)
-    assert e <= rtol, '{}: max error {:.3e} (relative to tensor scale) exceeds {:.1e}'.format(what, e, rtol)
+    REPORT.append((what, abs_err(got, ref64), e, rtol))
+    assert e <= rtol, '{}: max error {:.3e} (relative to tensor scale; absolute {:.3e}) exceeds {:.1e}'.format(
+        what, e, REPORT[-1][1], rtol)
     return e
+
+
+def record_flips(what, flips):
+    """symbol flips between the fp32 device path and the float64 oracle (they are only legitimate inside the fp32 error band
+    of a quantiser decision midpoint); the rate goes into the terminal summary."""
+    flips = np.asarray(flips)
+    FLIPS.append((what, int(flips.sum()), int(flips.size)))
+    return float(flips.mean())
 
 
 def dev(a, device, dtype=torch.float32):
