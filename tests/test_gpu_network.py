@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import assert_close, dev, rel_err, record_flips, RTOL
+from tests.util import assert_close, dev, rel_err, record_flips, RTOL, NET_RTOL, HEATMAP_RTOL
 
 pytestmark = pytest.mark.gpu
 
@@ -50,8 +50,8 @@ def test_encode_matches_oracle(cuda, configs, syn_weights, nets, shape, kind, al
     torch.cuda.synchronize()
     ref = O.encode(torch.as_tensor(x).double(), syn_weights, ae_cfg.as_dict())
     assert enc.symbols.dtype == torch.int64 and enc.symbols.shape == ref.symbols.shape
-    assert_close(enc.heatmap, ref.heatmap, 'heatmap')
-    assert_close(enc.z, ref.z, 'z')
+    assert_close(enc.heatmap, ref.heatmap, 'heatmap', HEATMAP_RTOL)
+    assert_close(enc.z, ref.z, 'z', NET_RTOL)
     # symbols: bit-exact wherever z is not within the fp32 error band of a decision midpoint
     centers = syn_weights['autoencoder/encoder/centers']
     zerr = float((enc.z.double().cpu() - ref.z).abs().max())
@@ -79,7 +79,7 @@ def test_decode_matches_oracle(cuda, configs, syn_weights, nets, shape, algo):
     torch.cuda.synchronize()
     ref = O.decode(torch.as_tensor(q).double(), syn_weights, ae_cfg.as_dict())
     assert float(x_out.min()) >= 0 and float(x_out.max()) <= 255
-    assert_close(x_out, ref, 'decoded RGB')
+    assert_close(x_out, ref, 'decoded RGB', NET_RTOL)
     # uint8 truncation (val.py:91) can differ only where the float64 value sits on an integer boundary
     u_hip = x_out.to(torch.uint8).cpu()
     u_ref = ref.to(torch.uint8)
@@ -106,10 +106,10 @@ def test_val_wiring(cuda, configs, syn_weights, nets, algo):
     q = torch.as_tensor(centers)[sym].double()
     assert torch.equal(q.float(), enc.qhard.cpu())
     rb, _ = O.bitcost(q, sym, syn_weights, float(centers[0]))
-    assert_close(bc, rb, 'bit cost')
+    assert_close(bc, rb, 'bit cost', NET_RTOL)
     assert abs(bpp - O.bitcost_to_bpp(rb, torch.as_tensor(x))) < 1e-4
     ref_out = O.decode(q, syn_weights, ae_cfg.as_dict())
-    assert_close(x_out, ref_out, 'x_out')
+    assert_close(x_out, ref_out, 'x_out', NET_RTOL)
     # val.py:174 invariant: bitcost from symbols alone == bitcost from the encoder's qbar
     # (qbar = qsoft + (qhard - qsoft) equals qhard only up to fp32 rounding, so: close, not identical)
     bc2 = pc.bitcost(dev(q.float().numpy(), cuda), enc.symbols, False, pad_value=float(centers[0]))
@@ -279,8 +279,8 @@ def test_high_rate_config_matches_oracle(cuda):
     enc = ae.encode(xd, False)
     assert tuple(enc.symbols.shape) == (1, 64, 6, 10)
     ref = O.encode(torch.as_tensor(x).double(), wts, ae_cfg.as_dict())
-    assert_close(enc.z, ref.z, 'z (hi)')
-    assert_close(enc.heatmap, ref.heatmap, 'heatmap (hi)')
+    assert_close(enc.z, ref.z, 'z (hi)', NET_RTOL)
+    assert_close(enc.heatmap, ref.heatmap, 'heatmap (hi)', HEATMAP_RTOL)
     assert record_flips('hi + res_shallow_64', (enc.symbols.cpu() != ref.symbols).numpy()) < 2e-3
     x_out = ae.decode(enc.qhard, False)
     bc = pc.bitcost(enc.qbar, enc.symbols, False, pad_value=pc.auto_pad_value(ae))
@@ -288,8 +288,8 @@ def test_high_rate_config_matches_oracle(cuda):
     centers = wts['autoencoder/encoder/centers']
     q = torch.as_tensor(centers)[sym].double()
     rb, _ = O.bitcost(q, sym, wts, float(centers[0]))
-    assert_close(bc, rb, 'bit cost (hi, k = 64)')
-    assert_close(x_out, O.decode(q, wts, ae_cfg.as_dict()), 'x_out (hi)')
+    assert_close(bc, rb, 'bit cost (hi, k = 64)', NET_RTOL)
+    assert_close(x_out, O.decode(q, wts, ae_cfg.as_dict()), 'x_out (hi)', NET_RTOL)
     assert abs(float(bits.bitcost_to_bpp(bc, xd)) - O.bitcost_to_bpp(rb, torch.as_tensor(x))) < 1e-4
 
 
@@ -316,15 +316,15 @@ def test_against_frozen_oracle_fixture(cuda, configs, syn_weights, nets):
     x = W.synthetic_image((1, 3, 64, 96), 'natural', seed=3)
     xd = dev(x, cuda)
     enc = ae.encode(xd, False)
-    assert_close(enc.z, torch.as_tensor(g['z']), 'z vs fixture')
-    assert_close(enc.heatmap, torch.as_tensor(g['heatmap']), 'heatmap vs fixture')
+    assert_close(enc.z, torch.as_tensor(g['z']), 'z vs fixture', NET_RTOL)
+    assert_close(enc.heatmap, torch.as_tensor(g['heatmap']), 'heatmap vs fixture', HEATMAP_RTOL)
     flips = enc.symbols.cpu().numpy() != g['symbols']
     assert record_flips('frozen fixture', flips) < 2e-3
     if not flips.any():                                   # same symbols -> the rest is comparable element-wise
         bc = pc.bitcost(enc.qbar, enc.symbols, False, pad_value=pc.auto_pad_value(ae))
-        assert_close(bc, torch.as_tensor(g['bitcost']), 'bit cost vs fixture')
+        assert_close(bc, torch.as_tensor(g['bitcost']), 'bit cost vs fixture', NET_RTOL)
         assert abs(float(bits.bitcost_to_bpp(bc, xd)) - float(g['bpp'])) < 1e-4
-        assert_close(ae.decode(enc.qhard, False), torch.as_tensor(g['x_out']), 'x_out vs fixture')
+        assert_close(ae.decode(enc.qhard, False), torch.as_tensor(g['x_out']), 'x_out vs fixture', NET_RTOL)
 
 
 def test_branch_streams_cu_range(cuda, configs, syn_weights, nets):

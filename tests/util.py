@@ -8,7 +8,9 @@ import torch
 # (round-2 GPU runs: single ops <= 3e-6, whole-network z / x_out / bit cost <= 1e-5).  Every comparison is recorded --
 # absolute and relative maximum error -- and printed in the terminal summary (tests/conftest.py), so the log of a run shows
 # the achieved accuracy, not just "passed".
-RTOL = 2e-5
+RTOL = 2e-5                 # a single op
+NET_RTOL = 5e-5             # a whole network (35 layers deep): the errors of the layers add up (measured <= 2.7e-5)
+HEATMAP_RTOL = 1e-4         # heatmap = clip(sigmoid(z0) * C - c, 0, 1): amplifies the error of z0 by up to C / 4 (8 .. 16 x)
 NORTH_STAR_RTOL = 1e-4
 REPORT = []          # (label, max abs error, relative error, bound)
 FLIPS = []           # (label, flipped symbols, total symbols)
