@@ -69,6 +69,8 @@ PROTOTYPES = {
     'ic_heatmap_quantize_f32': (c_int, [c_void_p, c_void_p, c_int, c_float] + [c_void_p] * 6 +
                                 [c_int] * 4 + [c_void_p]),
     'ic_pc_workspace_bytes': (c_size_t, [c_int] * 5),
+    'ic_pc_packed_floats': (c_size_t, [c_int, c_int]),
+    'ic_pc_pack_filters_f32': (c_int, [POINTER(c_void_p), c_int, c_int, c_void_p, c_void_p]),
     'ic_pc_logits_f32': (c_int, [c_void_p, POINTER(c_void_p), c_int, c_int, c_float, c_void_p] +
                          [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),
     'ic_pc_logits_padded_f32': (c_int, [c_void_p, POINTER(c_void_p), c_int, c_int, c_void_p] +
@@ -162,7 +164,7 @@ def ptr_table(tensors):
     """host array of device pointers (keeps no reference: caller must keep tensors alive)."""
     arr = (c_void_p * len(tensors))()
     for i, t in enumerate(tensors):
-        arr[i] = t.data_ptr()
+        arr[i] = t.data_ptr() if t is not None else None
     return arr
 
 

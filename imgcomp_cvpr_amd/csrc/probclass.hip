@@ -261,13 +261,15 @@ void pc_mfma_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
             const int so = (int)((((size_t)(p / 2)) * cstride + (size_t)(p & 1) * HW) * 4);      // scalar: plane (ci, kd) of the chunk
             stv[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, loff, so, 0));
         }
-        // unpredicated writes (a predicate per write makes the compiler pair every load with its own wait + branch): the
-        // lanes past the plane write their zeros into the spare floats behind the brick
-        // unpredicated writes (a predicate per write makes the compiler pair every load with its own wait + exec-mask
-        // branch): the lanes past the plane put their zeros into the spare floats behind the brick
-        const int lw = tid < DS ? tid : CHUNK + (tid & 63), lstep = tid < DS ? DS : 0;
+        // ONE predicate around all the writes (a predicate per write made the compiler pair every load with its own wait +
+        // branch; an unpredicated form with a per-lane stride cost a vector multiply-add per write -- 48 per chunk, and
+        // vector instructions are paid in matrix-pipe time here): plane p of the brick goes to lds[p * DS + tid] through the
+        // instruction's immediate offset
+        asm volatile("" ::: "memory");
+        if (tid < DS) {
 #pragma unroll
-        for (int p = 0; p < 2 * KC; ++p) lds[lw + p * lstep] = stv[p];
+            for (int p = 0; p < 2 * KC; ++p) lds[tid + p * DS] = stv[p];
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         // B operands of tap g + 1 are read while the MFMAs of tap g run (left alone the compiler reads each one right before
@@ -321,32 +323,46 @@ void pc_mfma_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
     const int ovol = a.OD * a.OH * a.OW;
     const int v = (od * a.OH + (live ? oy : 0)) * a.OW + (live ? ox : 0);
     float val[16];
-    // one 64-bit base per tensor, then 32-bit channel steps (a channel plane is far below 2^31 elements)
-    const int co0 = 32 * cot + 4 * kh;
-    float* __restrict__ outp = FINAL ? nullptr : a.out + ((size_t)n * a.Cout + co0) * ovol + v;
+    // Bias, residual and output go through buffer descriptors, one per group of 8 channels (registers 4g .. 4g+3 of both
+    // half-waves): the channel is a SCALAR offset, a voxel outside the volume an out-of-range lane offset (loads return 0,
+    // stores are dropped), a group past Cout a wave-uniform skip -- no per-channel address arithmetic, compares or exec
+    // masks.  Every vector instruction here is paid in matrix-pipe time of the three other waves of the SIMD (PMC pass:
+    // 2.7 vector instructions per MFMA in the first version of this epilogue, 56 % MFMA utilisation).
     const int rvol = a.RD * a.RH * a.RW;
-    const float* __restrict__ resp = a.res ? a.res + ((size_t)n * a.Cout + co0) * rvol + (size_t)(od + 2) * a.RH * a.RW
-                                                 + (size_t)((live ? oy : 0) + 2) * a.RW + (live ? ox : 0) + 2 : nullptr;
-    // all bias / residual operands first, then the arithmetic and the stores: fetched inside the loop, each of the 16
-    // channels waits out its own L2 round trip (same finding as in the Winograd epilogue)
-    float bia[16], rsd[16];
-    const float* __restrict__ biasp = a.bias + co0;
+    const unsigned ovoff = live ? (unsigned)((4 * kh * ovol + v) * 4) : 0x80000000u;
+    const unsigned rvoff = live ? (unsigned)((4 * kh * rvol + (od + 2) * a.RH * a.RW + (oy + 2) * a.RW + ox + 2) * 4) : 0x80000000u;
+    const int cot_s = __builtin_amdgcn_readfirstlane(cot);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int cr = (r & 3) + 8 * (r >> 2);           // channel = co0 + cr
-        const bool cok = co0 + cr < a.Cout;
-        bia[r] = cok ? biasp[cr] : 0.f;
-        rsd[r] = (a.res && cok) ? resp[(unsigned)(cr * rvol)] : 0.f;
-    }
+    for (int g = 0; g < 4; ++g) {
+        const int c0 = 32 * cot_s + 8 * g;                       // first channel of the group (wave-uniform)
+        if (c0 >= a.Cout) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int cr = (r & 3) + 8 * (r >> 2);
-        const bool cok = co0 + cr < a.Cout;
-        float x = acc[r] + bia[r];
-        if (a.relu) x = fmaxf(x, 0.f);
-        if (a.res && cok) x += rsd[r];
-        val[r] = x;
-        if (!FINAL && cok && live) outp[(unsigned)(cr * ovol)] = x;
+            for (int i = 0; i < 4; ++i) val[4 * g + i] = 0.f;
+            continue;
+        }
+        const int nch = a.Cout - c0 < 8 ? a.Cout - c0 : 8;
+        const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bias + c0), 0, nch * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.res ? a.res + ((size_t)n * a.Cout + c0) * rvol : a.bias), 0, a.res ? nch * rvol * 4 : 0, 0x00020000);
+        float bia[4], rsd[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bia[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, (unsigned)(16 * kh), 4 * i, 0));
+            rsd[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, rvoff, i * rvol * 4, 0));
+        }
+        const float relu_lo = a.relu ? 0.f : -__builtin_inff();
+        if constexpr (!FINAL) {
+            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + ((size_t)n * a.Cout + c0) * ovol), 0, nch * ovol * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float x = fmaxf(acc[4 * g + i] + bia[i], relu_lo) + rsd[i];
+                val[4 * g + i] = x;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), yr, ovoff, i * ovol * 4, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) val[4 * g + i] = fmaxf(acc[4 * g + i] + bia[i], relu_lo) + rsd[i];
+        }
     }
     if (FINAL) {
         // logits of one voxel are split over the two half-waves (kh = 0: channels 0-3, 8-11, ...; kh = 1: 4-7, ...)
@@ -386,6 +402,173 @@ void pc_mfma_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Final layer (k -> L <= 16 logits + cross-entropy) on v_mfma_f32_16x16x4_f32: 16 output rows instead of 32 -- with L = 6
+// the 32-row form spends 26 of its 32 rows on padding, this one 10 of 16, half the matrix-pipe time (40 -> ~22 us on a
+// Kodak volume).  Same K order as pc_mfma_kernel (8-channel group, tap, ascending channel) and the same four partial
+// sums (p0 + p1) + (p2 + p3): an fp32 MFMA is an fmaf chain in k order, so the logits are bit-identical to the 32-row
+// form's (tests compare them) and to the sequential decoder's, which keeps the 32-row packing.
+//   A: packed16[((c8 * 14 + t) * 64 + lane) * 2 + h] = w[tap t][ci = 8 c8 + 4 h + (lane >> 4)][co = lane & 15]
+//   B: lane (voxel n = lane & 15 of a 16-voxel tile row, k = lane >> 4) reads channels 8 c8 + 4 h + k, h = 0, 1 of one
+//      brick position as ONE ds_read_b64: LDS brick [c8][k][kd][position][h]
+//   a work-group = 8 x 16 voxels of one depth slice, wave w = tile rows 2w, 2w + 1 (two N tiles sharing every A fragment).
+// ------------------------------------------------------------------------------------------------
+typedef float pc_f32x2 __attribute__((ext_vector_type(2)));
+
+__global__ void pc_pack16_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int h = idx & 1, l = (idx >> 1) & 63;
+    const int r = idx >> 7;
+    const int t = r % PC_NT, c8 = r / PC_NT;
+    const int tap = (pc_tap_kd(t) * 3 + pc_tap_kh(t)) * 3 + pc_tap_kw(t);
+    const int ci = 8 * c8 + 4 * h + (l >> 4), co = l & 15;
+    out[idx] = co < Cout ? w[((size_t)tap * Cin + ci) * Cout + co] : 0.f;
+}
+
+template <int CIN, int KC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void pc_final16_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
+    constexpr int TR = 8, TC = 16, S = TC + 2, DS = (TR + 2) * S, CHUNK = KC * 2 * DS;
+    constexpr int NST = (CHUNK + 255) / 256, NCH = CIN / KC, C8 = KC / 8, RD = 7;
+    static_assert(DS <= 256 && NST * 256 >= CHUNK + 64, "one brick plane per pass, 64 spare floats behind the brick");
+    __shared__ __attribute__((aligned(16))) float lds[NST * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (a.OW + TC - 1) / TC, tiles_y = (a.OH + TR - 1) / TR;
+    int b = ic_xcd_run(blockIdx.x, gridDim.x);
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y; const int od = b / tiles_y;
+    const int n = blockIdx.z;
+    const int x0 = tx * TC, y0 = ty * TR;
+    const int HW = a.H * a.W;
+    const size_t cstride = (size_t)a.D * HW;
+    const float* __restrict__ xin = a.in + (size_t)n * CIN * cstride + (size_t)od * HW;
+    const int xr_bytes = (int)(((size_t)KC * cstride - (size_t)od * HW) * 4);
+    unsigned loff;
+    {
+        const int rr = tid / S, cc = tid - rr * S;
+        const int iy = y0 + rr, ix = x0 + cc;
+        loff = (tid < DS && iy < a.H && ix < a.W) ? (unsigned)((iy * a.W + ix) * 4) : 0x80000000u;
+    }
+    const int nn = lane & 15, kq = lane >> 4;
+    // B operand base of this lane for N tile nt: brick position (2 wave + nt, nn); float index of (c8 = 0, k = kq, kd = 0, pos, h = 0)
+    const int bbase = (kq * 2 * DS + (2 * wave) * S + nn) * 2;
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, (CIN / 8) * PC_NT * 512, 0x00020000);
+    const unsigned wlane = (unsigned)lane * 8u;
+    auto wload = [&](int gt) -> pc_f32x2 {                   // gt = group * PC_NT + tap: 512 bytes per (group, tap)
+        return __builtin_bit_cast(pc_f32x2, __builtin_amdgcn_raw_buffer_load_b64(wr, wlane, gt * 512, 0));
+    };
+    constexpr int STEPS = (CIN / 8) * PC_NT * 2;             // 4-channel steps of the K sequence
+    static_assert(STEPS % PC_NP == 0, "K steps divide into the partial sums");
+    pc_f32x4 accp[PC_NP][2];
+#pragma unroll
+    for (int p = 0; p < PC_NP; ++p)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accp[p][t][r] = 0.f;
+    pc_f32x2 ring[RD];
+#pragma unroll
+    for (int t = 0; t < RD - 2; ++t) ring[t] = wload(t);
+
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c > 0) __syncthreads();
+        float stv[2 * KC];
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(xin + (size_t)c * KC * cstride), 0, xr_bytes, 0x00020000);
+#pragma unroll
+        for (int p = 0; p < 2 * KC; ++p) {
+            const int so = (int)((((size_t)(p / 2)) * cstride + (size_t)(p & 1) * HW) * 4);
+            stv[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, loff, so, 0));
+        }
+        // brick [c8][k][kd][position][h]: plane (ci, kd) of the chunk goes to ((((ci >> 3) * 4 + (ci & 3)) * 2 + kd) * DS + pos) * 2 + ((ci >> 2) & 1);
+        asm volatile("" ::: "memory");
+        if (tid < DS) {                                        // one predicate around all the writes (see pc_mfma_kernel)
+#pragma unroll
+            for (int p = 0; p < 2 * KC; ++p) {
+                const int ci = p >> 1, kd = p & 1;
+                lds[2 * tid + ((((ci >> 3) * 4 + (ci & 3)) * 2 + kd) * DS) * 2 + ((ci >> 2) & 1)] = stv[p];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        auto tapoff_of = [](int t) { return (pc_tap_kd(t) * DS + pc_tap_kh(t) * S + pc_tap_kw(t)) * 2; };
+        pc_f32x2 bq[2][2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) bq[0][nt] = *(const pc_f32x2*)&lds[bbase + nt * S * 2 + tapoff_of(0)];
+#pragma unroll
+        for (int g = 0; g < C8 * PC_NT; ++g) {
+            const int c8 = g / PC_NT, t = g % PC_NT;
+            const bool more = (c * C8 + c8 + 1) * 8 < CIN;
+            {
+                const int tn = t + RD - 2;
+                if (tn < PC_NT || more) ring[tn % RD] = wload((c * C8 + c8) * PC_NT + tn);
+            }
+            if (g + 1 < C8 * PC_NT) {
+                const int c8n = (g + 1) / PC_NT, tn1 = (g + 1) % PC_NT;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    bq[(g + 1) & 1][nt] = *(const pc_f32x2*)&lds[bbase + c8n * 4 * 2 * DS * 2 + nt * S * 2 + tapoff_of(tn1)];
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int step = (c * C8 * PC_NT + g) * 2 + h, part = step / (STEPS / PC_NP);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    accp[part][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[t % RD][h], bq[g & 1][nt][h], accp[part][nt], 0, 0, 0);
+                if (step + 1 == 2 * (STEPS / PC_NP)) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) accp[0][nt] = accp[0][nt] + accp[1][nt];
+                }
+            }
+        }
+    }
+    // D rows 4 kq + r = output channel, column nn = voxel.  Channels 0..3 sit in the kq = 0 lanes, 4..7 in kq = 1, ...
+    const float* __restrict__ biasp = a.bias;
+    const int ovol = a.OD * a.OH * a.OW;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        pc_f32x4 acc = accp[0][nt] + (accp[2][nt] + accp[3][nt]);          // accp[0] already holds p0 + p1
+        float val[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = 4 * kq + r;
+            val[r] = fmaxf(acc[r] + (co < a.Cout ? biasp[co] : 0.f), 0.f);    // final layer keeps conv3d's default ReLU
+        }
+        // gather the voxel's logits into its kq = 0 lane
+        float lg[16];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lg[4 * g4 + r] = __shfl(val[r], 16 * g4 + nn);
+        const int oy = y0 + 2 * wave + nt, ox = x0 + nn;
+        if (kq == 0 && oy < a.OH && ox < a.OW) {
+            const size_t vox = (size_t)n * ovol + ((size_t)od * a.OH + oy) * a.OW + ox;
+            if (a.out) {
+#pragma unroll
+                for (int c2 = 0; c2 < 16; ++c2) if (c2 < a.Cout) a.out[vox * a.Cout + c2] = lg[c2];
+            }
+            if (a.bits) {
+                float m = lg[0];
+#pragma unroll
+                for (int c2 = 1; c2 < 16; ++c2) if (c2 < a.Cout) m = fmaxf(m, lg[c2]);
+                float ssum = 0.f, lsym = 0.f;
+                const int sym = (int)a.symbols[vox];
+#pragma unroll
+                for (int c2 = 0; c2 < 16; ++c2) {
+                    if (c2 < a.Cout) {
+                        const float shv = lg[c2] - m;
+                        ssum += expf(shv);
+                        if (c2 == sym) lsym = shv;
+                    }
+                }
+                a.bits[vox] = __fmul_rn(logf(ssum) - lsym, 1.44269504f);
+            }
+        }
+    }
+}
+
+static size_t pc_packed16_floats(int k) { return (size_t)(k / 8) * PC_NT * 128; }
 static size_t pc_packed_floats(int k, int cout) { return (size_t)(k / 8) * PC_NT * ic_cdiv(cout, 32) * 256; }
 static bool pc_mfma_supported(int k, int L) { return (k == 24 || k == 64) && L <= 16; }
 
@@ -394,7 +577,7 @@ extern "C" size_t ic_pc_workspace_bytes(int N, int C, int h, int w, int k) {
     size_t f = (size_t)(C + 3) * (h + 6) * (w + 6) + (size_t)(C + 2) * (h + 4) * (w + 4)
                + (size_t)(C + 1) * (h + 2) * (w + 2);
     size_t bytes = f * (size_t)N * k * sizeof(float);
-    if (pc_mfma_supported(k, 16)) bytes += (2 * pc_packed_floats(k, k) + pc_packed_floats(k, 32)) * sizeof(float);
+    if (pc_mfma_supported(k, 16)) bytes += (2 * pc_packed_floats(k, k) + pc_packed_floats(k, 32) + pc_packed16_floats(k)) * sizeof(float);
     return bytes;
 }
 
@@ -424,8 +607,38 @@ static int launch_pc_mfma(const PcLayerArgs& a, const float* wpk, int k, bool fi
     return IC_OK;
 }
 
-// prepacked: the three MFMA filter packings already sit at the end of the workspace (a caller that runs the network
-// many times on small volumes -- the sequential decoder -- packs once with pc_pack_filters).
+// the three matrix-core filter packings [k->k | k->k | k->L] of one network, in one launch
+static int pc_pack_filters(const float* const* wt, int k, int L, float* packed, hipStream_t st) {
+    const int t1 = (int)pc_packed_floats(k, k), t3 = (int)pc_packed_floats(k, L);
+    PcPack3 pa{};
+    pa.w[0] = wt[2]; pa.w[1] = wt[4]; pa.w[2] = wt[6];
+    pa.out[0] = packed; pa.out[1] = packed + t1; pa.out[2] = packed + 2 * (size_t)t1;
+    pa.cout[0] = pa.cout[1] = k; pa.cout[2] = L;
+    pa.ncot[0] = pa.ncot[1] = ic_cdiv(k, 32); pa.ncot[2] = 1;
+    pa.total[0] = pa.total[1] = t1; pa.total[2] = t3;
+    hipLaunchKernelGGL(pc_pack3_kernel, dim3(ic_cdiv(t1 > t3 ? t1 : t3, 256), 3), dim3(256), 0, st, pa, k);
+    // the final layer once more in 16-row fragments (pc_final16_kernel); the 32-row packing stays for the sequential decoder
+    const int t16 = (int)pc_packed16_floats(k);
+    hipLaunchKernelGGL(pc_pack16_kernel, dim3(ic_cdiv(t16, 256)), dim3(256), 0, st, wt[6], packed + 2 * (size_t)t1 + pc_packed_floats(k, 32), k, L, t16);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
+// [k->k | k->k | k->L in 32-row fragments (room for 32 rows) | k->L in 16-row fragments]
+extern "C" size_t ic_pc_packed_floats(int k, int L) {
+    return pc_mfma_supported(k, L) ? 2 * pc_packed_floats(k, k) + pc_packed_floats(k, 32) + pc_packed16_floats(k) : 0;
+}
+
+extern "C" int ic_pc_pack_filters_f32(const float* const* wtab_host, int k, int L, float* packed, ic_stream_t stream) {
+    IC_CHECK_ARG(wtab_host && packed && k > 0 && L > 0);
+    for (int i = 0; i < 8; ++i) IC_CHECK_ARG(wtab_host[i] != nullptr);
+    if (!pc_mfma_supported(k, L)) return IC_ERR_UNSUPPORTED;
+    return pc_pack_filters(wtab_host, k, L, packed, (hipStream_t)stream);
+}
+
+// prepacked: the three MFMA filter packings already sit at the end of the workspace (the sequential decoder packs once
+// per call).  wt[8], when not NULL, is a caller-owned packing made once at load time (ic_pc_pack_filters_f32): inference
+// then runs without the per-call packing launch.
 static int pc_forward(const float* q, int prepadded, const int64_t* symbols, const float* const* wt, int k, int L,
                       float pad_value, float* logits, float* bits, int N, int C, int h, int w,
                       void* workspace, size_t workspace_bytes, hipStream_t st, bool prepacked = false) {
@@ -450,19 +663,11 @@ static int pc_forward(const float* q, int prepadded, const int64_t* symbols, con
     // The same path must serve the parallel pass and the sequential decoder -- their logits have to agree bit for bit --
     // so the limit is the slab, not the volume: every volume a 288 GB device can hold stays on the matrix cores.)
     const bool use_mfma = pc_mfma_supported(k, L) && (size_t)(k == 24 ? 24 : 16) * (C + 3) * (h + 6) * (w + 6) * 4 < (1ull << 31);
-    float* pk1 = b2 + (size_t)N * k * (C + 1) * (h + 2) * (w + 2);
+    float* pk1 = wt[8] ? (float*)wt[8] : b2 + (size_t)N * k * (C + 1) * (h + 2) * (w + 2);
     float* pk2 = pk1 + pc_packed_floats(k, k);
     float* pk3 = pk2 + pc_packed_floats(k, k);
-    if (use_mfma && !prepacked) {
-        const int t1 = (int)pc_packed_floats(k, k), t3 = (int)pc_packed_floats(k, L);
-        PcPack3 pa{};
-        pa.w[0] = wt[2]; pa.w[1] = wt[4]; pa.w[2] = wt[6];
-        pa.out[0] = pk1; pa.out[1] = pk2; pa.out[2] = pk3;
-        pa.cout[0] = pa.cout[1] = k; pa.cout[2] = L;
-        pa.ncot[0] = pa.ncot[1] = ic_cdiv(k, 32); pa.ncot[2] = 1;
-        pa.total[0] = pa.total[1] = t1; pa.total[2] = t3;
-        hipLaunchKernelGGL(pc_pack3_kernel, dim3(ic_cdiv(t1 > t3 ? t1 : t3, 256), 3), dim3(256), 0, st, pa, k);
-        IC_LAUNCH_CHECK();
+    if (use_mfma && !prepacked && !wt[8]) {
+        if ((rc = pc_pack_filters(wt, k, L, pk1, st))) return rc;
     }
     // res1/conv1: k -> k, other mask, ReLU
     a.in = b0; a.w = wt[2]; a.bias = wt[3]; a.out = b1;
@@ -475,7 +680,15 @@ static int pc_forward(const float* q, int prepadded, const int64_t* symbols, con
     // conv2 (final): k -> L, ReLU (default activation), logits channels-last + bits
     a.in = b2; a.w = wt[6]; a.bias = wt[7]; a.out = logits; a.res = nullptr; a.symbols = symbols; a.bits = bits;
     a.Cout = L; a.D = C + 1; a.H = h + 2; a.W = w + 2; a.OD = C; a.OH = h; a.OW = w; a.relu = 1;
-    if (use_mfma) rc = launch_pc_mfma(a, pk3, k, true, st);
+    if (use_mfma && !(k == 24 || k == 64)) rc = launch_pc_mfma(a, pk3, k, true, st);
+    else if (use_mfma) {
+        const float* pk16 = pk3 + pc_packed_floats(k, 32);
+        dim3 g(a.OD * ic_cdiv(a.OH, 8) * ic_cdiv(a.OW, 16), 1, a.N);
+        if (k == 24) hipLaunchKernelGGL((pc_final16_kernel<24, 24>), g, dim3(256), 0, st, a, pk16);
+        else hipLaunchKernelGGL((pc_final16_kernel<64, 16>), g, dim3(256), 0, st, a, pk16);
+        IC_LAUNCH_CHECK();
+        rc = IC_OK;
+    }
     else if (L <= 8) rc = launch_pc<8, false, true>(a, st);
     else rc = launch_pc<16, false, true>(a, st);
     return rc;
@@ -974,16 +1187,8 @@ extern "C" int ic_pc_decode_f32(const uint8_t* bitstream, long long nbytes, int 
     const bool use_mfma = pc_mfma_supported(k, L);
     if (use_mfma) {
         float* pk1 = (float*)pcws + (size_t)k * (4 * 7 * 7 + 3 * 5 * 5 + 2 * 3 * 3);
-        float* pk2 = pk1 + pc_packed_floats(k, k);
-        float* pk3 = pk2 + pc_packed_floats(k, k);
-        const int t1 = (int)pc_packed_floats(k, k), t3 = (int)pc_packed_floats(k, L);
-        PcPack3 pa{};
-        pa.w[0] = wtab_host[2]; pa.w[1] = wtab_host[4]; pa.w[2] = wtab_host[6];
-        pa.out[0] = pk1; pa.out[1] = pk2; pa.out[2] = pk3;
-        pa.cout[0] = pa.cout[1] = k; pa.cout[2] = L;
-        pa.ncot[0] = pa.ncot[1] = ic_cdiv(k, 32); pa.ncot[2] = 1;
-        pa.total[0] = pa.total[1] = t1; pa.total[2] = t3;
-        hipLaunchKernelGGL(pc_pack3_kernel, dim3(ic_cdiv(t1 > t3 ? t1 : t3, 256), 3), dim3(256), 0, st, pa, k);
+        const int rc = pc_pack_filters(wtab_host, k, L, pk1, st);
+        if (rc) return rc;
     }
     hipLaunchKernelGGL(pc_dec_fill_kernel, dim3((unsigned)((nvol + 255) / 256)), dim3(256), 0, st, a.vol, nvol, centers);
     if (use_mfma && k == 24 && !(flags & IC_PC_DECODE_PER_LAYER)) {

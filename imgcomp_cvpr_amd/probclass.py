@@ -173,8 +173,16 @@ class _ResShallow(_Network3D):
             w, b = self._params[scope + '/weights'], self._params[scope + '/biases']
             assert tuple(w.shape) == tuple(shape), (scope, tuple(w.shape), shape)
             tabs += [w, b]
-        self._tab_tensors = tabs
-        self._tab = _lib.ptr_table(tabs)
+        # the matrix-core layers' filter fragments, packed once: inference runs without a per-call packing launch
+        n = lib.ic_pc_packed_floats(self._k, self.L)
+        packed = None
+        if n:
+            packed = torch.empty(n, dtype=torch.float32, device=self._device)
+            check(lib.ic_pc_pack_filters_f32(_lib.ptr_table(tabs + [None]), self._k, self.L, ptr(packed), _lib.current_stream(self._device)),
+                  'ic_pc_pack_filters_f32')
+            torch.cuda.synchronize(self._device)
+        self._tab_tensors = tabs + [packed]
+        self._tab = _lib.ptr_table(self._tab_tensors)
 
     def _workspace(self, N, C, h, w):
         need = lib.ic_pc_workspace_bytes(N, C, h, w, self._k)

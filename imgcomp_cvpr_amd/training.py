@@ -444,7 +444,7 @@ class TrainGraph(object):
         logits = self._new(N, C, h, w, self.L)
         bc = self._new(N, C, h, w)
         q = q.contiguous()
-        check(lib.ic_pc_bitcost_f32(ptr(q), ptr(symbols), _lib.ptr_table(wtab_t), self.k, self.L, float(pad_value), ptr(logits),
+        check(lib.ic_pc_bitcost_f32(ptr(q), ptr(symbols), _lib.ptr_table(wtab_t + [None]), self.k, self.L, float(pad_value), ptr(logits),
                                     ptr(bc), N, C, h, w, ptr(pc_ws), pc_need, self._st()), 'pc forward')
         self._tape_pc = (q, symbols, logits, pc_ws, float(pad_value), (N, C, h, w))
         return bc

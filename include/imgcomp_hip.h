@@ -197,13 +197,17 @@ int ic_heatmap_quantize_f32(const float* bottleneck, const float* centers, int L
  * H/W 4 each side; four masked VALID (2,3,3) conv3d layers 1->k->k->k->L with one residual;
  * the last layer keeps conv3d's default ReLU.  Logits for ALL positions are produced in parallel.
  *   q        (N,C,h,w) fp32     symbols (N,C,h,w) int64
- *   wtab[8]  device pointers {w0,b0,w1,b1,w2,b2,w3,b3}; w* in TF layout [2,3,3,cin,cout], UNMASKED
+ *   wtab[9]  device pointers {w0,b0,w1,b1,w2,b2,w3,b3, packed}; w* in TF layout [2,3,3,cin,cout], UNMASKED
  *            (the masks are applied by skipping the dead taps); layers: conv0, res1/conv1,
- *            res1/conv2, conv2(final)
+ *            res1/conv2, conv2(final).  packed: NULL, or the matrix-core fragment packing of w1..w3 made ONCE with
+ *            ic_pc_pack_filters_f32 (ic_pc_packed_floats(k, L) floats; inference: the weights do not change between
+ *            calls) -- with NULL every call packs into its workspace first (training: the weights change every step)
  *   logits   (N,C,h,w,L) fp32 (nullable for bitcost)     bits (N,C,h,w) fp32 = CE * log2(e)
  *   workspace: ic_pc_workspace_bytes(N,C,h,w,k) bytes.
  */
 size_t ic_pc_workspace_bytes(int N, int C, int h, int w, int k);
+size_t ic_pc_packed_floats(int k, int L);       /* 0: this (k, L) runs the any-shape VALU kernels, nothing to pack */
+int ic_pc_pack_filters_f32(const float* const* wtab_host, int k, int L, float* packed, ic_stream_t stream);
 int ic_pc_logits_f32(const float* q, const float* const* wtab_host, int k, int L, float pad_value,
                      float* logits, int N, int C, int h, int w,
                      void* workspace, size_t workspace_bytes, ic_stream_t stream);

@@ -391,7 +391,7 @@ def test_error_codes(cuda):
                                       None, None, None) == -1
     x = torch.zeros(8, device=cuda)
     assert L.lib.ic_quantize_f32(L.ptr(x), L.ptr(x), 17, 1.0, None, None, None, 8, None) == -2
-    assert L.lib.ic_pc_logits_f32(L.ptr(x), L.ptr_table([x] * 8), 24, 6, 0.0, L.ptr(x), 1, 1, 1, 1,
+    assert L.lib.ic_pc_logits_f32(L.ptr(x), L.ptr_table([x] * 8 + [None]), 24, 6, 0.0, L.ptr(x), 1, 1, 1, 1,
                                   L.ptr(x), 4, None) == -3
     with pytest.raises(L.HipLibraryError):
         L.check(-2, 'demo')

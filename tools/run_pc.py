@@ -1,0 +1,15 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from imgcomp_cvpr_amd import probclass, config_parser as cp, weights as W
+dev = torch.device('cuda:0')
+ae_cfg, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'low'))
+pc_cfg, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
+wts = W.synthetic_weights(ae_cfg, pc_cfg)
+pc = probclass.get_network_cls(pc_cfg)(pc_cfg, num_centers=ae_cfg.num_centers).load_weights(wts, dev)
+centers = torch.as_tensor(wts['autoencoder/encoder/centers']).to(dev)
+sym = torch.randint(0, 6, (1, 32, 64, 96), device=dev)
+q = centers[sym].contiguous()
+for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 50):
+    pc.bitcost(q, sym, False, pad_value=float(centers[0]))
+torch.cuda.synchronize()
