@@ -71,7 +71,7 @@ class Pipeline(object):
         self.N, self.H, self.Wd = N, H, Wd
         self.x_np = self.W.synthetic_image((N, 3, H, Wd), 'natural', seed=self.seed)
         self.x = self.torch.as_tensor(self.x_np).float().to(self.dev)
-        self.side = self.branch.context_model_stream(N, H, Wd)
+        self.side = self.branch.context_model_stream(N, H, Wd, int(self.ae_cfg.num_chan_bn))
         self.dec_flags = self.branch.decode_flags(self.side)
         return self
 
@@ -102,7 +102,7 @@ def main():
     p.add_argument('--mode', default='infer', choices=['infer', 'train'])
     p.add_argument('--share', default='auto', choices=['auto', 'cu_range', 'full_chip'],
                    help='how decoder and context model share the chip (imgcomp_cvpr_amd/streams.py); auto = the package default')
-    p.add_argument('--idle_layers', type=int, default=None, help="cu_range sharing: 3x3 launches of the decoder that leave the side stream's CUs idle (0 = all)")
+    p.add_argument('--idle_layers', type=int, default=None, help="cu_range sharing: 3x3 launches of the decoder that leave the side stream's CUs idle (0 = all; default: sized from the context model's work)")
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--no_extras', action='store_true', help='headline only: no stage split, roofline, extra shapes (rocprofv3 runs)')
     p.add_argument('--pipelined', action='store_true', help='also run the informational three-pipelines-in-flight section')

@@ -28,7 +28,7 @@ from . import _lib
 
 
 DEFAULT_SHARE = 'cu_range'
-DEFAULT_IDLE_LAYERS = 0          # 0 = the whole residual stack
+DEFAULT_IDLE_LAYERS = None       # None = sized from the context model's work (BranchStreams.auto_idle_layers); 0 = the whole stack
 
 
 class BranchStreams(object):
@@ -39,6 +39,7 @@ class BranchStreams(object):
         # 3x3 launches of a decode call that leave the side stream's CUs alone; the rest of the stack takes the whole chip
         # again (the context model is done long before the decoder: 0.4 ms of a 1.3 ms decode on a Kodak-sized image)
         self.idle_layers = DEFAULT_IDLE_LAYERS if idle_layers is None else int(idle_layers)
+        self._auto_layers = 0
         assert share in ('cu_range', 'full_chip')
         self.share = share
         self.device = torch.device(device)
@@ -58,8 +59,23 @@ class BranchStreams(object):
             return 0
         return min((self.n_cus - wgs) // 8 * 8, self.n_cus // 2)
 
-    def context_model_stream(self, N, H, W):
+    # Measured on the MI355X (bench.py --idle_layers sweep, Kodak image): the context model's 196,608 symbols take ~0.6 ms on
+    # 64 CUs = 3.05 ns per symbol per 64 CUs, a one-work-group-per-CU 3x3 launch 37.5 us.  The decoder leaves the side
+    # stream's CUs alone for that many of its 3x3 launches and takes the whole chip for the rest (sweep: 12 launches 149.4
+    # Mpix/s -- the context model is not done and the step waits for it -- 16: 153.2, 20: 152.6, all 32: 149.4).
+    NS_PER_SYMBOL_64CU = 3.05
+    US_PER_LAYER = 37.5
+
+    def auto_idle_layers(self, N, H, W, n_cus, C=32):
+        import math
+        symbols = N * C * (H // 8) * (W // 8)
+        t_pc_us = symbols * self.NS_PER_SYMBOL_64CU * 1e-3 * 64.0 / max(n_cus, 1)
+        n = int(math.ceil(t_pc_us / self.US_PER_LAYER))
+        return 0 if n >= 60 else max(n, 4)
+
+    def context_model_stream(self, N, H, W, C=32):
         n = self.idle_cus(N, H, W)
+        self._auto_layers = self.auto_idle_layers(N, H, W, n, C) if n >= self.MIN_CUS else 0
         if n < self.MIN_CUS:
             return self._plain           # the decoder fills the chip in rounds: nothing to partition
         if n not in self._ranged:
@@ -78,7 +94,8 @@ class BranchStreams(object):
         rounds stay one work-group per CU (the idle CUs untouched) instead of being spread over every CU."""
         if side is self._plain:
             return 0
-        return _lib.CONV3_LEAVE_IDLE_CUS | _lib.conv3_leave_idle_layers(self.idle_layers)
+        layers = self._auto_layers if self.idle_layers is None else self.idle_layers
+        return _lib.CONV3_LEAVE_IDLE_CUS | _lib.conv3_leave_idle_layers(layers)
 
     def close(self):
         for h in self._handles:

@@ -187,7 +187,7 @@ class Fetcher(object):
         # decoder and context model are independent consumers of the encoder output: two streams, the context model on
         # the CUs the decoder's 3x3 launches leave idle (streams.py)
         cur = torch.cuda.current_stream(self.device)
-        side = self._streams.context_model_stream(x.shape[0], x.shape[2], x.shape[3])
+        side = self._streams.context_model_stream(x.shape[0], x.shape[2], x.shape[3], int(self.ae.config.num_chan_bn))
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             bc = self.pc.bitcost(enc.qbar, enc.symbols, is_training=False, pad_value=self.pc.auto_pad_value(self.ae))

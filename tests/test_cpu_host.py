@@ -181,7 +181,8 @@ def test_abi_header_bindings_and_exports_agree():
     assert _lib.lib.ic_conv3x3_c128_packed_floats() == 9 * 128 * 128
     # size queries are pure host arithmetic
     feat = 4 * 24 * (35 * 38 * 38 + 34 * 36 * 36 + 33 * 34 * 34)          # three feature volumes
-    packed = 4 * 3 * (3 * 14 * 256)                                        # three filters in MFMA fragment order
+    packed = 4 * (3 * (3 * 14 * 256) + 3 * 14 * 128)                       # three filters in 32-row MFMA fragment order + the final layer in 16-row fragments
+    assert _lib.lib.ic_pc_packed_floats(24, 6) * 4 == packed and _lib.lib.ic_pc_packed_floats(12, 6) == 0
     assert _lib.lib.ic_pc_workspace_bytes(1, 32, 32, 32, 24) == feat + packed
     assert _lib.lib.ic_ae_workspace_bytes(1, 512, 768, 32) > 0 and _lib.lib.ic_ae_workspace_bytes(0, 1, 1, 1) == 0
 

@@ -10,6 +10,7 @@ pc = probclass.get_network_cls(pc_cfg)(pc_cfg, num_centers=ae_cfg.num_centers).l
 centers = torch.as_tensor(wts['autoencoder/encoder/centers']).to(dev)
 sym = torch.randint(0, 6, (1, 32, 64, 96), device=dev)
 q = centers[sym].contiguous()
+pad = float(centers[0])
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 50):
-    pc.bitcost(q, sym, False, pad_value=float(centers[0]))
+    pc.bitcost(q, sym, False, pad_value=pad)
 torch.cuda.synchronize()
