@@ -58,10 +58,13 @@ __device__ __forceinline__ float tn_sub(float x, float y) { float r; asm("v_sub_
 // PK: input transform on packed-fp32 adds (v_pk_add_f32: 16 instructions instead of 32); PK = false keeps every add a
 // single-issue v_add_f32 / v_sub_f32 (inline asm, so that the SLP vectoriser does not re-pack them) -- packed fp32 next to
 // MFMAs is measured as slower per instruction than two plain adds (MI355X_MICROARCH.md, "price of one filler").
-template <int NB, bool PK>
+template <int NB, bool PK, bool WT>
 __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void wino3x3_c128_tn_kernel(const WnArgs a) {
 #ifdef WN_PROF
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef WN_PROF3     // shader clock against the constant 100 MHz counter: what frequency does the kernel actually run at?
+    const unsigned long long r_entry = __builtin_amdgcn_s_memrealtime();
 #endif
     constexpr int SLOT = 4 * NB * 4 * 64;                       // float4 elements of one ring slot: [k-step][segment][quad][lane]
     __shared__ f32x4 ring[3 * SLOT];
@@ -76,43 +79,72 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void wino3x3_c128_tn_kernel(c
     const int nseg = 2 * a.ngroups;
 
     // ---- the NB segments of this job: segment s of the launch = tile row (s & 1) of tile group g0 + s / 2 ----
+    // Everything up to the first patch request is serial scalar work of a wave that has nothing else to run (measured:
+    // 2,700 clocks with compiler-generated integer divisions, branches and all address arithmetic ahead of the first load;
+    // the layer is 74,000).  So: divisions by host-made reciprocals, no branches, and each segment's requests leave as soon
+    // as ITS addresses exist.
     int sg_n[NB], sg_ty[NB], sg_gx[NB];
     bool sg_ok[NB];
     {
         const int s0 = job * NB;
         const int g = a.g0 + (s0 >> 1);
-        int gx = g % a.gcols;
-        const int t = g / a.gcols;
-        int n = t / a.grows, gy = t - n * a.grows, r = s0 & 1;
+        const int t = a.mg_cols ? (int)__umulhi((unsigned)g, a.mg_cols) : g;            // g / gcols
+        int gx = g - t * a.gcols;
+        int n = a.mg_rows ? (int)__umulhi((unsigned)t, a.mg_rows) : t;                  // t / grows
+        int gy = t - n * a.grows, r = s0 & 1;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             sg_ok[i] = s0 + i < nseg;
             sg_n[i] = sg_ok[i] ? n : 0; sg_ty[i] = 2 * gy + r; sg_gx[i] = gx;
             r ^= 1;
-            if (r == 0) { if (++gx == a.gcols) { gx = 0; if (++gy == a.grows) { gy = 0; ++n; } } }
+            gx += r == 0;                                        // next tile group after its second row
+            const bool wx = gx == a.gcols; gx = wx ? 0 : gx;
+            gy += wx;
+            const bool wy = gy == a.grows; gy = wy ? 0 : gy;
+            n += wy;
         }
     }
+    f32x2 pp[NB][4], pe[NB][4];                                  // own pair / end-of-row pair of the 4 patch rows
     __amdgpu_buffer_rsrc_t xr[NB];
     unsigned o0[NB][4], oe[NB][4];
+#ifdef WN_PROF2
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t_addr = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         xr[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)sg_n[i] * WN_C * HW), 0, WN_C * HW * 4, 0x00020000);
         const int tx = sg_gx[i] * 16 + tj;
         const int r0 = 2 * sg_ty[i] - 1;
         // the end-of-row value is fetched as the aligned pair that contains it -- lane 0: (2tx-2, 2tx-1), lane 15: (2tx+2, 2tx+3)
-        const int ecol = tj == 0 ? 2 * tx - 2 : (tj == 15 ? 2 * tx + 2 : -1);
+        const int ecol = 2 * tx + (tj == 0 ? -2 : 2);
+        const bool has_e = (tj == 0 || tj == 15) && ecol >= 0 && ecol < W;
+        const bool has_0 = 2 * tx < W;
+        const int so = wave * 4 * HW * 4;                       // own k-step of the first ring slot
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = r0 + q;
             const bool rok = sg_ok[i] && r >= 0 && r < H;
             const unsigned rb = (unsigned)(kq * HW + r * W) * 4u;
-            o0[i][q] = (rok && 2 * tx < W) ? rb + 8u * tx : WN_OOB;
-            oe[i][q] = (rok && ecol >= 0 && ecol < W) ? rb + 4u * ecol : WN_OOB;
+            o0[i][q] = (rok && has_0) ? rb + 8u * tx : WN_OOB;
+            oe[i][q] = (rok && has_e) ? rb + 4u * ecol : WN_OOB;
+            pp[i][q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr[i], o0[i][q], so, 0));
+            pe[i][q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr[i], oe[i][q], so, 0));
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
     const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wp + WN_FRAG_FLOATS), 0, WN_FRAG_FLOATS * 4, 0x00020000);
     const unsigned fo = lane * 16u;
-
+    f32x4 fl[TN_FST][4];
+#pragma unroll
+    for (int st = 0; st < TN_FST - 1; ++st) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            fl[st][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(fr, fo + q * 1024u, (ct * 32 + st) * 4096, 0));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // the accumulators are cleared while the requests are in flight (192 v_accvgpr_write for NB = 3)
     f32x4 acc[NB][16];
 #pragma unroll
     for (int i = 0; i < NB; ++i)
@@ -120,8 +152,11 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void wino3x3_c128_tn_kernel(c
         for (int p = 0; p < 16; ++p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][p][r] = 0.f;
-    f32x2 pp[NB][4], pe[NB][4];                                  // own pair / end-of-row pair of the 4 patch rows
-    f32x4 fl[TN_FST][4];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int p = 0; p < 16; ++p) asm volatile("" : "+a"(acc[i][p]));
+    __builtin_amdgcn_sched_barrier(0);
 
     auto load_patch = [&](int i, int ks) __attribute__((always_inline)) {
         const int so = ks * 4 * HW * 4;                         // scalar: channels 4 ks ..
@@ -130,12 +165,6 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void wino3x3_c128_tn_kernel(c
             pp[i][q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr[i], o0[i][q], so, 0));
             pe[i][q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr[i], oe[i][q], so, 0));
         }
-    };
-    auto load_filter = [&](int s, int ks) __attribute__((always_inline)) {
-        const int so = (ct * 32 + ks) * 4096;                   // scalar: 4 KB per (channel tile, k-step)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            fl[s][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(fr, fo + q * 1024u, so, 0));
     };
     // Bt d B of one lane's patch -> the 16 B operands of a k-step (position 4 row + column), cut into 16 micro-steps of
     // 2-4 vector instructions so that the main loop can place them behind individual MFMAs.
@@ -204,27 +233,32 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void wino3x3_c128_tn_kernel(c
     };
 
     constexpr int NKS = 32, NIT = NKS / 4;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) load_patch(i, wave);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int st = 0; st < TN_FST - 1; ++st) {
-        load_filter(st, st);
-        __builtin_amdgcn_sched_barrier(0);
-    }
     float vt[16];
+#ifdef WN_PROF2
+    unsigned long long t_data = 0, t_puts = 0;
+#endif
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         transform(i, vt);
+#ifdef WN_PROF2
+        if (i == 0) { asm volatile("" : "+v"(vt[0])); __builtin_amdgcn_sched_barrier(0); t_data = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#endif
         put(rb0, i, vt);
         load_patch(i, 4 + wave);
         __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef WN_PROF2
+    t_puts = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     __syncthreads();
     f32x4 bq[2][4];
     get(rb0, 0, 0, bq[0]);
 #ifdef WN_PROF
     const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef WN_PROF3
+    const unsigned long long r_loop0 = __builtin_amdgcn_s_memrealtime();
 #endif
     // slot rotation: rd = slot read by this iteration, wr = slot written (and read by the next one), fr3 = the third.
     //
@@ -323,20 +357,10 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void wino3x3_c128_tn_kernel(c
         }
         f32x4* const t = rd; rd = wr; wr = fr3; fr3 = t;
     }
-    // The last MFMAs' results are read by compiler code below, and inline asm is opaque to the hazard recogniser: left
-    // alone it schedules v_accvgpr_read right behind the last MFMA with one wait state (measured: wrong outputs in the
-    // NB = 2 build).  Volatile asm statements keep their order, and every accumulator passes through an empty one AFTER
-    // the pad, so no read of an accumulator can be scheduled above it.
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-#pragma unroll
-        for (int p = 0; p < 16; ++p) asm volatile("" : "+a"(acc[i][p]));
-#ifdef WN_PROF
-    const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
-#endif
-
     // ---- At M A, BN fold, activation, residuals, store: lane (kq, tile tj) holds channels 16 ct + 4 kq + r of its tile ----
+    // Like the prologue this is serial time of the whole CU (no second work-group to overlap with), so the residual requests
+    // go out FIRST -- before the wait for the last MFMAs -- and the output transform of every accumulator runs under their
+    // latency; only the final adds wait for them.
     const float relu_lo = a.relu ? 0.f : -__builtin_inff();
     const f32x4 sc4 = *(const f32x4*)(a.scale + 16 * ct + 4 * kq);
     const f32x4 sh4 = *(const f32x4*)(a.shift + 16 * ct + 4 * kq);
@@ -364,6 +388,23 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void wino3x3_c128_tn_kernel(c
             rb1v[i][r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r2r, lo1[i], so, 0));
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // The last MFMAs' results are read by compiler code below, and inline asm is opaque to the hazard recogniser: left
+    // alone it schedules v_accvgpr_read right behind the last MFMA with one wait state (measured: wrong outputs in the
+    // NB = 2 build).  Volatile asm statements keep their order, and every accumulator passes through an empty one AFTER
+    // the pad, so no read of an accumulator can be scheduled above it.
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int p = 0; p < 16; ++p) asm volatile("" : "+a"(acc[i][p]));
+#ifdef WN_PROF
+    const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef WN_PROF3
+    const unsigned long long r_loop1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    f32x2 q0[NB][4], q1[NB][4];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
 #pragma unroll
@@ -380,27 +421,41 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void wino3x3_c128_tn_kernel(c
             o00 = fmaf(o00, sc4[r], sh4[r]); o01 = fmaf(o01, sc4[r], sh4[r]);
             o10 = fmaf(o10, sc4[r], sh4[r]); o11 = fmaf(o11, sc4[r], sh4[r]);
             o00 = fmaxf(o00, relu_lo); o01 = fmaxf(o01, relu_lo); o10 = fmaxf(o10, relu_lo); o11 = fmaxf(o11, relu_lo);
-            f32x2 q0 = {o00, o01}, q1 = {o10, o11};
-            q0 += ra0[i][r]; q1 += ra1[i][r];
-            q0 += rb0v[i][r]; q1 += rb1v[i][r];
+            q0[i][r] = f32x2{o00, o01}; q1[i][r] = f32x2{o10, o11};
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { asm volatile("" : "+v"(q0[i][r])); asm volatile("" : "+v"(q1[i][r])); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            f32x2 v0 = q0[i][r] + ra0[i][r], v1 = q1[i][r] + ra1[i][r];
+            v0 += rb0v[i][r]; v1 += rb1v[i][r];
             const int so = (16 * ct + r) * HW * 4;
-            // Single-round launches store write-through (sc1): nothing is left dirty in the L2s for the kernel boundary to
+            // WT: single-round launches store write-through (sc1): nothing is left dirty in the L2s for the kernel boundary to
             // write back, which shortens the gap to the next layer's launch (Kodak layer 33.5 -> 32.5 us, A/B'd); launches
             // of several rounds keep plain stores (4K map: write-through 1.5 % slower -- later rounds re-read their neighbours'
             // rows from L2).
-            if (a.store_wt) {
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q0), yr[i], lo0[i], so, 16);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q1), yr[i], lo1[i], so, 16);
-            } else {
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q0), yr[i], lo0[i], so, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q1), yr[i], lo1[i], so, 0);
-            }
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v0), yr[i], lo0[i], so, WT ? 16 : 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v1), yr[i], lo1[i], so, WT ? 16 : 0);
         }
     }
 #ifdef WN_PROF
     if (a.prof && lane == 0) {
         unsigned long long* d = a.prof + 4 * ((size_t)blockIdx.x * 4 + wave);
+#ifdef WN_PROF3
+        d[0] = __builtin_amdgcn_s_memtime() - t_entry; d[1] = __builtin_amdgcn_s_memrealtime() - r_entry;
+        d[2] = t_loop1 - t_loop0; d[3] = r_loop1 - r_loop0;
+#elif defined(WN_PROF2)
+        // prologue split: address set-up | first patch data transformed | all ring writes issued | barrier + first operands
+        d[0] = t_addr - t_entry; d[1] = t_data - t_addr; d[2] = t_puts - t_data; d[3] = t_loop0 - t_puts;
+#else
         d[0] = t_loop0 - t_entry; d[1] = t_loop1 - t_loop0; d[2] = __builtin_amdgcn_s_memtime() - t_loop1; d[3] = t_entry;
+#endif
     }
 #endif
 }
@@ -411,12 +466,18 @@ int icx_wino_tn_launch(const WnArgs& a_in, int nb, int scalar_transform, hipStre
     const unsigned jobs = (unsigned)((2 * a_in.ngroups + nb - 1) / nb);
     const dim3 grid(2 * jobs), block(256);
     WnArgs a = a_in;
-    a.store_wt = 2 * jobs <= (nb == 1 ? 512u : 256u) ? 1 : 0;       // everything resident at once: one round
-#define TN_GO(NB_, PK_) hipLaunchKernelGGL((wino3x3_c128_tn_kernel<NB_, PK_>), grid, block, 0, st, a)
+    const bool wt = 2 * jobs <= (nb == 1 ? 512u : 256u);            // everything resident at once: one round
+    a.store_wt = wt ? 1 : 0;
+    // reciprocals for the kernel's two divisions: n / d = mulhi(n, 2^32 / d + 1) exactly while n d < 2^32
+    if ((unsigned long long)(a.g0 + a.ngroups) * (unsigned)(a.gcols > a.grows ? a.gcols : a.grows) >= (1ull << 32)) return IC_ERR_UNSUPPORTED;
+    a.mg_cols = a.gcols > 1 ? (unsigned)((1ull << 32) / (unsigned)a.gcols) + 1u : 0u;
+    a.mg_rows = a.grows > 1 ? (unsigned)((1ull << 32) / (unsigned)a.grows) + 1u : 0u;
+#define TN_GO(NB_, PK_, WT_) hipLaunchKernelGGL((wino3x3_c128_tn_kernel<NB_, PK_, WT_>), grid, block, 0, st, a)
     if (scalar_transform) {
-        if (nb == 1) TN_GO(1, false); else if (nb == 2) TN_GO(2, false); else TN_GO(3, false);
-    } else {
-        if (nb == 1) TN_GO(1, true); else if (nb == 2) TN_GO(2, true); else TN_GO(3, true);
+        if (wt) { if (nb == 1) TN_GO(1, false, true); else if (nb == 2) TN_GO(2, false, true); else TN_GO(3, false, true); }
+        else { if (nb == 1) TN_GO(1, false, false); else if (nb == 2) TN_GO(2, false, false); else TN_GO(3, false, false); }
+    } else {                        // the packed-transform form is a measurement variant: plain stores only
+        if (nb == 1) TN_GO(1, true, false); else if (nb == 2) TN_GO(2, true, false); else TN_GO(3, true, false);
     }
 #undef TN_GO
     IC_LAUNCH_CHECK();

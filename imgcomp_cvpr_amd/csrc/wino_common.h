@@ -22,6 +22,7 @@ struct WnArgs {
     int g0;                     // first tile group of this launch (a shape may be split into launches of different forms)
     int ngroups;                // tile groups of this launch (the NB-segment kernels: 2 segments per group)
     int store_wt;               // NB-segment kernels: 1 = write-through output stores (single-round launches)
+    unsigned mg_cols, mg_rows;  // NB-segment kernels: 2^32 / gcols + 1, 2^32 / grows + 1 (0 for a divisor of 1); set by the launcher
     unsigned long long* prof;   // profiling builds (WN_PROF) only
 };
 
