@@ -226,6 +226,12 @@ def main():
 
         enc_l = layer_entry('enc', 0)
         dec_l = layer_entry('dec', pipe.dec_flags)
+        n_idle = (pipe.dec_flags >> 12) & 0x7f
+        if pipe.dec_flags & _lib.CONV3_LEAVE_IDLE_CUS and 0 < n_idle < dec_l['layers_timed']:
+            # mixed stack: the first n_idle launches keep off the context model's CUs, the rest take the whole chip
+            dec_l['plan'] = {'first_launches': n_idle, 'first': dec_l['plan'],
+                             'remaining_launches': dec_l['layers_timed'] - n_idle, 'remaining': plan_name(lib, _lib, N, h4, w4, 0)}
+        extra['decoder_idle_layers'] = n_idle if pipe.dec_flags & _lib.CONV3_LEAVE_IDLE_CUS else None
         # PMC counters cannot be read from inside this process: rocprofv3 --pmc passes over `bench.py --no_extras`
         # (tools/profile.sh) write profiles/r02_conv3x3_traffic.json, keyed by kernel name and shape
         traffic = traffic_src = None
