@@ -26,6 +26,7 @@ CONV3_LEAVE_IDLE_CUS = 0x10
 CONV3_NO_XCD_RUNS = 0x20
 CONV3_PACKED_TRANSFORM = 0x40
 PC_DECODE_PER_LAYER = 0x01
+PC_DECODE_RECOMPUTE = 0x02
 
 
 def conv3_leave_idle_layers(n):

@@ -1155,12 +1155,197 @@ __global__ __launch_bounds__(256) void pc_dec_fused_kernel(const PcFusedArgs f) 
 #endif
 }
 
+// ---- the persistent decoder with activation caches (k = 24): one NEW voxel per layer per symbol ----------------------------
+// pc_dec_fused_kernel recomputes the whole 5x9x9 context of every symbol: 196 + 75 + 18 + 1 voxels.  But an activation depends
+// only on symbols BEFORE its own position (the first layer's mask excludes the centre), so every voxel of every layer can
+// be computed exactly once, the moment its last input is known, and kept (Fast-PixelCNN caching; here for a VALID-conv
+// network over a padded volume, so the caches include the halo voxels that see pad values).  In absolute indices of the
+// padded volume V[(C+4)][(h+8)][(w+8)]:
+//     A0[d][i][j] = relu(conv0(V[d..d+1][i..i+2][j..j+2]))          d <= C+2, i <= h+5, j <= w+5
+//     A1[d][i][j] = relu(conv1(A0[d..d+1][i..i+2][j..j+2]))         d <= C+1, i <= h+3, j <= w+3
+//     A2[d][i][j] = conv2(A1[d..d+1][i..i+2][j..j+2]) + A0[d+2][i+2][j+2]
+//     logits of symbol (c, y, x) = relu(conv3(A2[c..c+1][y..y+2][x..x+2]))
+// and the last live tap of every window is its (1,1,1) corner ((1,1,0) for conv0).  The kernel sweeps P = (D, I, J) over the
+// padded volume in raster order; at P it knows V[P] and computes  A0[D-1][I-1][J] -> A1[D-2][I-2][J-1] -> A2[D-3][I-3][J-2]
+// -> the logits of the symbol at V[D][I][J+1], decodes it, and moves on.  Everything else those four need was computed at
+// an earlier P: 13 of a window's 14 taps are prefetched from the caches (channels-last, in HBM/L2) while the range decoder
+// works on the previous symbol, the (1,1,0) tap is the previous step's voxel and stays in LDS.
+// Bit-identical to the parallel pass: fp32 MFMA is an fma chain in ascending k (tools/mfma_order.hip: v_mfma_f32_32x32x2_f32 and
+// 16x16x4 against fmaf chains, 0 mismatches), so ONE output of pc_mfma_kernel is four fmaf chains over the K sequence
+// (8-channel group, tap, channel pair) cut at 42-step boundaries, summed (p0 + p1) + (p2 + p3).  Wave w runs part w; lanes
+// 0..23 hold the weights of conv1's outputs, lanes 24..47 conv2's, lanes 48.. conv3's -- the same 84 registers per lane serve
+// all three layers, each layer is one pass of 84 dependent v_fma over broadcast LDS reads.
+struct PcCachedArgs {
+    PcDecArgs d;
+    const float* w0; const float* b0; const float* w1; const float* b1; const float* w2; const float* b2; const float* w3; const float* b3;
+    float* c0; float* c1; float* c2;          // activation caches, [d][i][j][24]
+    int* status;
+};
+
+// chain position of (tap t, channel ci) in the K sequence of pc_mfma_kernel<24, ...>: 2 * (4 * ((ci / 8) * 14 + t) + (ci % 8) / 2) + ci % 2
+__device__ __forceinline__ int pc_chain_idx(int t, int ci) { return 8 * ((ci >> 3) * PC_NT + t) + (ci & 7); }
+
+__global__ __launch_bounds__(256) void pc_dec_cached_kernel(const PcCachedArgs f) {
+    constexpr int K = 24, KT = PC_NT * K;                 // 336 inputs per output
+    __shared__ __attribute__((aligned(16))) float s_in[3][KT];          // inputs of conv1 / conv2 / conv3 in chain order
+    __shared__ float s_v[16];                             // the 13 live taps of conv0
+    __shared__ float s_part[2][4][64];
+    __shared__ float s_centers[16];
+    __shared__ float s_logits[16];
+    const PcDecArgs& a = f.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = a.L;
+    // ---- per-lane constants ----
+    const int grp = lane < 24 ? 0 : (lane < 48 ? 1 : 2), co = lane - (grp == 2 ? 48 : 24 * grp), co0 = lane % 24;
+    const int cout_g = grp == 2 ? L : K;
+    const float* wl = grp == 0 ? f.w1 : (grp == 1 ? f.w2 : f.w3);
+    float wreg[84];
+#pragma unroll
+    for (int n = 0; n < 84; ++n) {
+        const int g = 42 * wave + (n >> 1), ts = g >> 2, c8 = ts / PC_NT, t = ts - c8 * PC_NT;
+        const int ci = 8 * c8 + 2 * (g & 3) + (n & 1);
+        const int tap = (pc_tap_kd(t) * 3 + pc_tap_kh(t)) * 3 + pc_tap_kw(t);
+        wreg[n] = co < cout_g ? wl[((size_t)tap * K + ci) * cout_g + co] : 0.f;
+    }
+    float w0reg[13];
+#pragma unroll
+    for (int lt = 0; lt < 13; ++lt) w0reg[lt] = f.w0[lt * K + co0];     // live taps of the first mask are TF taps 0..12
+    const float bias0 = f.b0[co0];
+    const float bias_l = grp == 0 ? f.b1[co] : (grp == 1 ? f.b2[co] : (co < L ? f.b3[co] : 0.f));
+    if (tid < L) s_centers[tid] = a.centers[tid];
+    const float pad = a.centers[0];
+    // ---- prefetch role: thread -> (layer pl, tap t < 12, channel quad q), and the conv0 taps on threads 0..11 ----
+    const int pl = tid / 84, pe = tid - pl * 84, pt = pe / 6, pq = pe - pt * 6;
+    const bool pf_on = tid < 252 && pt < 12;
+    const int pkd = pt < 9 ? 0 : 1, pkh = pt < 9 ? pt / 3 : 0, pkw = pt < 9 ? pt % 3 : pt - 9;
+    const int ni = a.h + 6 - 2 * pl, nj = a.w + 6 - 2 * pl;
+    const float* cpl = pl == 0 ? f.c0 : (pl == 1 ? f.c1 : f.c2);
+    const int pdst = 8 * ((pq >> 1) * PC_NT + pt) + 4 * (pq & 1);      // chain position of channels 4 pq .. 4 pq + 3 of tap pt
+    const int vkd = tid < 9 ? 0 : 1, vkh = tid < 9 ? tid / 3 : 0, vkw = tid < 9 ? tid % 3 : tid - 9;
+    const int PH = a.h + 8, PW = a.w + 8, HW = a.h * a.w;
+    const int D1 = a.C + 3, I1 = a.h + 6, J1 = a.w + 5;   // last D, I, J of the sweep
+    auto layer_valid = [&](int l, int D, int I, int J) -> bool {     // does step (D, I, J) produce a voxel of layer l + 1?
+        return D >= 2 + l && I >= 2 + l && J >= 1 + l && I <= a.h + 5 - l && J <= a.w + 4 - l;
+    };
+    pc_f32x4 pf = {0.f, 0.f, 0.f, 0.f};
+    float pv = pad;
+    auto prefetch = [&](int D, int I, int J) {
+        if (pf_on && layer_valid(pl, D, I, J)) {
+            const int off = (((D - 2 - pl + pkd) * ni + (I - 2 - pl + pkh)) * nj + (J - 1 - pl + pkw)) * K + 4 * pq;
+            pf = *reinterpret_cast<const pc_f32x4*>(cpl + off);
+        }
+        if (tid < 12) pv = a.vol[((size_t)(D - 1 + vkd) * PH + (I - 1 + vkh)) * PW + J + vkw];
+    };
+    PcDecState s;
+    if (tid == 0) {
+        s.low = 0; s.high = (1ull << PC_AC_BITS) - 1; s.code = 0;
+        s.byte_pos = -1; s.bit_left = 0; s.cur_byte = 0; s.nxt_byte = a.nbytes > 0 ? a.bits[0] : 0; s.error = 0; s.next = 1;
+        for (int i = 0; i < PC_AC_BITS; ++i) s.code = (s.code << 1) | (unsigned)pc_dec_bit(a, s);
+        s_v[12] = pad;                                    // V[1][1][0]
+    }
+    int D = 1, I = 1, J = 0;
+    prefetch(D, I, J);
+    // one chain pass: this wave's part of the K sequence for the output this lane holds the weights of
+    auto chain = [&](const float* in) -> float {
+        const pc_f32x4* in4 = reinterpret_cast<const pc_f32x4*>(in + 84 * wave);
+        float acc = 0.f;
+#pragma unroll
+        for (int n4 = 0; n4 < 21; ++n4) {
+            const pc_f32x4 v = in4[n4];
+            acc = fmaf(wreg[4 * n4], v[0], acc); acc = fmaf(wreg[4 * n4 + 1], v[1], acc);
+            acc = fmaf(wreg[4 * n4 + 2], v[2], acc); acc = fmaf(wreg[4 * n4 + 3], v[3], acc);
+        }
+        return acc;
+    };
+    for (;;) {
+        // ---- the prefetched taps of this step -> LDS ----
+        if (pf_on) *reinterpret_cast<pc_f32x4*>(&s_in[pl][pdst]) = pf;
+        if (tid < 12) s_v[tid] = pv;
+        __syncthreads();                                  // also: thread 0's s_v[12] of the previous step
+        const bool v1 = layer_valid(0, D, I, J), v2 = layer_valid(1, D, I, J), v3 = layer_valid(2, D, I, J);
+        // ---- conv0: every lane computes channel lane % 24 (so lane 24 + c holds the skip operand of conv2's output c) ----
+        float a0 = 0.f;
+#pragma unroll
+        for (int lt = 0; lt < 13; ++lt) a0 = fmaf(s_v[lt], w0reg[lt], a0);
+        a0 = fmaxf(a0 + bias0, 0.f);
+        if (lane < K) {
+            s_in[0][pc_chain_idx(13, lane)] = a0;         // every wave writes the same value: no barrier before its own reads
+            if (wave == 0) f.c0[(((size_t)(D - 1) * (a.h + 6) + (I - 1)) * (a.w + 6) + J) * K + lane] = a0;
+        }
+        // ---- conv1 ----
+        s_part[0][wave][lane] = chain(s_in[0]);
+        __syncthreads();
+        if (grp == 0) {
+            const float v = (s_part[0][0][lane] + s_part[0][1][lane]) + (s_part[0][2][lane] + s_part[0][3][lane]);
+            const float a1 = fmaxf(v + bias_l, 0.f);
+            s_in[1][pc_chain_idx(13, co)] = a1;
+            if (wave == 0 && v1) f.c1[(((size_t)(D - 2) * (a.h + 4) + (I - 2)) * (a.w + 4) + (J - 1)) * K + co] = a1;
+        }
+        // ---- conv2 + skip ----
+        s_part[1][wave][lane] = chain(s_in[1]);
+        __syncthreads();
+        if (grp == 1) {
+            const float v = (s_part[1][0][lane] + s_part[1][1][lane]) + (s_part[1][2][lane] + s_part[1][3][lane]);
+            float a2 = v + bias_l;
+            a2 += a0;
+            s_in[2][pc_chain_idx(13, co)] = a2;
+            if (wave == 0 && v2) f.c2[(((size_t)(D - 3) * (a.h + 2) + (I - 3)) * (a.w + 2) + (J - 2)) * K + co] = a2;
+        }
+        // ---- conv3 -> logits of the symbol at V[D][I][J + 1] ----
+        float logit = 0.f;
+        if (v3) {
+            s_part[0][wave][lane] = chain(s_in[2]);
+            __syncthreads();
+            const float v = (s_part[0][0][lane] + s_part[0][1][lane]) + (s_part[0][2][lane] + s_part[0][3][lane]);
+            logit = fmaxf(v + bias_l, 0.f);
+        }
+        // next step's coordinates
+        int Dn = D, In = I, Jn = J + 1;
+        if (Jn > J1) { Jn = 0; if (++In > I1) { In = 1; ++Dn; } }
+        if (wave == 0) {
+            if (lane >= 48) s_logits[lane - 48] = logit;  // same wave as thread 0: LDS operations of a wave execute in order
+            if (tid == 0) {
+                float vnext = pad;
+                if (v3) {
+                    const long long idx = ((long long)(D - 4) * a.h + (I - 4)) * a.w + (J - 3);
+                    const int sym = idx == 0 ? a.first_sym : pc_dec_symbol(a, s, s_logits);
+                    a.symbols[idx] = sym;
+                    vnext = s_centers[sym];
+                    a.vol[((size_t)D * PH + I) * PW + J + 1] = vnext;
+                }
+                s_v[12] = vnext;                          // V at the next step's position (pad outside the symbol volume)
+            }
+        }
+        if (Dn > D1) break;
+        // (1,1,0) taps of the next step = this step's voxels: centre slot -> tap-12 slot
+        if (tid >= 64 && tid < 64 + 3 * K) {
+            const int e = tid - 64, l2 = e / K, c = e - l2 * K;
+            s_in[l2][pc_chain_idx(12, c)] = s_in[l2][pc_chain_idx(13, c)];
+        }
+        D = Dn; I = In; J = Jn;
+        prefetch(D, I, J);
+    }
+    if (tid == 0) *f.status = s.error;
+}
+
 static size_t pc_dec_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// activation caches of pc_dec_cached_kernel (k = 24): the three feature volumes of the padded symbol volume, channels-last
+static size_t pc_dec_cache_floats(int C, int h, int w, int k, int layer) {
+    return (size_t)k * (C + 3 - layer) * (h + 6 - 2 * layer) * (w + 6 - 2 * layer);
+}
+static size_t pc_dec_cache_bytes(int C, int h, int w, int k) {
+    if (k != 24) return 0;
+    size_t b = 0;
+    for (int l = 0; l < 3; ++l) b += pc_dec_align(pc_dec_cache_floats(C, h, w, k, l) * sizeof(float));
+    return b;
+}
 
 extern "C" size_t ic_pc_decode_workspace_bytes(int C, int h, int w, int k) {
     if (C <= 0 || h <= 0 || w <= 0 || k <= 0) return 0;
     return pc_dec_align((size_t)(C + 4) * (h + 8) * (w + 8) * sizeof(float)) + pc_dec_align(405 * sizeof(float)) +
-           pc_dec_align(16 * sizeof(float)) + pc_dec_align(sizeof(PcDecState)) + ic_pc_workspace_bytes(1, 1, 1, 1, k);
+           pc_dec_align(16 * sizeof(float)) + pc_dec_align(sizeof(PcDecState)) + ic_pc_workspace_bytes(1, 1, 1, 1, k) +
+           pc_dec_cache_bytes(C, h, w, k);
 }
 
 extern "C" int ic_pc_decode_f32(const uint8_t* bitstream, long long nbytes, int first_sym, const float* const* wtab_host,
@@ -1183,6 +1368,21 @@ extern "C" int ic_pc_decode_f32(const uint8_t* bitstream, long long nbytes, int 
     a.st = (PcDecState*)p; p += pc_dec_align(sizeof(PcDecState));
     void* pcws = p;
     const size_t pcws_bytes = ic_pc_workspace_bytes(1, 1, 1, 1, k);
+    p += pcws_bytes;
+    hipLaunchKernelGGL(pc_dec_fill_kernel, dim3((unsigned)((nvol + 255) / 256)), dim3(256), 0, st, a.vol, nvol, centers);
+    if (k == 24 && !(flags & (IC_PC_DECODE_PER_LAYER | IC_PC_DECODE_RECOMPUTE))) {
+        PcCachedArgs f{};
+        f.d = a;
+        f.w0 = wtab_host[0]; f.b0 = wtab_host[1]; f.w1 = wtab_host[2]; f.b1 = wtab_host[3];
+        f.w2 = wtab_host[4]; f.b2 = wtab_host[5]; f.w3 = wtab_host[6]; f.b3 = wtab_host[7];
+        f.c0 = (float*)p; p += pc_dec_align(pc_dec_cache_floats(C, h, w, k, 0) * sizeof(float));
+        f.c1 = (float*)p; p += pc_dec_align(pc_dec_cache_floats(C, h, w, k, 1) * sizeof(float));
+        f.c2 = (float*)p;
+        f.status = status;
+        hipLaunchKernelGGL(pc_dec_cached_kernel, dim3(1), dim3(256), 0, st, f);
+        IC_LAUNCH_CHECK();
+        return IC_OK;
+    }
     // filters packed once (pc_forward's own layout: after the three feature volumes of the 5x9x9 context)
     const bool use_mfma = pc_mfma_supported(k, L);
     if (use_mfma) {
@@ -1190,7 +1390,6 @@ extern "C" int ic_pc_decode_f32(const uint8_t* bitstream, long long nbytes, int 
         const int rc = pc_pack_filters(wtab_host, k, L, pk1, st);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(pc_dec_fill_kernel, dim3((unsigned)((nvol + 255) / 256)), dim3(256), 0, st, a.vol, nvol, centers);
     if (use_mfma && k == 24 && !(flags & IC_PC_DECODE_PER_LAYER)) {
         PcFusedArgs f{};
         f.d = a;

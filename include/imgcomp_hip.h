@@ -68,6 +68,9 @@ typedef void* ic_stream_t;
 #define IC_EDGE_TILES_PER_WG(n)   ((n) & 0xff)
 /* ic_pc_decode_f32: always the launch-per-layer loop, also for k = 24 (tests) */
 #define IC_PC_DECODE_PER_LAYER    0x01
+/* ic_pc_decode_f32, k = 24: the persistent work-group that recomputes each symbol's whole 5x9x9 context (round-1 kernel)
+ * instead of the one with activation caches (tests, A/B) */
+#define IC_PC_DECODE_RECOMPUTE    0x02
 
 int ic_abi_version(void);
 /* static string for a return code of this library (hipGetErrorString for codes > 0) */
@@ -239,7 +242,8 @@ int ic_pc_logits_to_freqs_f32(const float* logits, long long count, int L, float
  *   symbols: out, device int64 (C,h,w);  status: out, device int (0 ok, 1 = a table's total exceeded the coder's range)
  *   wtab_host / k / L as ic_pc_logits_f32.  workspace: ic_pc_decode_workspace_bytes(C, h, w, k). */
 size_t ic_pc_decode_workspace_bytes(int C, int h, int w, int k);
-/* flags: IC_PC_DECODE_PER_LAYER forces the launch-per-layer loop (tests); 0 lets k = 24 run as one persistent work-group */
+/* flags: 0 lets k = 24 run as ONE persistent work-group with activation caches (one new voxel per layer per symbol);
+ * IC_PC_DECODE_RECOMPUTE: the persistent work-group without caches; IC_PC_DECODE_PER_LAYER: the launch-per-layer loop */
 int ic_pc_decode_f32(const uint8_t* bitstream, long long nbytes, int first_sym, const float* const* wtab_host,
                      const float* centers, int k, int L, float resolution, int64_t* symbols, int* status,
                      int C, int h, int w, void* workspace, size_t workspace_bytes, int flags, ic_stream_t stream);

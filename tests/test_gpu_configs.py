@@ -109,8 +109,14 @@ def test_cfg4_real_bpp_full_kodak_volume(cuda):
     finally:
         os.remove(path)
     assert len(data) * 8 == nbits
+    import time
+    torch.cuda.synchronize()
+    t0 = time.time()
     out = pred.decode_stream(data, sym.shape, first)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
     assert np.array_equal(out, sym), 'device decoder lost sync on a full Kodak volume'
+    print('cfg4: on-device decode {:.2f} s = {:.2f} us per symbol'.format(dt, dt / sym.size * 1e6))
     bits_theory = checker.get_total_bit_cost(sym)
     assert abs(nbits - bits_theory) < 0.01 * bits_theory + 64            # val.py:279-281: "up to 1 %"
     print('cfg4: {} symbols, {} bits coded, {:.1f} bits cross-entropy ({:+.3f} %)'.format(sym.size, nbits, bits_theory,

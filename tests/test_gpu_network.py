@@ -195,9 +195,11 @@ def test_device_decoder_stream(cuda, configs, syn_weights, nets, tmp_path):
     nbits, first, _ = bit_counter._encode(fd, padded, sym, pred)
     data = open(path, 'rb').read()
     assert len(data) * 8 == nbits
-    out = pred.decode_stream(data, sym.shape, first)                        # k = 24: one persistent work-group
+    out = pred.decode_stream(data, sym.shape, first)                        # k = 24: one persistent work-group, activation caches
     assert out.dtype == np.int64 and np.array_equal(out, sym)
     from imgcomp_cvpr_amd import _lib
+    out1 = pred.decode_stream(data, sym.shape, first, flags=_lib.PC_DECODE_RECOMPUTE)      # the same without caches (round-1 kernel)
+    assert np.array_equal(out1, sym)
     out2 = pred.decode_stream(data, sym.shape, first, flags=_lib.PC_DECODE_PER_LAYER)      # the launch-per-layer loop (any k)
     assert np.array_equal(out2, sym)
     ref = pred.undo_pad_symbols_volume(bit_counter._decode(path, padded.shape, pred.input_ctx_shape, first, pred.get_freqs))
