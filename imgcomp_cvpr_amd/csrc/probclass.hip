@@ -916,6 +916,63 @@ __device__ int pc_dec_symbol(const PcDecArgs& a, PcDecState& s, const float* log
     return sym;
 }
 
+// n / d for n < 2^63, d < 2^34, n / d < 2^34: the double-precision quotient is within 2^-18 of the true one, so its integer
+// part is off by at most one; one exact 64-bit multiply decides.  (The 64-bit integer division the compiler expands to is
+// ~4x the instructions, and the sequential decoder does three per symbol on its critical path.)
+__device__ __forceinline__ unsigned long long pc_udiv(unsigned long long n, unsigned long long d) {
+    unsigned long long q = (unsigned long long)((double)n / (double)d);
+    const long long rem = (long long)(n - q * d);
+    if (rem < 0) --q; else if ((unsigned long long)rem >= d) ++q;
+    return q;
+}
+
+// pc_dec_symbol for a whole wave: lane 48 + j holds logit j (0 beyond L -- logits are >= 0 after the ReLU, so the extra
+// lanes do not move the maximum), the coder state is identical in every lane.  The per-symbol table is the expression of
+// pc_table_row with its L exponentials, divisions and conversions spread over L lanes; the sum runs over readlane values in
+// j order (0 + e0 + e1 + ...: the same fp32 sequence).  Returns the symbol (uniform).
+template <int LC>       // LC = number of centres when known at compile time (the loops over readlane unroll), 0 = a.L
+__device__ __forceinline__ int pc_dec_symbol_wave(const PcDecArgs& a, PcDecState& s, float logit) {
+    const unsigned long long MASK = (1ull << PC_AC_BITS) - 1, TOP = 1ull << (PC_AC_BITS - 1), SECOND = TOP >> 1;
+    const unsigned long long MAX_TOTAL = (1ull << (PC_AC_BITS - 2)) + 2;
+    const int L = LC ? LC : a.L, lane = threadIdx.x & 63;
+    auto bcast = [](float v, int src) -> float { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); };
+    float m = bcast(logit, 48);
+#pragma unroll
+    for (int j = 1; j < L; ++j) m = fmaxf(m, bcast(logit, 48 + j));
+    const float e = (lane >= 48 && lane < 48 + L) ? expf(logit - m) : 0.f;
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < L; ++j) sum += bcast(e, 48 + j);
+    const float pr = e / sum;
+    long long fl = (long long)__fmul_rn(pr, a.resolution);
+    fl = fl < 1 ? 1 : fl;
+    const unsigned f32 = (unsigned)fl;                   // <= resolution < 2^31 (total is checked against 2^30 + 2 below)
+    unsigned long long total = 0;
+#pragma unroll
+    for (int j = 0; j < L; ++j) total += (unsigned)__builtin_amdgcn_readlane((int)f32, 48 + j);
+    if (total > MAX_TOTAL || (fl >> 31) != 0) s.error = 1;
+    const unsigned long long r = s.high - s.low + 1;
+    const unsigned long long value = pc_udiv((s.code - s.low + 1) * total - 1, r);
+    int sym = 0;
+    unsigned long long cum = 0;
+    unsigned fs = (unsigned)__builtin_amdgcn_readlane((int)f32, 48);
+    while (sym + 1 < L && cum + fs <= value) { cum += fs; ++sym; fs = (unsigned)__builtin_amdgcn_readlane((int)f32, 48 + sym); }
+    const unsigned long long cum_lo = cum, cum_hi = cum + fs;
+    s.high = s.low + pc_udiv(cum_hi * r, total) - 1;
+    s.low = s.low + pc_udiv(cum_lo * r, total);
+    while (((s.low ^ s.high) & TOP) == 0) {
+        s.code = ((s.code << 1) & MASK) | (unsigned)pc_dec_bit(a, s);
+        s.low = (s.low << 1) & MASK;
+        s.high = ((s.high << 1) & MASK) | 1;
+    }
+    while ((s.low & ~s.high & SECOND) != 0) {
+        s.code = (s.code & TOP) | ((s.code << 1) & (MASK >> 1)) | (unsigned)pc_dec_bit(a, s);
+        s.low = (s.low << 1) & (MASK >> 1);
+        s.high = ((s.high << 1) & (MASK >> 1)) | TOP | 1;
+    }
+    return sym;
+}
+
 __device__ __forceinline__ void pc_dec_store(const PcDecArgs& a, long long idx, int sym) {
     const int HW = a.h * a.w;
     const int c = (int)(idx / HW), rr = (int)(idx - (long long)c * HW);
@@ -1188,10 +1245,9 @@ __device__ __forceinline__ int pc_chain_idx(int t, int ci) { return 8 * ((ci >> 
 __global__ __launch_bounds__(256) void pc_dec_cached_kernel(const PcCachedArgs f) {
     constexpr int K = 24, KT = PC_NT * K;                 // 336 inputs per output
     __shared__ __attribute__((aligned(16))) float s_in[3][KT];          // inputs of conv1 / conv2 / conv3 in chain order
-    __shared__ float s_v[16];                             // the 13 live taps of conv0
+    __shared__ __attribute__((aligned(16))) float s_v[16];              // the 13 live taps of conv0
     __shared__ float s_part[2][4][64];
     __shared__ float s_centers[16];
-    __shared__ float s_logits[16];
     const PcDecArgs& a = f.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int L = a.L;
@@ -1236,13 +1292,16 @@ __global__ __launch_bounds__(256) void pc_dec_cached_kernel(const PcCachedArgs f
         }
         if (tid < 12) pv = a.vol[((size_t)(D - 1 + vkd) * PH + (I - 1 + vkh)) * PW + J + vkw];
     };
-    PcDecState s;
-    if (tid == 0) {
-        s.low = 0; s.high = (1ull << PC_AC_BITS) - 1; s.code = 0;
-        s.byte_pos = -1; s.bit_left = 0; s.cur_byte = 0; s.nxt_byte = a.nbytes > 0 ? a.bits[0] : 0; s.error = 0; s.next = 1;
+    PcDecState s;                                         // wave 0 keeps the coder state, identical in all its lanes
+    s.low = 0; s.high = (1ull << PC_AC_BITS) - 1; s.code = 0;
+    s.byte_pos = -1; s.bit_left = 0; s.cur_byte = 0; s.nxt_byte = a.nbytes > 0 ? a.bits[0] : 0; s.error = 0; s.next = 1;
+    if (wave == 0)
         for (int i = 0; i < PC_AC_BITS; ++i) s.code = (s.code << 1) | (unsigned)pc_dec_bit(a, s);
-        s_v[12] = pad;                                    // V[1][1][0]
-    }
+    if (tid == 0) s_v[12] = pad;                          // V[1][1][0]
+    // LDS hand-over between the waves: wait for this wave's LDS operations only.  (__syncthreads() also waits for the global
+    // stores of the cache voxels to be acknowledged; their readers are a row of steps away and every wave drains its
+    // memory counter at the top of each step, where it consumes its prefetch.)
+    auto lds_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     int D = 1, I = 1, J = 0;
     prefetch(D, I, J);
     // one chain pass: this wave's part of the K sequence for the output this lane holds the weights of
@@ -1257,33 +1316,45 @@ __global__ __launch_bounds__(256) void pc_dec_cached_kernel(const PcCachedArgs f
         }
         return acc;
     };
+#ifdef PC_DEC_PROF
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
+        PC_PH(6);
         // ---- the prefetched taps of this step -> LDS ----
         if (pf_on) *reinterpret_cast<pc_f32x4*>(&s_in[pl][pdst]) = pf;
         if (tid < 12) s_v[tid] = pv;
-        __syncthreads();                                  // also: thread 0's s_v[12] of the previous step
+        lds_barrier();                                    // also: s_v[12] from the previous step's decode
+        PC_PH(0);
         const bool v1 = layer_valid(0, D, I, J), v2 = layer_valid(1, D, I, J), v3 = layer_valid(2, D, I, J);
         // ---- conv0: every lane computes channel lane % 24 (so lane 24 + c holds the skip operand of conv2's output c) ----
         float a0 = 0.f;
+        {
+            const pc_f32x4* v4 = reinterpret_cast<const pc_f32x4*>(s_v);
+            const pc_f32x4 va = v4[0], vb = v4[1], vc = v4[2], vd = v4[3];
+            const float vv[13] = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3], vc[0], vc[1], vc[2], vc[3], vd[0]};
 #pragma unroll
-        for (int lt = 0; lt < 13; ++lt) a0 = fmaf(s_v[lt], w0reg[lt], a0);
+            for (int lt = 0; lt < 13; ++lt) a0 = fmaf(vv[lt], w0reg[lt], a0);
+        }
         a0 = fmaxf(a0 + bias0, 0.f);
         if (lane < K) {
             s_in[0][pc_chain_idx(13, lane)] = a0;         // every wave writes the same value: no barrier before its own reads
             if (wave == 0) f.c0[(((size_t)(D - 1) * (a.h + 6) + (I - 1)) * (a.w + 6) + J) * K + lane] = a0;
         }
+        PC_PH(1);
         // ---- conv1 ----
         s_part[0][wave][lane] = chain(s_in[0]);
-        __syncthreads();
+        lds_barrier();
         if (grp == 0) {
             const float v = (s_part[0][0][lane] + s_part[0][1][lane]) + (s_part[0][2][lane] + s_part[0][3][lane]);
             const float a1 = fmaxf(v + bias_l, 0.f);
             s_in[1][pc_chain_idx(13, co)] = a1;
             if (wave == 0 && v1) f.c1[(((size_t)(D - 2) * (a.h + 4) + (I - 2)) * (a.w + 4) + (J - 1)) * K + co] = a1;
         }
+        PC_PH(2);
         // ---- conv2 + skip ----
         s_part[1][wave][lane] = chain(s_in[1]);
-        __syncthreads();
+        lds_barrier();
         if (grp == 1) {
             const float v = (s_part[1][0][lane] + s_part[1][1][lane]) + (s_part[1][2][lane] + s_part[1][3][lane]);
             float a2 = v + bias_l;
@@ -1291,31 +1362,33 @@ __global__ __launch_bounds__(256) void pc_dec_cached_kernel(const PcCachedArgs f
             s_in[2][pc_chain_idx(13, co)] = a2;
             if (wave == 0 && v2) f.c2[(((size_t)(D - 3) * (a.h + 2) + (I - 3)) * (a.w + 2) + (J - 2)) * K + co] = a2;
         }
+        PC_PH(3);
         // ---- conv3 -> logits of the symbol at V[D][I][J + 1] ----
         float logit = 0.f;
         if (v3) {
             s_part[0][wave][lane] = chain(s_in[2]);
-            __syncthreads();
+            lds_barrier();
             const float v = (s_part[0][0][lane] + s_part[0][1][lane]) + (s_part[0][2][lane] + s_part[0][3][lane]);
             logit = fmaxf(v + bias_l, 0.f);
         }
+        PC_PH(4);
         // next step's coordinates
         int Dn = D, In = I, Jn = J + 1;
         if (Jn > J1) { Jn = 0; if (++In > I1) { In = 1; ++Dn; } }
         if (wave == 0) {
-            if (lane >= 48) s_logits[lane - 48] = logit;  // same wave as thread 0: LDS operations of a wave execute in order
-            if (tid == 0) {
-                float vnext = pad;
-                if (v3) {
-                    const long long idx = ((long long)(D - 4) * a.h + (I - 4)) * a.w + (J - 3);
-                    const int sym = idx == 0 ? a.first_sym : pc_dec_symbol(a, s, s_logits);
+            float vnext = pad;
+            if (v3) {
+                const long long idx = ((long long)(D - 4) * a.h + (I - 4)) * a.w + (J - 3);
+                const int sym = idx == 0 ? a.first_sym : (L == 6 ? pc_dec_symbol_wave<6>(a, s, logit) : pc_dec_symbol_wave<0>(a, s, logit));
+                vnext = s_centers[sym];
+                if (lane == 0) {
                     a.symbols[idx] = sym;
-                    vnext = s_centers[sym];
                     a.vol[((size_t)D * PH + I) * PW + J + 1] = vnext;
                 }
-                s_v[12] = vnext;                          // V at the next step's position (pad outside the symbol volume)
             }
+            if (lane == 0) s_v[12] = vnext;               // V at the next step's position (pad outside the symbol volume)
         }
+        PC_PH(5);
         if (Dn > D1) break;
         // (1,1,0) taps of the next step = this step's voxels: centre slot -> tap-12 slot
         if (tid >= 64 && tid < 64 + 3 * K) {
@@ -1326,6 +1399,10 @@ __global__ __launch_bounds__(256) void pc_dec_cached_kernel(const PcCachedArgs f
         prefetch(D, I, J);
     }
     if (tid == 0) *f.status = s.error;
+#ifdef PC_DEC_PROF
+    if (tid == 0) printf("pc_dec_cached phases (clocks, thread 0): wait+stage %llu | conv0 %llu | conv1 %llu | conv2 %llu | conv3 %llu | decode %llu | tail+prefetch issue %llu\n",
+                         ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
+#endif
 }
 
 static size_t pc_dec_align(size_t b) { return (b + 255) & ~(size_t)255; }
