@@ -114,6 +114,7 @@ PROTOTYPES = {
                         [c_void_p, c_size_t, c_void_p]),
     'ic_channel_sum_workspace_bytes': (c_size_t, [c_int]),
     'ic_channel_sum_f32': (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p, c_void_p]),
+    'ic_adam_tf_f32': (c_int, [c_void_p] * 4 + [c_longlong] + [c_float] * 4 + [c_void_p]),
     'ic_stream_create_cu_range': (c_int, [c_int, c_int, POINTER(c_void_p)]),
     'ic_stream_destroy': (c_int, [c_void_p]),
     'ic_event_create': (c_int, [POINTER(c_void_p)]),

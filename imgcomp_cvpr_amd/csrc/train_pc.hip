@@ -192,3 +192,43 @@ extern "C" int ic_channel_sum_f32(const float* x, float* out, int N, int C, int 
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
+
+// ---- tf.train.AdamOptimizer on a flat bucket (train.py:339-349 via training_helpers.py:38-48) ------------------------------
+//   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g g;  var -= lr_t m / (sqrt(v) + eps)      (epsilon OUTSIDE the bias correction;
+//   lr_t = lr sqrt(1 - b2^t) / (1 - b1^t) comes from the host).  One pass over four arrays instead of seven multi-tensor
+//   passes: parameters, gradients and both slots of a variable group share one flat layout.
+__global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                      float* __restrict__ v, long long n, float lr_t, float b1, float b2, float eps) {
+    const float c1 = 1.f - b1, c2 = 1.f - b2;
+    const long long n4 = n >> 2;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float* pa = &pp.x; float* ma = &mm.x; float* va = &vv.x; const float* ga = &gg.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ma[j] = fmaf(c1, ga[j], ma[j] * b1);
+            va[j] = fmaf(c2 * ga[j], ga[j], va[j] * b2);
+            pa[j] = fmaf(-lr_t, ma[j] / (sqrtf(va[j]) + eps), pa[j]);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    for (long long i = 4 * n4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i];
+        const float mi = fmaf(c1, gi, m[i] * b1), vi = fmaf(c2 * gi, gi, v[i] * b2);
+        m[i] = mi; v[i] = vi;
+        p[i] = fmaf(-lr_t, mi / (sqrtf(vi) + eps), p[i]);
+    }
+}
+
+extern "C" int ic_adam_tf_f32(float* var, const float* grad, float* m, float* v, long long count, float lr_t, float beta1,
+                              float beta2, float eps, ic_stream_t stream) {
+    IC_CHECK_ARG(var && grad && m && v && count > 0);
+    if ((((size_t)var | (size_t)grad | (size_t)m | (size_t)v) & 15) != 0) return IC_ERR_ARG;      // 16-byte accesses
+    const long long blocks = (count / 4 + 255) / 256;
+    hipLaunchKernelGGL(adam_tf_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks))), dim3(256), 0,
+                       (hipStream_t)stream, var, grad, m, v, count, lr_t, beta1, beta2, eps);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}

@@ -140,16 +140,24 @@ class TrainGraph(object):
         for n in self.trainable:
             groups['pc' if n.startswith('probclass3d/') else ('dec' if n.startswith(_weights.DEC) else 'enc')].append(n)
         self.group_names = groups
-        self.flat_grads, self.grads = {}, OrderedDict()
+        # Variables and gradients of a group live in two flat buffers with ONE layout (every tensor starts on a 256-byte
+        # boundary): a bucket is all-reduced as one message and updated by one fused Adam launch (ic_adam_tf_f32).
+        self.flat_grads, self.flat_params, self.grads = {}, {}, OrderedDict()
         for g, names in groups.items():
-            total = sum(self.trainable[n].numel() for n in names)
-            flat = torch.zeros(total, dtype=torch.float32, device=self.dev)
-            self.flat_grads[g] = flat
-            off = 0
+            offs, total = [], 0
             for n in names:
-                k = self.trainable[n].numel()
-                self.grads[n] = flat[off:off + k].view(self.trainable[n].shape)
-                off += k
+                offs.append(total)
+                total += (self.trainable[n].numel() + 63) // 64 * 64
+            flat = torch.zeros(total, dtype=torch.float32, device=self.dev)
+            flat_p = torch.zeros(total, dtype=torch.float32, device=self.dev)
+            self.flat_grads[g], self.flat_params[g] = flat, flat_p
+            for n, off in zip(names, offs):
+                t = self.trainable[n]
+                k = t.numel()
+                view = flat_p[off:off + k].view(t.shape)
+                view.copy_(t)
+                self.params[n] = self.trainable[n] = view
+                self.grads[n] = flat[off:off + k].view(t.shape)
         # ---- constants and scratch ----
         self.ones = torch.ones(256, device=self.dev)
         self.zeros = torch.zeros(256, device=self.dev)
@@ -802,17 +810,38 @@ class TFAdam(object):
     lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t); var -= lr_t * m / (sqrt(v) + eps)  (epsilon outside the bias
     correction, unlike torch.optim.Adam)."""
 
-    def __init__(self, params, grads, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    def __init__(self, params, grads, lr, beta1=0.9, beta2=0.999, eps=1e-8, flat=None):
+        """flat: [(flat_params, flat_grads), ...] -- buffers that params / grads are views of, in one common layout (TrainGraph's
+        buckets).  The step is then ONE fused launch per buffer pair (ic_adam_tf_f32) and m / v are views of flat slot buffers;
+        without it, seven multi-tensor passes over the tensor lists."""
         self.params, self.grads = list(params), list(grads)
         self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
-        self.m = [torch.zeros_like(p) for p in self.params]
-        self.v = [torch.zeros_like(p) for p in self.params]
+        self.flat = None
+        if flat:
+            self.flat = [(fp, fg, torch.zeros_like(fp), torch.zeros_like(fp)) for fp, fg in flat]
+
+            def slot(p, which):
+                for fp, _, fm, fv in self.flat:
+                    off = (p.data_ptr() - fp.data_ptr()) // 4
+                    if 0 <= off < fp.numel() and p.data_ptr() >= fp.data_ptr():
+                        return (fm, fv)[which][off:off + p.numel()].view(p.shape)
+                raise ValueError('a parameter is not a view of the flat buffers')
+            self.m = [slot(p, 0) for p in self.params]
+            self.v = [slot(p, 1) for p in self.params]
+        else:
+            self.m = [torch.zeros_like(p) for p in self.params]
+            self.v = [torch.zeros_like(p) for p in self.params]
         self.t = 0
 
     def step(self, lr=None):
         self.t += 1
         lr = self.lr if lr is None else lr
         lr_t = lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        if self.flat:
+            for fp, fg, fm, fv in self.flat:
+                check(lib.ic_adam_tf_f32(ptr(fp), ptr(fg), ptr(fm), ptr(fv), fp.numel(), lr_t, self.b1, self.b2, self.eps,
+                                         _lib.current_stream(fp.device)), 'ic_adam_tf_f32')
+            return
         torch._foreach_mul_(self.m, self.b1)
         torch._foreach_add_(self.m, self.grads, alpha=1.0 - self.b1)
         torch._foreach_mul_(self.v, self.b2)
@@ -850,8 +879,10 @@ class Trainer(object):
         ae_names = g.group_names['enc'] + g.group_names['dec']
         pc_names = g.group_names['pc']
         self._ae_names, self._pc_names = ae_names, pc_names
-        self.opt_ae = TFAdam([g.trainable[n] for n in ae_names], [g.grads[n] for n in ae_names], float(ae_config.lr_initial))
-        self.opt_pc = TFAdam([g.trainable[n] for n in pc_names], [g.grads[n] for n in pc_names], float(pc_config.lr_initial))
+        self.opt_ae = TFAdam([g.trainable[n] for n in ae_names], [g.grads[n] for n in ae_names], float(ae_config.lr_initial),
+                             flat=[(g.flat_params[k], g.flat_grads[k]) for k in ('enc', 'dec')])
+        self.opt_pc = TFAdam([g.trainable[n] for n in pc_names], [g.grads[n] for n in pc_names], float(pc_config.lr_initial),
+                             flat=[(g.flat_params['pc'], g.flat_grads['pc'])])
         self.num_itr_per_epoch = num_itr_per_epoch
         self.global_step = 0
 

@@ -359,6 +359,10 @@ int ic_pc_wgrad_f32(const float* U, const float* q, float pad_value, const float
                     void* workspace, size_t workspace_bytes, ic_stream_t stream);
 size_t ic_channel_sum_workspace_bytes(int C);
 int ic_channel_sum_f32(const float* x, float* out, int N, int C, int M, void* workspace, ic_stream_t stream);
+/* tf.train.AdamOptimizer step on a flat bucket (train.py:339-349, training_helpers.py:38-48): var, m, v updated in place;
+ * lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) from the host; epsilon outside the bias correction.  16-byte aligned pointers. */
+int ic_adam_tf_f32(float* var, const float* grad, float* m, float* v, long long count, float lr_t, float beta1,
+                   float beta2, float eps, ic_stream_t stream);
 /* The context-model backward reads the three feature volumes ic_pc_bitcost_f32 left in its workspace
  * (layout: conv0 out (N,k,C+3,h+6,w+6) | res1/conv1 out (N,k,C+2,h+4,w+4) | res1 out (N,k,C+1,h+2,w+2) | packed
  * filters): keep that workspace untouched between the forward call and the ic_pc_* backward calls. */
