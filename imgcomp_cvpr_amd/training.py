@@ -203,9 +203,10 @@ class TrainGraph(object):
                                                      self._st()), 'batched winograd pack')
         self._wino_pk = self._w3_buf
 
-    def _conv3x3(self, x, name, backward=False):
-        """raw 3x3 128->128 conv (backward: its adjoint = the data gradient).  name: a parameter name -- its fragments
-        come from this step's batched packing when there is one -- or a filter tensor in the TF layout."""
+    def _conv3x3(self, x, name, backward=False, res1=None, res2=None):
+        """raw 3x3 128->128 conv (backward: its adjoint = the data gradient), + res1 + res2 in the kernel's epilogue (the skip
+        gradients of the residual stack: (conv + res1) + res2, the order the separate adds had).  name: a parameter name -- its
+        fragments come from this step's batched packing when there is one -- or a filter tensor in the TF layout."""
         N, _, H, W = x.shape
         y = self._new(N, 128, H, W)
         st = self._st()
@@ -216,13 +217,13 @@ class TrainGraph(object):
             else:
                 wp = self._new(lib.ic_wino3x3_c128_packed_floats())
                 check(lib.ic_pack_wino3x3_c128_f32(ptr(w_tf), ptr(wp), int(backward), st))
-            check(lib.ic_wino3x3_c128_bn_act_f32(ptr(x), ptr(wp), ptr(self.ones), ptr(self.zeros), None, None, ptr(y),
+            check(lib.ic_wino3x3_c128_bn_act_f32(ptr(x), ptr(wp), ptr(self.ones), ptr(self.zeros), ptr(res1), ptr(res2), ptr(y),
                                                  N, H, W, 0, 0, st), 'conv3x3 (winograd)')
         else:
             wp = self._new(lib.ic_conv3x3_c128_packed_floats())
             f = lib.ic_pack_conv3x3_c128_bwd_f32 if backward else lib.ic_pack_conv3x3_c128_f32
             check(f(ptr(w_tf), ptr(wp), st))
-            check(lib.ic_conv3x3_c128_bn_act_f32(ptr(x), ptr(wp), ptr(self.ones), ptr(self.zeros), None, None, ptr(y),
+            check(lib.ic_conv3x3_c128_bn_act_f32(ptr(x), ptr(wp), ptr(self.ones), ptr(self.zeros), ptr(res1), ptr(res2), ptr(y),
                                                  N, H, W, 0, 0, st), 'conv3x3')
         return y
 
@@ -264,15 +265,19 @@ class TrainGraph(object):
             return self._conv_s(x, w, l.kh, l.kw, l.cin, l.cout, l.stride)
         return self._deconv_s(x, w, l.kh, l.kw, l.cin, l.cout)
 
-    def _raw_backward_data(self, l, g):
-        """gradient wrt the layer input of the raw conv (g = gradient wrt its output)."""
+    def _raw_backward_data(self, l, g, add1=None, add2=None):
+        """gradient wrt the layer input of the raw conv (g = gradient wrt its output), + add1 + add2."""
         w = self.params[l.scope + '/weights']
         if l.kind == 'conv' and l.kh == 3 and l.cin == 128 and l.cout == 128:
-            return self._conv3x3(g, l.scope + '/weights', backward=True)
+            return self._conv3x3(g, l.scope + '/weights', backward=True, res1=add1, res2=add2)
         if l.kind == 'conv':      # adjoint of a strided conv = transposed conv with the SAME array read as [kh,kw,out=cin,in=cout]
-            return self._deconv_s(g, w, l.kh, l.kw, l.cout, l.cin)
-        # adjoint of a transposed conv = strided conv with the same array read as [kh,kw,cin=cout_l,cout=cin_l]
-        return self._conv_s(g, w, l.kh, l.kw, l.cout, l.cin, 2)
+            dx = self._deconv_s(g, w, l.kh, l.kw, l.cout, l.cin)
+        else:                     # adjoint of a transposed conv = strided conv with the same array read as [kh,kw,cin=cout_l,cout=cin_l]
+            dx = self._conv_s(g, w, l.kh, l.kw, l.cout, l.cin, 2)
+        for a in (add1, add2):
+            if a is not None:
+                dx = dx + a
+        return dx
 
     def _wgrad(self, l, x_in, g):
         N = x_in.shape[0]
@@ -335,7 +340,7 @@ class TrainGraph(object):
             tape.append((l, x, raw, mean, invstd, scale, shift, relu))
         return y
 
-    def _cba_bwd(self, rec, dy, need_dx=True):
+    def _cba_bwd(self, rec, dy, need_dx=True, add1=None, add2=None):
         l, x, raw, mean, invstd, scale, shift, relu = rec
         N, Cc, H, W = raw.shape
         draw = self._new(N, Cc, H, W)
@@ -357,7 +362,7 @@ class TrainGraph(object):
                                                ptr(sums), N * H * W * world, ptr(draw), N, Cc, H * W, int(relu), self._st()),
                   'bn backward apply')
         self._wgrad(l, x, draw)
-        return self._raw_backward_data(l, draw) if need_dx else None
+        return self._raw_backward_data(l, draw, add1, add2) if need_dx else None
 
     # ---- residual stack (autoencoder.py:224-234 / :252-262) ----
     def _stack_names(self, kind):
@@ -383,8 +388,9 @@ class TrainGraph(object):
         recs = list(tape)
         # final block: out = conv2(conv1(net)) + net + res0
         g_res0 = g
+        # the skip gradients ride in the epilogue of the data-gradient conv: (conv path + skip) + group skip
         gt = self._cba_bwd(recs.pop(), g)
-        g_net = g + self._cba_bwd(recs.pop(), gt)
+        g_net = self._cba_bwd(recs.pop(), gt, add1=g)
         for b in reversed(range(self.B)):
             g_resb = None
             for i in (2, 1, 0):
@@ -392,8 +398,7 @@ class TrainGraph(object):
                 if i == 2:
                     g_resb = gout                              # group skip taps the last block's output sum
                 gt = self._cba_bwd(recs.pop(), gout)
-                g_net = gout + self._cba_bwd(recs.pop(), gt)   # block input: skip + conv path
-            g_net = g_net + g_resb
+                g_net = self._cba_bwd(recs.pop(), gt, add1=gout, add2=g_resb if i == 0 else None)   # block input: skip + conv path
         assert not recs
         return g_net + g_res0
 
