@@ -102,6 +102,8 @@ PROTOTYPES = {
     'ic_bn_backward_f32': (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p, c_void_p]),
     'ic_conv2d_wgrad_workspace_bytes': (c_size_t, [c_int] * 7),
     'ic_conv2d_wgrad_f32': (c_int, [c_void_p] * 3 + [c_int] * 8 + [c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
+    'ic_conv3x3_c128_wgrad_workspace_bytes': (c_size_t, [c_int] * 3),
+    'ic_conv3x3_c128_wgrad_f32': (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     'ic_pack_conv3x3_c128_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p]),
     'ic_heatmap_quantize_bwd_workspace_bytes': (c_size_t, [c_int]),
     'ic_heatmap_quantize_bwd_f32': (c_int, [c_void_p, c_void_p, c_int, c_float] + [c_void_p] * 4 + [c_int] * 5 +

@@ -279,11 +279,21 @@ class TrainGraph(object):
                 dx = dx + a
         return dx
 
+    WINOGRAD_WGRAD = True     # 3x3 128 -> 128 filter gradients in the Winograd domain (ic_conv3x3_c128_wgrad_f32)
+
     def _wgrad(self, l, x_in, g):
         N = x_in.shape[0]
         dw = self.grads[l.scope + '/weights']
         wd = float(self.ae_config.regularization_factor)
         w = self.params[l.scope + '/weights']
+        if l.kind == 'conv' and l.kh == 3 and l.cin == 128 and l.cout == 128 and self.WINOGRAD_WGRAD:
+            H, W = x_in.shape[2], x_in.shape[3]
+            need = lib.ic_conv3x3_c128_wgrad_workspace_bytes(N, H, W)
+            if need:                                   # 0: odd width / beyond 31-bit offsets -> the direct form below
+                ws = self._scratch('wgrad', need)
+                check(lib.ic_conv3x3_c128_wgrad_f32(ptr(x_in), ptr(g), ptr(dw), N, H, W, ptr(w), wd, ptr(ws), need, self._st()),
+                      'winograd wgrad ' + l.scope)
+                return
         if l.kind == 'conv':
             U, V, A, Bc, UH, UW = x_in, g, l.cin, l.cout, x_in.shape[2], x_in.shape[3]
         else:

@@ -336,6 +336,13 @@ size_t ic_conv2d_wgrad_workspace_bytes(int N, int A, int B, int VH, int VW, int 
 int ic_conv2d_wgrad_f32(const float* U, const float* V, float* dw, int N, int A, int UH, int UW, int B,
                         int KH, int KW, int stride, const float* w, float wd,
                         void* workspace, size_t workspace_bytes, ic_stream_t stream);
+/* Filter gradient of the 3x3 128 -> 128 layer in the Winograd domain (16/36 of the direct form's multiply-adds):
+ *   dw[ky][kx][ci][co] = sum_{n,y,x} x[n][ci][y+ky-1][x+kx-1] * dy[n][co][y][x]  (+ wd * w),  TF filter layout, SAME padding.
+ * Replaces tf.gradients of the residual blocks' slim.conv2d w.r.t. `weights` (autoencoder.py:274-287).  Even W only and tensors
+ * below 2^31 bytes; IC_ERR_UNSUPPORTED otherwise (workspace query returns 0): use ic_conv2d_wgrad_f32 then. */
+size_t ic_conv3x3_c128_wgrad_workspace_bytes(int N, int H, int W);
+int ic_conv3x3_c128_wgrad_f32(const float* x, const float* dy, float* dw, int N, int H, int W, const float* w, float wd,
+                              void* workspace, size_t workspace_bytes, ic_stream_t stream);
 int ic_pack_conv3x3_c128_bwd_f32(const float* w_tf, float* w_packed, ic_stream_t stream);
 /* importance map + quantiser backward (autoencoder.py:127-134,171-200; quantizer.py:43-100): d_qbar, d_heatmap
  * (nullable) -> d_bottleneck (N,C+1,h,w), d_centers (L).  workspace: ic_heatmap_quantize_bwd_workspace_bytes(L). */

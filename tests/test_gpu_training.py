@@ -61,6 +61,39 @@ def test_bn_train_forward_backward(cuda):
         assert_close(dx, xt.grad, 'bn dx', 1e-5)
 
 
+@pytest.mark.parametrize('N,H,W', [(2, 16, 16), (1, 12, 20), (1, 7, 8), (3, 9, 34), (32, 32, 32)])
+def test_winograd_filter_gradient(cuda, N, H, W):
+    """ic_conv3x3_c128_wgrad_f32 (Winograd-domain GEMMs over all 2x2 tiles) against autograd in float64 on the small shapes and
+    against the direct-form kernel everywhere: ragged chunks of tiles (W = 20: 10 tiles = 8 + 2), odd heights, several slices."""
+    from oracle import train_oracle as T
+    L = _L()
+    rs = np.random.RandomState(N * 100 + H)
+    x = rs.normal(0, 1, (N, 128, H, W)).astype(np.float32)
+    dy = rs.normal(0, 1, (N, 128, H, W)).astype(np.float32)
+    w = rs.normal(0, 0.1, (3, 3, 128, 128)).astype(np.float32)
+    d = lambda a: dev(a, cuda)
+    xd, dyd, wd_ = d(x), d(dy), d(w)
+    need = L.lib.ic_conv3x3_c128_wgrad_workspace_bytes(N, H, W)
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device=cuda)
+    dw = torch.full((3, 3, 128, 128), float('nan'), device=cuda)
+    L.check(L.lib.ic_conv3x3_c128_wgrad_f32(L.ptr(xd), L.ptr(dyd), L.ptr(dw), N, H, W, L.ptr(wd_), 0.25, L.ptr(ws), need,
+                                            L.current_stream()))
+    need2 = L.lib.ic_conv2d_wgrad_workspace_bytes(N, 128, 128, H, W, 3, 3)
+    ws2 = torch.empty(need2, dtype=torch.uint8, device=cuda)
+    dw2 = torch.empty((3, 3, 128, 128), device=cuda)
+    L.check(L.lib.ic_conv2d_wgrad_f32(L.ptr(xd), L.ptr(dyd), L.ptr(dw2), N, 128, H, W, 128, 3, 3, 1, L.ptr(wd_), 0.25,
+                                      L.ptr(ws2), need2, L.current_stream()))
+    torch.cuda.synchronize()
+    assert_close(dw, dw2.double(), 'dW winograd vs direct {}x{}x{}'.format(N, H, W), 2e-5)
+    if N * H * W <= 2048:
+        wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+        y = T._conv(torch.tensor(x, dtype=torch.float64), wt, 1)
+        y.backward(torch.tensor(dy, dtype=torch.float64))
+        assert_close(dw, wt.grad + 0.25 * wt.detach(), 'dW winograd {}x{}x{}'.format(N, H, W), 1e-5)
+    assert L.lib.ic_conv3x3_c128_wgrad_workspace_bytes(1, 8, 9) == 0          # odd width: the direct form serves it
+
+
 @pytest.mark.parametrize('name,kind,N,Cin,Cout,H,W,K,stride', [
     ('res3x3', 'conv', 2, 128, 128, 9, 12, 3, 1),
     ('h2', 'conv', 2, 64, 128, 12, 16, 5, 2),
