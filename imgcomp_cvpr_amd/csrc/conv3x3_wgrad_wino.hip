@@ -33,12 +33,17 @@ struct WwArgs {
     int nchunks, chunks_per_slice;
 };
 
-__device__ __forceinline__ float ww_shr1(float v) {      // lane i <- lane i - 1 (within a row of 16; lane 0 of a row gets 0)
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));
+__device__ __forceinline__ float ww_shr1(float v) {      // lane i <- lane i - 1 within a row of 16 (the row's lane 0: don't care)
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x111, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float ww_shl1(float v) {      // lane i <- lane i + 1
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x101, 0xf, 0xf, true));
 }
+// single adds as inline asm: left to itself the SLP vectoriser packs pairs of them into v_pk_add_f32 and pays for it with
+// register shuffles (53 v_mov per chunk in the first build)
+__device__ __forceinline__ float ww_add(float x, float y) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ float ww_sub(float x, float y) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ float ww_neg(float x) { float r; asm("v_xor_b32 %0, 0x80000000, %1" : "=v"(r) : "v"(x)); return r; }
 
 __global__ __launch_bounds__(256) void wino3x3_c128_wgrad_kernel(const WwArgs a) {
     // [buffer][tile][channel: 0..63 V (ci), 64..127 U (co)][4 float4, slot j at j ^ ((channel >> 2) & 3)].  Consumers read 32
@@ -74,41 +79,46 @@ __global__ __launch_bounds__(256) void wino3x3_c128_wgrad_kernel(const WwArgs a)
     const unsigned v_edge = tj == 0 ? v_own : v_own + 16u;
     const __amdgpu_buffer_rsrc_t xre = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x - 2), 0, tensor_bytes + 8u, 0x00020000);
     f32x2 xv[2][4], xe[2][4], du[2][2];
-    // coordinates of the chunk whose raw operands are being requested (scalars) and its two lane offsets
-    int rq_xbase = 0, rq_gbase = 0, rq_ty = 0;
-    unsigned rq_vo = WN_OOB, rq_ve = WN_OOB;
-    auto raw_setup = [&](int q) __attribute__((always_inline)) {
+    // The chunk whose raw operands are being requested: (image, tile row, chunk column) advance incrementally -- no divisions in
+    // the loop -- and everything that depends on them is prepared ONCE per chunk: the scalar offsets of the first patch / gradient
+    // row and, per patch row, the lane offset with the row's validity already folded in (rows -1 and H.. read as zeros).
+    int rq_n, rq_ty, rq_txc, rq_q;
+    {
         const int per_img = a.tiles_y * a.chunks_x;
-        const bool live = q < q1;
-        const int qq = live ? q : q0;
-        const int n = qq / per_img, rem = qq - n * per_img;
-        const int ty = rem / a.chunks_x, txc = rem - ty * a.chunks_x;
-        const int tx = WW_TC * txc + tj;
+        rq_n = q0 / per_img; const int rem = q0 - rq_n * per_img;
+        rq_ty = rem / a.chunks_x; rq_txc = rem - rq_ty * a.chunks_x; rq_q = q0;
+    }
+    int rq_xbase = 0, rq_gbase = 0;
+    unsigned rq_vo[4], rq_ve[4], rq_vg[2];
+    auto raw_setup = [&]() __attribute__((always_inline)) {          // prepares chunk rq_q, then steps the coordinates to rq_q + 1
+        const bool live = rq_q < q1;
+        const int tx = WW_TC * rq_txc + tj;
         const bool tile_ok = live && tx < a.tiles_x;
         const bool e_ok = tile_ok && (tj == 0 ? tx > 0 : (tj == WW_TC - 1 && 2 * tx + 2 < W));
-        rq_vo = tile_ok ? v_own : WN_OOB; rq_ve = e_ok ? v_edge : WN_OOB;
-        rq_ty = ty;
-        rq_xbase = ((n * WN_C + 64 * cib + 8 * wave) * HW + 2 * WW_TC * txc) * 4;
-        rq_gbase = ((n * WN_C + 64 * cob + 8 * wave) * HW + 2 * WW_TC * txc) * 4;
+        const unsigned vo = tile_ok ? v_own : WN_OOB, ve = e_ok ? v_edge : WN_OOB;
+        const int r0 = 2 * rq_ty - 1;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const bool rok = r0 + r4 >= 0 && r0 + r4 < H;            // uniform
+            rq_vo[r4] = rok ? vo : WN_OOB; rq_ve[r4] = rok ? ve : WN_OOB;
+        }
+        rq_vg[0] = vo; rq_vg[1] = 2 * rq_ty + 1 < H ? vo : WN_OOB;
+        const int img = live ? rq_n : 0, row = live ? r0 : 0, col = live ? rq_txc : 0;
+        rq_xbase = ((img * WN_C + 64 * cib + 8 * wave) * HW + row * W + 2 * WW_TC * col) * 4;       // patch row 0; may be "row -1": never dereferenced then
+        rq_gbase = ((img * WN_C + 64 * cob + 8 * wave) * HW + (row + 1) * W + 2 * WW_TC * col) * 4;
+        ++rq_q; ++rq_txc;
+        const bool wx = rq_txc == a.chunks_x; rq_txc = wx ? 0 : rq_txc; rq_ty += wx;
+        const bool wy = rq_ty == a.tiles_y; rq_ty = wy ? 0 : rq_ty; rq_n += wy;
     };
     // one request of pass p: i = 0..3 own pair of patch row i, 4..7 edge pair of patch row i - 4, 8..9 gradient row i - 8
     auto raw_load = [&](int p, int i) __attribute__((always_inline)) {
         const int pofs = 32 * p * HW * 4;                         // pass 1: channels + 32
-        if (i < 8) {
-            const int r4 = i & 3, r = 2 * rq_ty - 1 + r4;
-            const bool rok = r >= 0 && r < H;                      // uniform
-            const int so = rok ? rq_xbase + pofs + r * W * 4 : 0;
-            const unsigned v = rok ? (i < 4 ? rq_vo : rq_ve) : WN_OOB;
-            if (i < 4) xv[p][r4] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, v, so, 0));
-            else xe[p][r4] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xre, v, so, 0));
-        } else {
-            const int r2 = i - 8, r = 2 * rq_ty + r2;
-            const bool rok = r < H;
-            du[p][r2] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(gr, rok ? rq_vo : WN_OOB, rok ? rq_gbase + pofs + r * W * 4 : 0, 0));
-        }
+        if (i < 4) xv[p][i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, rq_vo[i], rq_xbase + pofs + i * W * 4, 0));
+        else if (i < 8) xe[p][i - 4] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xre, rq_ve[i - 4], rq_xbase + pofs + (i - 4) * W * 4, 0));
+        else du[p][i - 8] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(gr, rq_vg[i - 8], rq_gbase + pofs + (i - 8) * W * 4, 0));
     };
-    auto load_raw = [&](int q) __attribute__((always_inline)) {
-        raw_setup(q);
+    auto load_raw = [&]() __attribute__((always_inline)) {
+        raw_setup();
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -133,18 +143,18 @@ __global__ __launch_bounds__(256) void wino3x3_c128_wgrad_kernel(const WwArgs a)
             tc[0][r4] = tj == 0 ? xe[p][r4][1] : left;
         } else if (m < 8) {             // Bt d: over the rows of patch column k
             const int k = m - 4;
-            tu[k][0] = tc[k][0] - tc[k][2]; tu[k][1] = tc[k][1] + tc[k][2];
-            tu[k][2] = tc[k][2] - tc[k][1]; tu[k][3] = tc[k][1] - tc[k][3];
+            tu[k][0] = ww_sub(tc[k][0], tc[k][2]); tu[k][1] = ww_add(tc[k][1], tc[k][2]);
+            tu[k][2] = ww_sub(tc[k][2], tc[k][1]); tu[k][3] = ww_sub(tc[k][1], tc[k][3]);
         } else if (m < 12) {            // (Bt d) B: transformed row r4 -> positions 4 r4 .. 4 r4 + 3
             const int r4 = m - 8;
-            const f32x4 v = {tu[0][r4] - tu[2][r4], tu[1][r4] + tu[2][r4], tu[2][r4] - tu[1][r4], tu[1][r4] - tu[3][r4]};
+            const f32x4 v = {ww_sub(tu[0][r4], tu[2][r4]), ww_add(tu[1][r4], tu[2][r4]), ww_sub(tu[2][r4], tu[1][r4]), ww_sub(tu[1][r4], tu[3][r4])};
             rv[wsl[r4]] = v;
         } else {                        // U = A dY At, row i of A dY: [p, q] -> [p, p + q, p - q, -q];  A = [[1,0],[1,1],[1,-1],[0,-1]]
             const int i = m - 12;
             const float d00 = du[p][0][0], d01 = du[p][0][1], d10 = du[p][1][0], d11 = du[p][1][1];
-            const float pp = i == 0 ? d00 : (i == 1 ? d00 + d10 : (i == 2 ? d00 - d10 : -d10));
-            const float qq = i == 0 ? d01 : (i == 1 ? d01 + d11 : (i == 2 ? d01 - d11 : -d11));
-            const f32x4 v = {pp, pp + qq, pp - qq, -qq};
+            const float pp = i == 0 ? d00 : (i == 1 ? ww_add(d00, d10) : (i == 2 ? ww_sub(d00, d10) : ww_neg(d10)));
+            const float qq = i == 0 ? d01 : (i == 1 ? ww_add(d01, d11) : (i == 2 ? ww_sub(d01, d11) : ww_neg(d11)));
+            const f32x4 v = {pp, ww_add(pp, qq), ww_sub(pp, qq), ww_neg(qq)};
             (rv + 64 * 4)[wsl[i]] = v;
         }
     };
@@ -165,19 +175,19 @@ __global__ __launch_bounds__(256) void wino3x3_c128_wgrad_kernel(const WwArgs a)
     auto lds_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
     if (q0 < q1) {
-        load_raw(q0);
+        load_raw();
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
             for (int m = 0; m < 16; ++m) micro(0, p, m);
-        load_raw(q0 + 1);
+        load_raw();
         lds_barrier();
 #pragma unroll
         for (int j = 0; j < 8; ++j) fetch(0, 0, 0, j);
         __builtin_amdgcn_sched_barrier(0);
         for (int q = q0; q < q1; ++q) {
             const int buf = (q - q0) & 1;
-            raw_setup(q + 2);
+            raw_setup();
             // k-steps 0 and 1: the NEXT chunk's two transform passes ride behind the MFMAs (one micro-step per MFMA); operands of
             // k-step s + 1 are fetched behind the first eight MFMAs of k-step s.  Before k-step 3 every wave has written the
             // other buffer: barrier, then k-step 3 fetches the first operands of the next chunk from it.
