@@ -3,7 +3,7 @@
 //   variance, eps 1e-5, decay 0.9), :127-134 (_quantize, qbar = qsoft + stop_gradient(qhard - qsoft)),
 //   :171-200 (heatmap), code/quantizer.py:43-100.
 // All of it is HBM streaming: every kernel reads/writes each activation once, per-channel sums are reduced in
-// float64 in a fixed two-stage order (deterministic, no atomics).
+// float64 in a fixed order by ONE work-group per channel (deterministic, no atomics).
 //
 // forward :  raw = conv(x)                      (conv kernels with scale = 1, shift = 0)
 //            mean, var = ic_bn_stats_f32(raw)   -> host folds scale = gamma / sqrt(var + eps), shift = beta - mean * scale
@@ -13,80 +13,124 @@
 //            ic_bn_bwd_apply_f32  -> draw = gamma * invstd * (g - sum_g / M - xhat * sum_gxhat / M)
 #include "common.h"
 
-#define BN_CHUNKS 64      // stage-1 slices per channel
+#define BN_CHUNKS 64      // (workspace layout of ABI version 1: [C][BN_CHUNKS][2] partials, then the [2][C] sums still used)
 
 struct BnArgs {
     const float* x; const float* dy; const float* scale; const float* shift;
     const float* mean; const float* invstd; const float* gamma;
-    const double* sums;       // [2][C] stage-2 results (sum_g, sum_gxhat)
-    double* partial;          // [C][BN_CHUNKS][2]
+    const double* sums;       // [2][C] (sum_g, sum_gxhat)
+    double* partial;          // workspace
     float* out0; float* out1; // stats: mean, var ; bwd_apply: dx
     int N, C, HW, relu;
-    int nchunks;              // stage-1 slices actually used (<= BN_CHUNKS): each covers >= ~1k elements
     long long count;          // bwd_apply: elements per channel the sums run over (0 = N * HW; larger under sync BatchNorm)
 };
 
-__device__ __forceinline__ void block_reduce2(double& a, double& b) {
-    __shared__ double sa[256], sb[256];
+// ---- one work-group of 1024 threads per channel: sums, and what follows from them, in ONE launch ----------------------------
+// The two-stage form of round 1 cost two launches per reduction (stage 1 over [C][chunks] blocks, stage 2 over the partials) and
+// the forward pass a third for the fold -- 5-6 us each of mostly launch latency, 140 + 70 times per training step.  A channel
+// of the training shapes is 128 K elements: one 1024-thread block streams it in a few microseconds (16-byte loads, 128
+// blocks on 128 CUs), reduces in a fixed order (per-thread double accumulators, LDS tree) and finishes the job itself.
+__device__ __forceinline__ void bn_block_reduce2_1024(double& a, double& b) {
+    __shared__ double sa[1024], sb[1024];
     sa[threadIdx.x] = a; sb[threadIdx.x] = b;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) { sa[threadIdx.x] += sa[threadIdx.x + o]; sb[threadIdx.x] += sb[threadIdx.x + o]; }
         __syncthreads();
     }
     a = sa[0]; b = sb[0];
 }
 
-// MODE 0: (sum x, sum x^2)   MODE 1: (sum g, sum g * xhat)
+// MODE 0: (sum x, sum x^2)   MODE 1: (sum g, sum g * xhat), g = dy masked by the ReLU of the forward pass
 template <int MODE>
-__global__ __launch_bounds__(256) void bn_reduce_stage1(const BnArgs a) {
-    // block (c, chunk): the channel's N * HW elements (N separate planes) are cut into nchunks contiguous runs of whole
-    // 256-element groups; divisions only per block and per plane, none per element
-    const int c = blockIdx.x, chunk = blockIdx.y;
-    const long long E = (long long)a.N * a.HW;
-    const long long per = ((E + a.nchunks - 1) / a.nchunks + 255) / 256 * 256;
-    const long long lo = per * chunk, hi = lo + per < E ? lo + per : E;
+__device__ __forceinline__ void bn_channel_sums(const BnArgs& a, int c, double& s0, double& s1) {
     float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
     if (MODE == 1) { sc = a.scale[c]; sh = a.shift[c]; mu = a.mean[c]; is = a.invstd[c]; }
-    double s0 = 0.0, s1 = 0.0;
-    if (lo < hi) {
-        const int n_lo = (int)(lo / a.HW), n_hi = (int)((hi - 1) / a.HW);
-        for (int n = n_lo; n <= n_hi; ++n) {
-            const size_t base = ((size_t)n * a.C + c) * a.HW;
-            const int p0 = n == n_lo ? (int)(lo - (long long)n * a.HW) : 0;
-            const int p1 = n == n_hi ? (int)(hi - (long long)n * a.HW) : a.HW;
-            for (int p = p0 + threadIdx.x; p < p1; p += 256) {
-                const float xv = a.x[base + p];
-                if (MODE == 0) { s0 += xv; s1 += (double)xv * xv; }
-                else {
-                    float g = a.dy[base + p];
-                    if (a.relu && !(fmaf(xv, sc, sh) > 0.f)) g = 0.f;
-                    s0 += g; s1 += (double)g * ((xv - mu) * is);
-                }
-            }
+    s0 = 0.0; s1 = 0.0;
+    auto acc = [&](float xv, float g) __attribute__((always_inline)) {
+        if (MODE == 0) { s0 += xv; s1 += (double)xv * xv; }
+        else {
+            if (a.relu && !(fmaf(xv, sc, sh) > 0.f)) g = 0.f;
+            s0 += g; s1 += (double)g * ((xv - mu) * is);
+        }
+    };
+    if ((a.HW & 3) == 0) {
+        const int HW4 = a.HW >> 2;
+        const long long E4 = (long long)a.N * HW4;
+        for (long long i = threadIdx.x; i < E4; i += 1024) {
+            const int n = (int)(i / HW4), p4 = (int)(i - (long long)n * HW4);
+            const size_t o = ((size_t)n * a.C + c) * a.HW + 4 * (size_t)p4;
+            const float4 xv = *reinterpret_cast<const float4*>(a.x + o);
+            float4 g = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == 1) g = *reinterpret_cast<const float4*>(a.dy + o);
+            acc(xv.x, g.x); acc(xv.y, g.y); acc(xv.z, g.z); acc(xv.w, g.w);
+        }
+    } else {
+        const long long E = (long long)a.N * a.HW;
+        for (long long i = threadIdx.x; i < E; i += 1024) {
+            const int n = (int)(i / a.HW), p = (int)(i - (long long)n * a.HW);
+            const size_t o = ((size_t)n * a.C + c) * a.HW + p;
+            acc(a.x[o], MODE == 1 ? a.dy[o] : 0.f);
         }
     }
-    block_reduce2(s0, s1);
-    if (threadIdx.x == 0) { a.partial[((size_t)c * BN_CHUNKS + chunk) * 2] = s0; a.partial[((size_t)c * BN_CHUNKS + chunk) * 2 + 1] = s1; }
+    bn_block_reduce2_1024(s0, s1);
 }
 
-template <int MODE>
-__global__ void bn_reduce_stage2(const double* __restrict__ partial, int C, long long M, float* __restrict__ o0,
-                                 float* __restrict__ o1, double* __restrict__ sums, int nchunks) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= C) return;
-    double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < nchunks; ++k) { s0 += partial[((size_t)c * BN_CHUNKS + k) * 2]; s1 += partial[((size_t)c * BN_CHUNKS + k) * 2 + 1]; }
-    if (MODE == 0) {
-        const double m = s0 / (double)M;
-        double v = s1 / (double)M - m * m;        // biased variance (what BN normalises with)
-        if (v < 0.0) v = 0.0;
-        o0[c] = (float)m; o1[c] = (float)v;
-    } else {
-        sums[c] = s0; sums[C + c] = s1;
-        if (o0) o0[c] = (float)s0;                 // dbeta
-        if (o1) o1[c] = (float)s1;                 // dgamma
+// what the forward pass derives from a channel's (sum x, sum x^2) over M elements: invstd, the folded scale/shift and the
+// moving-average update (decay 0.9; TF's fused kernel feeds the UNBIASED variance to the moving average while normalising
+// with the biased one).  One function for the fused and the cross-replica path: the same bits from the same sums.
+__device__ __forceinline__ void bn_fold_channel(int c, double s0, double s1, long long M, const float* gamma, const float* beta,
+                                                float* moving_mean, float* moving_var, float decay, float eps, float* mean,
+                                                float* invstd, float* scale, float* shift) {
+    const double m = s0 / (double)M;
+    double v = s1 / (double)M - m * m;
+    if (v < 0.0) v = 0.0;
+    const float mf = (float)m, vf = (float)v;
+    const float is = 1.0f / sqrtf(vf + eps);
+    const float sc = gamma[c] * is;
+    mean[c] = mf; invstd[c] = is; scale[c] = sc; shift[c] = beta[c] - mf * sc;
+    if (moving_mean) moving_mean[c] = moving_mean[c] * decay + mf * (1.f - decay);
+    if (moving_var) {
+        const float unbiased = vf * (float)((double)M / (double)(M > 1 ? M - 1 : 1));
+        moving_var[c] = moving_var[c] * decay + unbiased * (1.f - decay);
     }
+}
+
+struct BnFoldArgs {
+    const float* gamma; const float* beta; float* moving_mean; float* moving_var; float decay, eps;
+    float* mean; float* invstd; float* scale; float* shift;
+};
+
+// OUT 0: mean / biased variance (ic_bn_stats_f32)   1: the sums as doubles (cross-replica path)   2: the whole fold
+template <int OUT>
+__global__ __launch_bounds__(1024) void bn_channel_stats_kernel(const BnArgs a, double* __restrict__ sums, const BnFoldArgs f) {
+    const int c = blockIdx.x;
+    double s0, s1;
+    bn_channel_sums<0>(a, c, s0, s1);
+    if (threadIdx.x != 0) return;
+    const long long M = (long long)a.N * a.HW;
+    if (OUT == 0) {
+        const double m = s0 / (double)M;
+        double v = s1 / (double)M - m * m;
+        if (v < 0.0) v = 0.0;
+        a.out0[c] = (float)m; a.out1[c] = (float)v;
+    } else if (OUT == 1) {
+        sums[c] = s0; sums[a.C + c] = s1;
+    } else {
+        bn_fold_channel(c, s0, s1, M, f.gamma, f.beta, f.moving_mean, f.moving_var, f.decay, f.eps, f.mean, f.invstd, f.scale, f.shift);
+    }
+}
+
+// backward: (sum g, sum g xhat) -> sums[2][C] (doubles, for the data gradient) and dbeta / dgamma
+__global__ __launch_bounds__(1024) void bn_channel_bwd_sums_kernel(const BnArgs a, double* __restrict__ sums, float* __restrict__ dbeta,
+                                                                   float* __restrict__ dgamma) {
+    const int c = blockIdx.x;
+    double s0, s1;
+    bn_channel_sums<1>(a, c, s0, s1);
+    if (threadIdx.x != 0) return;
+    sums[c] = s0; sums[a.C + c] = s1;
+    if (dbeta) dbeta[c] = (float)s0;
+    if (dgamma) dgamma[c] = (float)s1;
 }
 
 // grid (plane chunks, N*C planes): one (n, c) plane per blockIdx.y -> channel constants are block-uniform
@@ -120,17 +164,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs a, long 
     }
 }
 
-#ifdef IC_TUNING
-static int g_bn_per_chunk = 1024;
-extern "C" int ic_bn_debug_set_tuning(int elems_per_chunk) { const int p = g_bn_per_chunk; if (elems_per_chunk > 0) g_bn_per_chunk = elems_per_chunk; return p; }
-#else
-static constexpr int g_bn_per_chunk = 1024;      // elements of a channel each stage-1 reduction block covers
-#endif
-static int bn_nchunks(int N, int HW) {
-    long long n = ((long long)N * HW) / g_bn_per_chunk;
-    return (int)(n < 1 ? 1 : (n > BN_CHUNKS ? BN_CHUNKS : n));
-}
-
 static int ew_grid(long long total) {
     long long g = (total + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -144,38 +177,10 @@ extern "C" int ic_bn_stats_f32(const float* x, float* mean, float* var, int N, i
     BnArgs a{};
     a.x = x; a.N = N; a.C = C; a.HW = HW; a.partial = (double*)workspace;
     hipStream_t st = (hipStream_t)stream;
-    a.nchunks = bn_nchunks(N, HW);
-    hipLaunchKernelGGL(bn_reduce_stage1<0>, dim3(C, a.nchunks), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(bn_reduce_stage2<0>, dim3(ic_cdiv(C, 64)), dim3(64), 0, st, a.partial, C, (long long)N * HW, mean, var,
-                       (double*)nullptr, a.nchunks);
+    a.out0 = mean; a.out1 = var;
+    hipLaunchKernelGGL(bn_channel_stats_kernel<0>, dim3(C), dim3(1024), 0, st, a, (double*)nullptr, BnFoldArgs{});
     IC_LAUNCH_CHECK();
     return IC_OK;
-}
-
-// stage 2 of the forward statistics with everything the host used to fold in a dozen tiny launches: invstd, the
-// folded scale/shift and the moving-average update (decay 0.9; TF's fused kernel feeds the UNBIASED variance to the
-// moving average while normalising with the biased one).
-__global__ void bn_train_fold_kernel(const double* __restrict__ partial, int C, long long M, const float* __restrict__ gamma,
-                                     const float* __restrict__ beta, float* __restrict__ moving_mean,
-                                     float* __restrict__ moving_var, float decay, float eps, float* __restrict__ mean,
-                                     float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
-                                     int nchunks) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= C) return;
-    double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < nchunks; ++k) { s0 += partial[((size_t)c * BN_CHUNKS + k) * 2]; s1 += partial[((size_t)c * BN_CHUNKS + k) * 2 + 1]; }
-    const double m = s0 / (double)M;
-    double v = s1 / (double)M - m * m;
-    if (v < 0.0) v = 0.0;
-    const float mf = (float)m, vf = (float)v;
-    const float is = 1.0f / sqrtf(vf + eps);
-    const float sc = gamma[c] * is;
-    mean[c] = mf; invstd[c] = is; scale[c] = sc; shift[c] = beta[c] - mf * sc;
-    if (moving_mean) moving_mean[c] = moving_mean[c] * decay + mf * (1.f - decay);
-    if (moving_var) {
-        const float unbiased = vf * (float)((double)M / (double)(M > 1 ? M - 1 : 1));
-        moving_var[c] = moving_var[c] * decay + unbiased * (1.f - decay);
-    }
 }
 
 extern "C" int ic_bn_train_stats_f32(const float* x, const float* gamma, const float* beta, float* moving_mean,
@@ -185,10 +190,8 @@ extern "C" int ic_bn_train_stats_f32(const float* x, const float* gamma, const f
     BnArgs a{};
     a.x = x; a.N = N; a.C = C; a.HW = HW; a.partial = (double*)workspace;
     hipStream_t st = (hipStream_t)stream;
-    a.nchunks = bn_nchunks(N, HW);
-    hipLaunchKernelGGL(bn_reduce_stage1<0>, dim3(C, a.nchunks), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(bn_train_fold_kernel, dim3(ic_cdiv(C, 64)), dim3(64), 0, st, a.partial, C, (long long)N * HW, gamma,
-                       beta, moving_mean, moving_var, decay, eps, mean, invstd, scale, shift, a.nchunks);
+    const BnFoldArgs f{gamma, beta, moving_mean, moving_var, decay, eps, mean, invstd, scale, shift};
+    hipLaunchKernelGGL(bn_channel_stats_kernel<2>, dim3(C), dim3(1024), 0, st, a, (double*)nullptr, f);
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
@@ -199,22 +202,12 @@ extern "C" int ic_bn_train_stats_f32(const float* x, const float* gamma, const f
 // between the two halves: forward  ic_bn_moments_f32 -> sum over ranks -> ic_bn_train_fold_moments_f32,
 //                         backward ic_bn_backward_reduce_f32 -> sum over ranks -> ic_bn_backward_apply_f32.
 // With one rank and no all-reduce the results are bit-identical to ic_bn_train_stats_f32 / ic_bn_backward_f32.
-__global__ void bn_sums_stage2(const double* __restrict__ partial, int C, double* __restrict__ sums, int nchunks) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= C) return;
-    double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < nchunks; ++k) { s0 += partial[((size_t)c * BN_CHUNKS + k) * 2]; s1 += partial[((size_t)c * BN_CHUNKS + k) * 2 + 1]; }
-    sums[c] = s0; sums[C + c] = s1;
-}
-
 extern "C" int ic_bn_moments_f32(const float* x, double* sums, int N, int C, int HW, void* workspace, ic_stream_t stream) {
     IC_CHECK_ARG(x && sums && workspace && N > 0 && C > 0 && HW > 0);
     BnArgs a{};
     a.x = x; a.N = N; a.C = C; a.HW = HW; a.partial = (double*)workspace;
     hipStream_t st = (hipStream_t)stream;
-    a.nchunks = bn_nchunks(N, HW);
-    hipLaunchKernelGGL(bn_reduce_stage1<0>, dim3(C, a.nchunks), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(bn_sums_stage2, dim3(ic_cdiv(C, 64)), dim3(64), 0, st, a.partial, C, sums, a.nchunks);
+    hipLaunchKernelGGL(bn_channel_stats_kernel<1>, dim3(C), dim3(1024), 0, st, a, sums, BnFoldArgs{});
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
@@ -225,18 +218,7 @@ __global__ void bn_fold_moments_kernel(const double* __restrict__ sums, int C, l
                                        float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= C) return;
-    const double m = sums[c] / (double)M;
-    double v = sums[C + c] / (double)M - m * m;
-    if (v < 0.0) v = 0.0;
-    const float mf = (float)m, vf = (float)v;
-    const float is = 1.0f / sqrtf(vf + eps);
-    const float sc = gamma[c] * is;
-    mean[c] = mf; invstd[c] = is; scale[c] = sc; shift[c] = beta[c] - mf * sc;
-    if (moving_mean) moving_mean[c] = moving_mean[c] * decay + mf * (1.f - decay);
-    if (moving_var) {
-        const float unbiased = vf * (float)((double)M / (double)(M > 1 ? M - 1 : 1));
-        moving_var[c] = moving_var[c] * decay + unbiased * (1.f - decay);
-    }
+    bn_fold_channel(c, sums[c], sums[C + c], M, gamma, beta, moving_mean, moving_var, decay, eps, mean, invstd, scale, shift);
 }
 
 extern "C" int ic_bn_train_fold_moments_f32(const double* sums, long long count, const float* gamma, const float* beta,
@@ -256,12 +238,8 @@ extern "C" int ic_bn_backward_reduce_f32(const float* dy, const float* x, const 
     BnArgs a{};
     a.x = x; a.dy = dy; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd;
     a.N = N; a.C = C; a.HW = HW; a.relu = relu;
-    a.partial = (double*)workspace;
     hipStream_t st = (hipStream_t)stream;
-    a.nchunks = bn_nchunks(N, HW);
-    hipLaunchKernelGGL(bn_reduce_stage1<1>, dim3(C, a.nchunks), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(bn_reduce_stage2<1>, dim3(ic_cdiv(C, 64)), dim3(64), 0, st, a.partial, C, (long long)N * HW, dbeta,
-                       dgamma, sums, a.nchunks);
+    hipLaunchKernelGGL(bn_channel_bwd_sums_kernel, dim3(C), dim3(1024), 0, st, a, sums, dbeta, dgamma);
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
@@ -302,10 +280,7 @@ extern "C" int ic_bn_backward_f32(const float* dy, const float* x, const float* 
     double* sums = a.partial + (size_t)C * BN_CHUNKS * 2;
     a.sums = sums; a.out0 = dx;
     hipStream_t st = (hipStream_t)stream;
-    a.nchunks = bn_nchunks(N, HW);
-    hipLaunchKernelGGL(bn_reduce_stage1<1>, dim3(C, a.nchunks), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(bn_reduce_stage2<1>, dim3(ic_cdiv(C, 64)), dim3(64), 0, st, a.partial, C, (long long)N * HW, dbeta,
-                       dgamma, sums, a.nchunks);
+    hipLaunchKernelGGL(bn_channel_bwd_sums_kernel, dim3(C), dim3(1024), 0, st, a, sums, dbeta, dgamma);
     const long long total = (long long)N * C * HW;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ic_cdiv(HW, 1024) < 1 ? 1 : ic_cdiv(HW, 1024), N * C), dim3(256), 0, st, a, total);
     IC_LAUNCH_CHECK();
