@@ -212,6 +212,32 @@ def test_device_decoder_stream(cuda, configs, syn_weights, nets, tmp_path):
     assert one.tolist() == [[[4]]]
 
 
+@pytest.mark.parametrize('L,shape', [(6, (1, 3, 40, 56)), (8, (1, 3, 24, 72)), (3, (1, 3, 8, 8))])
+def test_device_decoder_cached_shapes(cuda, L, shape, tmp_path):
+    """the activation-cache decoder on volumes with odd extents (5 x 7, 3 x 9, 1 x 1 planes: every tap of the first rows and
+    columns is a halo voxel) and with other numbers of centres than the specialised L = 6 (generic lane loops): the three
+    device decoders and the reference-style host loop return the encoder's symbols."""
+    import tempfile
+    from imgcomp_cvpr_amd import autoencoder, probclass, bit_counter, _lib, config_parser as cp, weights as W
+    ae_cfg, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'low'))
+    pc_cfg, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
+    ae_cfg.num_centers = L
+    wts = W.synthetic_weights(ae_cfg, pc_cfg)
+    ae = autoencoder.get_network_cls(ae_cfg)(ae_cfg).load_weights(wts, cuda)
+    pc = probclass.get_network_cls(pc_cfg)(pc_cfg, num_centers=L).load_weights(wts, cuda)
+    pred = probclass.PredictionNetwork(pc, pc_cfg, ae.get_centers_variable())
+    x = dev(W.synthetic_image(shape, 'natural', seed=L), cuda)
+    sym = ae.encode(x, False).symbols[0].cpu().numpy()
+    assert sym.max() < L
+    padded = pred.pad_symbols_volume(sym)
+    fd, path = tempfile.mkstemp(dir=str(tmp_path))
+    nbits, first, _ = bit_counter._encode(fd, padded, sym, pred)
+    data = open(path, 'rb').read()
+    for flags in (0, _lib.PC_DECODE_RECOMPUTE, _lib.PC_DECODE_PER_LAYER):
+        out = pred.decode_stream(data, sym.shape, first, flags=flags)
+        assert np.array_equal(out, sym), 'decoder flags {} lost sync (L = {}, volume {})'.format(flags, L, sym.shape)
+
+
 def test_blockwise_logits_bit_identical_to_full_volume(cuda, configs, syn_weights, nets):
     """the incremental decoder's contract: a (5,9,9) context evaluated alone gives the SAME fp32 logits as the
     all-position pass (fixed K order per output; SURVEY.md section 7 hard parts)."""

@@ -61,6 +61,38 @@ def test_bn_train_forward_backward(cuda):
         assert_close(dx, xt.grad, 'bn dx', 1e-5)
 
 
+def test_fused_adam_matches_the_multi_tensor_form(cuda):
+    """ic_adam_tf_f32 on flat buffers against TFAdam's seven multi-tensor passes (tf.train.AdamOptimizer: epsilon outside the
+    bias correction) over three steps, tensors of odd sizes at 256-byte aligned offsets of the flat buffers."""
+    from imgcomp_cvpr_amd import training
+    rs = np.random.RandomState(5)
+    sizes = [(3, 3, 5, 7), (33,), (128, 3), (1,)]
+    offs, total = [], 0
+    for sh in sizes:
+        offs.append(total)
+        total += (int(np.prod(sh)) + 63) // 64 * 64
+    fp, fg = torch.zeros(total, device=cuda), torch.zeros(total, device=cuda)
+    ps = [fp[o:o + int(np.prod(sh))].view(sh) for o, sh in zip(offs, sizes)]
+    gs = [fg[o:o + int(np.prod(sh))].view(sh) for o, sh in zip(offs, sizes)]
+    for p in ps:
+        p.copy_(dev(rs.normal(0, 1, tuple(p.shape)), cuda))
+    ref_p = [p.clone() for p in ps]
+    ref_g = [torch.zeros_like(p) for p in ps]
+    fused = training.TFAdam(ps, gs, lr=3e-3, flat=[(fp, fg)])
+    plain = training.TFAdam(ref_p, ref_g, lr=3e-3)
+    for step in range(3):
+        for g, rg in zip(gs, ref_g):
+            v = dev(rs.normal(0, 10.0 ** -step, tuple(g.shape)), cuda)
+            g.copy_(v); rg.copy_(v)
+        fused.step(); plain.step()
+    torch.cuda.synchronize()
+    for i, (p, rp) in enumerate(zip(ps, ref_p)):
+        assert_close(p, rp.double(), 'fused Adam, variable {}'.format(i), 1e-6)
+        assert_close(fused.m[i], plain.m[i].double(), 'fused Adam m {}'.format(i), 1e-6)
+        assert_close(fused.v[i], plain.v[i].double(), 'fused Adam v {}'.format(i), 1e-6)
+    assert float(fp[offs[1] + 33:offs[2]].abs().max()) == 0.0          # the padding between tensors stays zero
+
+
 @pytest.mark.parametrize('N,H,W', [(2, 16, 16), (1, 12, 20), (1, 7, 8), (3, 9, 34), (32, 32, 32)])
 def test_winograd_filter_gradient(cuda, N, H, W):
     """ic_conv3x3_c128_wgrad_f32 (Winograd-domain GEMMs over all 2x2 tiles) against autograd in float64 on the small shapes and
