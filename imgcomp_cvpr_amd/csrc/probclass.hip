@@ -192,7 +192,7 @@ void pc_mfma_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
     constexpr int S = TC + 2, DS = (TR + 2) * S, CS = 2 * DS, CHUNK = KC * CS;
     constexpr int NST = (CHUNK + 255) / 256;
     constexpr int NCH = CIN / KC, C8 = KC / 8, RD = 7;
-    static_assert(WM * WN == 4 && TR * TC == 32 * WN, "one 32-voxel accumulator tile per wave");
+    static_assert(WM * WN == 4 && TR * TC <= 32 * WN && TR * TC > 32 * (WN - 1), "one 32-voxel accumulator tile per wave (the last one may be ragged)");
     static_assert(CIN % KC == 0 && KC % 8 == 0, "channel chunking");
     static_assert(DS <= 256 && NST * 256 >= CHUNK + 64, "one brick plane per pass of the work-group, 64 spare floats behind the brick");
     __shared__ float lds[NST * 256];
@@ -224,7 +224,11 @@ void pc_mfma_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
         loff = (tid < DS && iy < a.H && ix < a.W) ? (unsigned)((iy * a.W + ix) * 4) : 0x80000000u;   // od + kd < D always
     }
     const int j = lane & 31, kh = lane >> 5;
-    const int q = 32 * wn + j;
+    // tile shapes whose voxel count is not a multiple of 32 (5 x 25, 6 x 21: chosen per layer so that the tile grid wastes the
+    // least of the plane) leave the last lanes of the last wave without a voxel: they compute voxel 0 again and store nothing
+    const int q_raw = 32 * wn + j;
+    const bool q_ok = TR * TC == 32 * WN || q_raw < TR * TC;
+    const int q = q_ok ? q_raw : 0;
     const int boff = kh * CS + (q / TC) * S + (q % TC);
     const int cot = blockIdx.y * WM + wm, ncot = gridDim.y * WM;
     // filter fragments: float4 index ((group * PC_NT + tap) * ncot + cot) * 64 + lane -- one loop-invariant lane offset and
@@ -319,7 +323,7 @@ void pc_mfma_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
 
     // epilogue: D[i][j], i = (r&3) + 8*(r>>2) + 4*kh output channel of tile `cot`, j = voxel
     const int oy = y0 + q / TC, ox = x0 + q % TC;
-    const bool live = oy < a.OH && ox < a.OW;
+    const bool live = q_ok && oy < a.OH && ox < a.OW;
     const int ovol = a.OD * a.OH * a.OW;
     const int v = (od * a.OH + (live ? oy : 0)) * a.OW + (live ? ox : 0);
     float val[16];
@@ -591,9 +595,23 @@ static int launch_pc(const PcLayerArgs& a, hipStream_t st) {
 
 static int launch_pc_mfma(const PcLayerArgs& a, const float* wpk, int k, bool final, hipStream_t st) {
     if (k == 24) {
-        dim3 g(a.OD * ic_cdiv(a.OH, 8) * ic_cdiv(a.OW, 16), 1, a.N);
-        if (final) hipLaunchKernelGGL((pc_mfma_kernel<24, 24, 1, 4, 8, 16, true>), g, dim3(256), 0, st, a, wpk);
-        else hipLaunchKernelGGL((pc_mfma_kernel<24, 24, 1, 4, 8, 16, false>), g, dim3(256), 0, st, a, wpk);
+        if (final) {
+            dim3 g(a.OD * ic_cdiv(a.OH, 8) * ic_cdiv(a.OW, 16), 1, a.N);
+            hipLaunchKernelGGL((pc_mfma_kernel<24, 24, 1, 4, 8, 16, true>), g, dim3(256), 0, st, a, wpk);
+        } else {
+            // tile shape per layer: a work-group computes TR x TC voxels and the launch runs ceil(OH / TR) x ceil(OW / TC) of them
+            // per plane -- a 68 x 100 plane is 84 % useful in 8 x 16 tiles and 95 % in 5 x 25 (Kodak volume, layer 1)
+            const int shapes[3][2] = {{8, 16}, {5, 25}, {6, 21}};
+            int best = 0; long long best_cost = -1;
+            for (int i = 0; i < 3; ++i) {
+                const long long cost = (long long)ic_cdiv(a.OH, shapes[i][0]) * ic_cdiv(a.OW, shapes[i][1]);
+                if (best_cost < 0 || cost < best_cost) { best = i; best_cost = cost; }
+            }
+            dim3 g((unsigned)(a.OD * best_cost), 1, a.N);
+            if (best == 0) hipLaunchKernelGGL((pc_mfma_kernel<24, 24, 1, 4, 8, 16, false>), g, dim3(256), 0, st, a, wpk);
+            else if (best == 1) hipLaunchKernelGGL((pc_mfma_kernel<24, 24, 1, 4, 5, 25, false>), g, dim3(256), 0, st, a, wpk);
+            else hipLaunchKernelGGL((pc_mfma_kernel<24, 24, 1, 4, 6, 21, false>), g, dim3(256), 0, st, a, wpk);
+        }
     } else {   // k == 64
         if (final) {
             dim3 g(a.OD * ic_cdiv(a.OH, 8) * ic_cdiv(a.OW, 16), 1, a.N);
