@@ -1,6 +1,6 @@
 // Which scalar expression reproduces v_mfma_f32_32x32x2_f32 bit for bit?  (Needed by the sequential decoder's cached form:
 // one new voxel per layer per symbol is computed on the vector units and must equal the matrix-core result of the parallel pass.)
-//   hipcc --offload-arch=gfx950 -O2 tools/mfma_order.hip -o /tmp/mfma_order && /tmp/mfma_order
+//   hipcc --offload-arch=gfx950 -O2 tools/mfma_order.hip -o tools/mfma_order.bin; gpurun -- ./tools/mfma_order.bin   (the binary is git-ignored)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,3 +1,7 @@
+#!/usr/bin/env python
+"""Prologue of the NB-segment 3x3 kernel split into phases (a -DWN_PROF -DWN_PROF2 build: tools/build_variants.sh for both
+conv3x3_wino.hip and conv3x3_wino_tn.hip, IMGCOMP_HIP_LIB=.../lib_prof2.so): address set-up | first patch data transformed |
+remaining transforms + ring writes | barrier + first operands, per wave (median, max) in shader clocks."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
