@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
 // KS = 4: small maps that cannot fill the chip with 4 x groups waves -- a work-group is ONE channel tile (cot) of a
 //         group, its four waves take a quarter of the input channels each (16 k-steps) and the partial accumulators are
 //         summed through LDS in the fixed order (w0 + w1) + (w2 + w3); wave w then finishes output registers 4w..4w+3.
-template <bool VEC, int KS, bool SHARE = false>
+template <bool VEC, int KS, bool SHARE = false, bool WT = false>
 __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx, int cot_in) {
 #ifdef WN_PROF
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
@@ -444,8 +444,10 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
                 q0 += ra0[sl]; q1 += ra1[sl];
                 q0 += rb0[sl]; q1 += rb1[sl];
                 const int so = (32 * cot + cr) * HW * 4;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q0), yr, lo0, so, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q1), yr, lo1, so, 0);
+                // WT: a launch that is one round of work-groups stores write-through (sc1): nothing is left dirty in the L2s for
+                // the kernel boundary to write back (measured on the NB-segment kernel: 1 us per layer)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q0), yr, lo0, so, WT ? 16 : 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q1), yr, lo1, so, WT ? 16 : 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
@@ -551,13 +553,14 @@ __global__ __launch_bounds__(256) void wino3x3_c128_kernel(const WnArgs a) {
 }
 
 // whole-K with the input transform shared between the four waves through LDS (even widths)
+template <bool WT>
 __global__ __launch_bounds__(256) void wino3x3_c128_shared_kernel(const WnArgs a) {
     // work-group i runs on XCD i % 8 (round-robin dispatch): give every XCD a contiguous run of tile groups, so that the
     // halo rows shared by vertically adjacent groups are found in ONE L2 instead of being fetched by several
     const int b = a.xcd_runs ? ic_xcd_run(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const int gx = b % a.gcols;
     const int t = b / a.gcols;
-    wino_body<true, 1, true>(a, t / a.grows, t % a.grows, gx, 0);
+    wino_body<true, 1, true, WT>(a, t / a.grows, t % a.grows, gx, 0);
 }
 
 // K-split form for maps that do not fill the chip: one work-group per (tile group, channel tile)
@@ -939,7 +942,10 @@ extern "C" int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed,
     if (p.whole > 0) {
         const dim3 grid((unsigned)p.whole);
         a.g0 = (int)g0; a.ngroups = (int)p.whole;
-        if (even_w && (flags & IC_CONV3_FORM_MASK) != IC_CONV3_WINO_WHOLEK_PW) hipLaunchKernelGGL(wino3x3_c128_shared_kernel, grid, dim3(256), 0, st, a);
+        if (even_w && (flags & IC_CONV3_FORM_MASK) != IC_CONV3_WINO_WHOLEK_PW) {
+            if (p.whole <= 256) hipLaunchKernelGGL(wino3x3_c128_shared_kernel<true>, grid, dim3(256), 0, st, a);      // one round
+            else hipLaunchKernelGGL(wino3x3_c128_shared_kernel<false>, grid, dim3(256), 0, st, a);
+        }
         else if (even_w) hipLaunchKernelGGL(wino3x3_c128_kernel<true>, grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(wino3x3_c128_kernel<false>, grid, dim3(256), 0, st, a);
         g0 += p.whole;

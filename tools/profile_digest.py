@@ -42,7 +42,7 @@ traffic = {'shape': [1, 128, 128, 192], 'source': 'profiles/{}_wino_pmc.txt: roc
 lines = ['rocprofv3 --pmc passes, one 3x3 128->128 layer on the Kodak residual-stack shape (1,128,128,192), 20 back-to-back launches per pass,',
          'per-launch averages.  FETCH_SIZE / WRITE_SIZE are in KiB (TCC_EA0 requests x 64 B / 1024).  Calibration in the same pass: a 256 MiB',
          'device-to-device copy (64 Mi floats read, 64 Mi written).', '']
-for form, kname in (('seg3', 'wino3x3_c128_tn_kernel<3, false>'), ('wholek', 'wino3x3_c128_shared_kernel')):
+for form, kname in (('seg3', 'wino3x3_c128_tn_kernel<3, false, true>'), ('wholek', 'wino3x3_c128_shared_kernel<true>')):
     ent = {}
     lines.append('== form {} : kernel {}'.format(form, kname))
     for grp in ('fetch', 'write', 'l2', 'ea', 'sq'):
@@ -64,7 +64,7 @@ for form, kname in (('seg3', 'wino3x3_c128_tn_kernel<3, false>'), ('wholek', 'wi
         w = 268435456.0 / (ent['calib_copy_WRITE_SIZE'] * 1024.0)
         rd, wr = ent['FETCH_SIZE'] * 1024.0 * f, ent['WRITE_SIZE'] * 1024.0 * w
         l2l1 = ent['TCP_TCC_READ_REQ_sum'] * (268435456.0 / ent['calib_copy_TCP_TCC_READ_REQ_sum'])
-        kkey = kname.replace(', false>', '>')
+        kkey = re.sub(r'<(\d+), \w+, \w+>', r'<\1>', kname).replace('<true>', '')      # bench.py's plan names
         traffic['kernels'][kkey] = {
             'fetch_counter_kib': ent['FETCH_SIZE'], 'write_counter_kib': ent['WRITE_SIZE'], 'fetch_calibration_factor': round(f, 3),
             'write_calibration_factor': round(w, 3), 'hbm_read_bytes_per_launch': int(rd), 'hbm_write_bytes_per_launch': int(wr),
