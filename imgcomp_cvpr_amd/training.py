@@ -791,12 +791,16 @@ class _GraphedDistortionFn(torch.autograd.Function):
         gd.x.copy_(x)
         gd.xo.copy_(x_out)
         gd.graph.replay()
-        ctx.gd = gd
+        gd.replays = getattr(gd, 'replays', 0) + 1
+        ctx.gd, ctx.replay = gd, gd.replays
         return gd.outs['d_loss_scaled'].clone()
 
     @staticmethod
     def backward(ctx, go):
         # the static gradient buffer is valid until the next replay; go is the scalar d(total)/d(d_loss_scaled) (= 1)
+        if ctx.replay != ctx.gd.replays:
+            raise RuntimeError('the graphed distortion was evaluated again before this backward: its gradient buffer has been '
+                               'overwritten (one forward_backward at a time per TrainGraph, or set TrainGraph.GRAPH_LOSS = False)')
         return None, None, ctx.gd.outs['grad'] * go
 
 
