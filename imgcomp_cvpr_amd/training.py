@@ -762,7 +762,8 @@ class _GraphedDistortion(object):
         cur.wait_stream(side)
         torch.cuda.synchronize(device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: other host threads (the RCCL watchdog of a data-parallel run) may keep calling the runtime during capture
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.outs = self._run()
 
     def _run(self):
