@@ -428,7 +428,7 @@ static constexpr int g_lds_pad = 0, g_pipe = -1, g_abl = 0;
 static constexpr unsigned long long* g_dbg = nullptr;
 #endif
 
-// Variant choice from a small cost model calibrated on MI355X (tools/bench_conv3x3.py, profiles/):
+// Variant choice from a small cost model calibrated on MI355X (tools/kbench.py conv3 with IC_CONV3_DIRECT_VARIANT(v), profiles/):
 // every CU gets W = ceil(nwg / 256) work-groups; up to `occ` of them are resident together, and the
 // matrix-pipe efficiency of a CU grows with the number of resident waves per SIMD (1: 0.70 with the
 // pipelined schedule, 2: 0.85, >= 3: 0.95 -- prologue/epilogue of one group hide under the others).

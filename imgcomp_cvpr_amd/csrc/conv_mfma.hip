@@ -140,7 +140,7 @@ __device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph,
 
     // BN scale / shift of the channels this lane finishes, requested before the main loop: fetched inside the store loop,
     // each of the 16 channel iterations waited out its own L2 round trip (25 k of a wave's 165 k clocks in h2,
-    // tools/cm_prof.py).  Channels past Cout read 0 through the descriptor's range check.
+    // a -DCM_PROF build).  Channels past Cout read 0 through the descriptor's range check.
     constexpr int RPW = 16 / WK;                           // accumulator registers finished by each K-slice wave
     float bsc[RPW], bsh[RPW];
     {
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void deconv5_mfma_kernel(const GArgs a, const 
 // host side
 // ------------------------------------------------------------------------------------------------
 static unsigned long long* g_cm_prof = nullptr;
-#ifdef CM_PROF      // tuning builds only (tools/cm_prof.py): device buffer of 4 x u64 shader-clock stamps per wave
+#ifdef CM_PROF      // tuning builds only (a -DCM_PROF build): device buffer of 4 x u64 shader-clock stamps per wave
 extern "C" void ic_conv2d_mfma_set_prof(unsigned lo, unsigned hi) { g_cm_prof = (unsigned long long*)(((unsigned long long)hi << 32) | lo); }
 #endif
 static int ncot_for(int Cout) { return ic_cdiv(Cout, 32) <= 2 ? 2 : ic_cdiv(ic_cdiv(Cout, 32), 4) * 4; }

@@ -220,7 +220,7 @@ extern "C" uint32_t ic_crc32c(const void* data, size_t n, uint32_t crc) {
 // one 512-register work-group per CU and, for a Kodak-sized map, occupy 192 of the 256 CUs; a context-model work-group
 // that lands on one of those CUs takes registers the next 3x3 work-group needs, and that one then waits for the whole
 // SIMD.  A stream restricted to the CUs the decoder leaves idle removes the interference: the two branches overlap
-// completely (tools/bench_cumask.py: 3.15 -> 2.98 ms per Kodak image).  Mask bit i is CU (i / 8) of XCD (i % 8)
+// completely (round-1 A/B: 3.15 -> 2.98 ms per Kodak image).  Mask bit i is CU (i / 8) of XCD (i % 8)
 // (tools/cumask_probe.hip), so a run of 8 m consecutive bits takes m CUs from every XCD.
 // The stream is created BLOCKING (the only flavour the runtime offers with a mask): it orders itself against the legacy
 // default stream, so the other branch must run on a non-blocking stream for the two to overlap.

@@ -5,7 +5,7 @@ output.  On the MI355X the decoder is a chain of 3x3 launches that keep ONE 512-
 Kodak-sized feature map -- occupy 192 of the 256 CUs.  A context-model work-group that lands on one of those CUs takes
 registers the next 3x3 work-group needs, which then waits for the whole SIMD: a plain second stream buys ~1 %.  A stream
 restricted to the CUs the decoder leaves idle (ic_stream_create_cu_range) removes the interference and hides the
-context model completely (tools/bench_cumask.py: 3.15 -> 2.98 ms per Kodak image).
+context model completely (round-1 A/B: 3.15 -> 2.98 ms per Kodak image).
 
     bs = BranchStreams(device)
     with torch.cuda.stream(bs.main):                 # CU-range streams are blocking w.r.t. the legacy default stream
