@@ -130,6 +130,61 @@ __global__ __launch_bounds__(256) void pc_conv3d_kernel(const PcLayerArgs a) {
     }
 }
 
+// conv0 for k = 24 (1 -> 24 channels, first mask: 13 live taps) with the addressing of the generic kernel taken out of the
+// tap loop.  One lane = one output voxel, all 24 channels: the same fmaf(x, w, acc) chain over the taps in (kd, kh, kw) order
+// as pc_conv3d_kernel<24, true, ...> -- bit-identical.  What changes: the symbol volume is read through a buffer descriptor
+// with ONE lane offset (the window's corner) and a scalar offset per tap; whether a tap lies in the pad region is the AND of
+// three per-axis masks computed once per lane; the 24 stores take the channel as a scalar offset.  (The generic kernel spent
+// ~15 vector instructions per tap on bounds checks and 64-bit addresses and 6 per store: 650 per voxel, now ~420.)
+__global__ __launch_bounds__(256) void pc_conv0_k24_kernel(const PcLayerArgs a) {
+    constexpr int K = 24;
+    const int n = blockIdx.z;
+    const int ovol = a.OD * a.OH * a.OW;
+    int v = blockIdx.x * 256 + threadIdx.x;
+    const bool live = v < ovol;
+    if (!live) v = ovol - 1;
+    const int ox = v % a.OW, t = v / a.OW;
+    const int oy = t % a.OH, od = t / a.OH;
+    const int qhw = a.qh * a.qw;
+    // corner of the 2 x 3 x 3 window in the UNPADDED volume: (od - 4, oy - 4, ox - 4)
+    const int c0 = od - 4, y0 = oy - 4, x0 = ox - 4;
+    bool okd[2], okh[3], okw[3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) okd[i] = c0 + i >= 0;                       // c0 + i < qC always
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { okh[i] = y0 + i >= 0 && y0 + i < a.qh; okw[i] = x0 + i >= 0 && x0 + i < a.qw; }
+    const __amdgpu_buffer_rsrc_t qr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)n * a.qC * qhw), 0, a.qC * qhw * 4, 0x00020000);
+    // the corner may lie before the volume (negative index); a tap inside the volume has a non-negative index, one in the
+    // pad region gets the out-of-range offset (no access) and the pad value
+    const int corner = (c0 * a.qh + y0) * a.qw + x0;
+    float acc[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                if (kd == 1 && (kh == 2 || (kh == 1 && kw >= 1))) continue;             // first mask (probclass.py:150-160)
+                const bool in = okd[kd] && okh[kh] && okw[kw];
+                const unsigned off = in ? (unsigned)((corner + (kd * a.qh + kh) * a.qw + kw) * 4) : 0x80000000u;
+                const float ld = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(qr, off, 0, 0));
+                const float xv = in ? ld : a.pad_value;
+                const float* wp = a.w + ((kd * 3 + kh) * 3 + kw) * K;                     // Cin = 1: [tap][co], wave-uniform
+#pragma unroll
+                for (int j = 0; j < K; ++j) acc[j] = fmaf(xv, wp[j], acc[j]);
+            }
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)n * K * ovol), 0, K * ovol * 4, 0x00020000);
+    const unsigned voff = live ? (unsigned)(v * 4) : 0x80000000u;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        float r = acc[j] + a.bias[j];
+        if (a.relu) r = fmaxf(r, 0.f);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r), yr, voff, j * ovol * 4, 0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Matrix-core version of the k -> k and k -> L layers ("other" mask, 14 live taps).
 // Same implicit-GEMM shape as the autoencoder convs: D[co][voxel] += A[co][kk] * B[kk][voxel] with
@@ -676,7 +731,10 @@ static int pc_forward(const float* q, int prepadded, const int64_t* symbols, con
     a.Cin = 1; a.Cout = k; a.D = C + 4; a.H = h + 8; a.W = w + 8; a.OD = C + 3; a.OH = h + 6; a.OW = w + 6;
     a.qC = C; a.qh = h; a.qw = w; a.relu = 1;
     // all k output channels of a voxel in one lane when k = 24: the input brick is read once instead of three times
-    if ((rc = (k == 24 ? launch_pc<24, true, false, true>(a, st) : launch_pc<8, true, false>(a, st)))) return rc;
+    if (k == 24 && !prepadded && (long long)k * (C + 3) * (h + 6) * (w + 6) * 4 < (1ll << 31) && (long long)C * h * w * 4 < (1ll << 31)) {
+        const int ovol0 = a.OD * a.OH * a.OW;
+        hipLaunchKernelGGL(pc_conv0_k24_kernel, dim3((unsigned)((ovol0 + 255) / 256), 1, N), dim3(256), 0, st, a);
+    } else if ((rc = (k == 24 ? launch_pc<24, true, false, true>(a, st) : launch_pc<8, true, false>(a, st)))) return rc;
     // (they address one KC-channel slab of an image's feature volume with 31-bit byte offsets; KC = 24 for k = 24, 16 for k = 64.
     // The same path must serve the parallel pass and the sequential decoder -- their logits have to agree bit for bit --
     // so the limit is the slab, not the volume: every volume a 288 GB device can hold stays on the matrix cores.)
