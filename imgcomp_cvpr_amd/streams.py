@@ -59,12 +59,13 @@ class BranchStreams(object):
             return 0
         return min((self.n_cus - wgs) // 8 * 8, self.n_cus // 2)
 
-    # Measured on the MI355X (bench.py --idle_layers sweep, Kodak image): the context model's 196,608 symbols take ~0.6 ms on
-    # 64 CUs = 3.05 ns per symbol per 64 CUs, a one-work-group-per-CU 3x3 launch 37.5 us.  The decoder leaves the side
-    # stream's CUs alone for that many of its 3x3 launches and takes the whole chip for the rest (sweep: 12 launches 149.4
-    # Mpix/s -- the context model is not done and the step waits for it -- 16: 153.2, 20: 152.6, all 32: 149.4).
-    NS_PER_SYMBOL_64CU = 3.05
-    US_PER_LAYER = 37.5
+    # Measured on the MI355X (bench.py --idle_layers sweep, Kodak image): the context model's 196,608 symbols take ~0.53 ms on
+    # 64 CUs = 2.7 ns per symbol per 64 CUs, a one-work-group-per-CU 3x3 launch 36.4 us.  The decoder leaves the side
+    # stream's CUs alone for that many of its 3x3 launches and takes the whole chip for the rest (sweep at the round's end:
+    # 13 launches 158.2 Mpix/s, 14: 158.5 / 157.9, 15: 158.1 / 157.9, 16: 157.3; with too few the context model is not done
+    # and the step waits for it -- 12 launches cost 4 Mpix/s with the round's first kernels).
+    NS_PER_SYMBOL_64CU = 2.7
+    US_PER_LAYER = 36.4
 
     def auto_idle_layers(self, N, H, W, n_cus, C=32):
         import math
