@@ -567,7 +567,8 @@ class TrainGraph(object):
             gd = self._graphed_distortion(x)
             main = torch.cuda.current_stream(self.dev)
             if getattr(self, '_loss_stream', None) is None:
-                self._loss_stream = torch.cuda.Stream(device=self.dev)
+                # its own hardware queue: streams of equal priority may share one, and a shared queue runs its streams in turn
+                self._loss_stream = torch.cuda.Stream(device=self.dev, priority=-1)
             side = self._loss_stream
             side.wait_stream(main)
             with torch.cuda.stream(side):
