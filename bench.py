@@ -64,7 +64,8 @@ class Pipeline(object):
         self.ae = autoencoder.get_network_cls(self.ae_cfg)(self.ae_cfg).load_weights(self.wts, dev)
         self.pc = probclass.get_network_cls(self.pc_cfg)(self.pc_cfg, num_centers=self.ae_cfg.num_centers).load_weights(self.wts, dev)
         self.pad_value = float(self.wts['autoencoder/encoder/centers'][0])
-        self.branch = streams.BranchStreams(dev, share=share, idle_layers=idle_layers)
+        self.serial = share == 'serial'              # bitcost, then decode, on one stream (A/B against the branch streams)
+        self.branch = streams.BranchStreams(dev, share='full_chip' if self.serial else share, idle_layers=idle_layers)
         self.seed = seed
 
     def set_input(self, N, H, Wd):
@@ -80,6 +81,9 @@ class Pipeline(object):
         torch = self.torch
         cur = torch.cuda.current_stream(self.dev)
         enc = self.ae.encode(self.x, is_training=False)
+        if self.serial:
+            bc = self.pc.bitcost(enc.qbar, enc.symbols, is_training=False, pad_value=self.pad_value)
+            return bits.bitcost_to_bpp(bc, self.x), self.ae.decode(enc.qhard, is_training=False)
         self.side.wait_stream(cur)
         with torch.cuda.stream(self.side):
             bc = self.pc.bitcost(enc.qbar, enc.symbols, is_training=False, pad_value=self.pad_value)
@@ -100,7 +104,7 @@ def main():
     p.add_argument('--batch', type=int, default=1)
     p.add_argument('--ae_config', default='low')
     p.add_argument('--mode', default='infer', choices=['infer', 'train'])
-    p.add_argument('--share', default='auto', choices=['auto', 'cu_range', 'full_chip'],
+    p.add_argument('--share', default='auto', choices=['auto', 'cu_range', 'full_chip', 'serial'],
                    help='how decoder and context model share the chip (imgcomp_cvpr_amd/streams.py); auto = the package default')
     p.add_argument('--idle_layers', type=int, default=None, help="cu_range sharing: 3x3 launches of the decoder that leave the side stream's CUs idle (0 = all; default: sized from the context model's work)")
     p.add_argument('--no_cpu_baseline', action='store_true')
@@ -125,7 +129,7 @@ def main():
 
     from imgcomp_cvpr_amd import weights as W, _lib, streams
     lib = _lib.lib
-    share = streams.DEFAULT_SHARE if a.share == 'auto' else a.share
+    share = streams.DEFAULT_SHARE if a.share == 'auto' else a.share        # 'auto': per shape (streams.py)
     pipe = Pipeline(dev, a.ae_config, share, seed=rank, idle_layers=a.idle_layers).set_input(a.batch, a.height, a.width)
     ae, pc, ae_cfg = pipe.ae, pipe.pc, pipe.ae_cfg
     N, H, Wd = a.batch, a.height, a.width
@@ -154,7 +158,8 @@ def main():
         elapsed = float(t.item())
     value = N * H * Wd * world * a.steps / elapsed / 1e6
 
-    cus = pipe.branch.idle_cus(N, H, Wd) if pipe.side is not pipe.branch._plain else 0
+    same_stream = pipe.serial or pipe.side is pipe.branch.main
+    cus = pipe.branch.idle_cus(N, H, Wd) if not same_stream and pipe.side is not pipe.branch._plain else 0
     extra = {'branch_sharing': share, 'context_model_stream_cus': cus, 'bpp_synthetic': round(float(bpp), 5)}
     roofline = roofline_pc = None
     if rank == 0 and not a.no_extras:
@@ -266,7 +271,7 @@ def main():
             lib.ic_event_destroy(e)
 
         # ---- the other sharing arrangement and the north_star's 256x256 shape through the same step() ----
-        other = 'full_chip' if share == 'cu_range' else 'cu_range'
+        other = 'full_chip' if share == 'cu_range' else 'cu_range'          # under 'auto' / 'serial': the CU-range arrangement
         try:
             po = Pipeline(dev, a.ae_config, other, seed=rank).set_input(N, H, Wd)
             dt, _ = run(po, 20, 3)
@@ -314,8 +319,14 @@ def main():
     if rank == 0:
         C = int(ae_cfg.num_chan_bn)
         flop_step = N * H * Wd * (FLOP_PER_PX_ENC + FLOP_PER_PX_DEC + FLOP_PER_SYMBOL_PC * C / 64.0)
-        sched = ('a stream limited to the {} CUs the decoder leaves idle'.format(cus) if cus else
-                 'a second stream next to the decoder (which fills the chip)')
+        if same_stream:
+            sched_text = ('one image at a time: encode, context-model bitcost, decode(qhard) in that order on one stream, every '
+                          'launch on the whole chip (val.py:85-89 evaluates bitcost and reconstruction in one session.run)')
+        else:
+            sched = ('a stream limited to the {} CUs the decoder leaves idle'.format(cus) if cus else
+                     'a second stream next to the decoder (which fills the chip)')
+            sched_text = ('one image at a time; bitcost and decode of that image run concurrently (val.py:85-89 evaluates both in '
+                          'one session.run), the bitcost on ' + sched)
         out = {
             'metric': 'Megapixels/s encode+pc-logits (and decode) per node',
             'value': round(value, 3), 'unit': 'Mpix/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -326,8 +337,7 @@ def main():
                                    'context-model bitcost + decode(qhard); random-init weights'.format(
                                        N, H, Wd, a.ae_config),
                        'batch_per_gpu': N, 'height': H, 'width': Wd, 'parallelism': 'image-sharded x{}'.format(world),
-                       'schedule': 'one image at a time; bitcost and decode of that image run concurrently (val.py:85-89 '
-                                   'evaluates both in one session.run), the bitcost on ' + sched},
+                       'schedule': sched_text},
             'model_tflops_per_s': round(flop_step * world * a.steps / elapsed / 1e12, 2),
             'roofline': roofline, 'roofline_context_model': roofline_pc, 'cpu_baseline': cpu,
         }

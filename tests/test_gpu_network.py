@@ -361,7 +361,12 @@ def test_branch_streams_cu_range(cuda, configs, syn_weights, nets):
     import ctypes
     from imgcomp_cvpr_amd import bits, streams, weights as W, _lib
     ae, pc = nets
-    bs = streams.BranchStreams(cuda)
+    auto = streams.BranchStreams(cuda)                  # default: a second stream only where the decoder leaves >= 96 CUs idle
+    assert auto.context_model_stream(1, 512, 768) is auto.main and auto.decode_flags(auto.main) == 0
+    small = auto.context_model_stream(1, 256, 256)
+    assert small is not auto.main and small is not auto._plain and auto.decode_flags(small) & _lib.CONV3_LEAVE_IDLE_CUS
+    auto.close()
+    bs = streams.BranchStreams(cuda, share='cu_range')
     try:
         # Kodak: 192 whole-K work-groups -> on a 256-CU MI355X a quarter of the chip is idle; 4K: the decoder fills every round
         assert int(_lib.lib.ic_wino3x3_c128_workgroups(1, 128, 192, 0)) >= 256   # alone, the layer is spread over the whole chip
