@@ -64,8 +64,8 @@ class Pipeline(object):
         self.ae = autoencoder.get_network_cls(self.ae_cfg)(self.ae_cfg).load_weights(self.wts, dev)
         self.pc = probclass.get_network_cls(self.pc_cfg)(self.pc_cfg, num_centers=self.ae_cfg.num_centers).load_weights(self.wts, dev)
         self.pad_value = float(self.wts['autoencoder/encoder/centers'][0])
-        self.serial = share == 'serial'              # bitcost, then decode, on one stream (A/B against the branch streams)
-        self.branch = streams.BranchStreams(dev, share='full_chip' if self.serial else share, idle_layers=idle_layers)
+        self.serial = share in ('serial', 'auto')    # bitcost, then decode, on one stream
+        self.branch = streams.BranchStreams(dev, share=share, idle_layers=idle_layers)
         self.seed = seed
 
     def set_input(self, N, H, Wd):
@@ -129,7 +129,7 @@ def main():
 
     from imgcomp_cvpr_amd import weights as W, _lib, streams
     lib = _lib.lib
-    share = streams.DEFAULT_SHARE if a.share == 'auto' else a.share        # 'auto': per shape (streams.py)
+    share = streams.DEFAULT_SHARE if a.share == 'auto' else a.share        # 'auto' = the library default (streams.py: 'serial')
     pipe = Pipeline(dev, a.ae_config, share, seed=rank, idle_layers=a.idle_layers).set_input(a.batch, a.height, a.width)
     ae, pc, ae_cfg = pipe.ae, pipe.pc, pipe.ae_cfg
     N, H, Wd = a.batch, a.height, a.width

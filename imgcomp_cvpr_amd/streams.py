@@ -16,14 +16,17 @@ context model completely (round-1 A/B: 3.15 -> 2.98 ms per Kodak image).
         x_out = ae.decode(enc.qhard, False, plan_flags=bs.decode_flags(side))     # per-call: no library state is touched
         bs.main.wait_stream(side)
 
-Which arrangement is used is a constructor argument (`share`): 'cu_range' as above; 'full_chip' -- the decoder's 3x3
-launches take the form that fills the chip (NB-segment jobs) and the context model runs on a plain second stream, filling
-whatever the decoder's launch boundaries leave; 'auto' (the default) -- 'cu_range' when the decoder leaves at least
-SERIAL_BELOW CUs idle (small images: a 256 x 256 image's 3x3 launches use half the chip), otherwise NO second stream: the
-context model runs ahead of the decoder on the same stream and every launch of both takes the whole chip.  (Round 2, Kodak
-image: with the context model at 0.135 ms the serial order and the CU-range order both give 157-158 Mpix/s -- the 64 CUs
-the decoder's one-work-group-per-CU form leaves are no longer worth the 4 us per launch that form costs against the
-full-chip form.)
+Which arrangement is used is a constructor argument (`share`):
+  'serial' (the default, alias 'auto') -- no second stream: the context model runs ahead of the decoder on the caller's stream
+             and every launch of both takes the whole chip;
+  'cu_range' -- as above: the context model on the CUs the decoder's one-work-group-per-CU launches leave idle;
+  'full_chip' -- the decoder's 3x3 launches take the form that fills the chip and the context model runs on a plain second
+             stream, filling whatever the decoder's launch boundaries leave.
+Round 1 measured 'cu_range' 5 % ahead (the context model took 0.24 ms, the full-chip 3x3 form did not exist).  At the end of
+round 2 -- context model 0.135 ms, NB-segment 3x3 jobs that fill the chip for any map of >= 32 tile groups -- 'serial' is
+level on a Kodak image (157.3 / 157.8 against 157.0 / 157.9 Mpix/s, then 158.7 against 155.8) and AHEAD on a 256 x 256 image
+(65.4 against 60.9 Mpix/s: next to a CU-range stream the decoder has to keep to the forms that stay off those CUs).  The other
+two stay available for callers whose side branch is heavier than this context model.
 """
 import ctypes
 
@@ -32,13 +35,12 @@ import torch
 from . import _lib
 
 
-DEFAULT_SHARE = 'auto'
+DEFAULT_SHARE = 'serial'
 DEFAULT_IDLE_LAYERS = None       # None = sized from the context model's work (BranchStreams.auto_idle_layers); 0 = the whole stack
 
 
 class BranchStreams(object):
     MIN_CUS = 32          # fewer than this and the context model becomes the critical path of a Kodak-sized image
-    SERIAL_BELOW = 96     # share = 'auto': with fewer idle CUs than this the context model simply runs ahead of the decoder
 
     def __init__(self, device, share=None, idle_layers=None):
         share = share or DEFAULT_SHARE
@@ -46,7 +48,8 @@ class BranchStreams(object):
         # again (the context model is done long before the decoder: 0.4 ms of a 1.3 ms decode on a Kodak-sized image)
         self.idle_layers = DEFAULT_IDLE_LAYERS if idle_layers is None else int(idle_layers)
         self._auto_layers = 0
-        assert share in ('auto', 'cu_range', 'full_chip')
+        share = 'serial' if share == 'auto' else share
+        assert share in ('serial', 'cu_range', 'full_chip')
         self.share = share
         self.device = torch.device(device)
         self.main = torch.cuda.Stream(device=self.device)
@@ -57,7 +60,7 @@ class BranchStreams(object):
 
     def idle_cus(self, N, H, W):
         """CUs the decoder's 3x3 launches leave idle for an (N, 3, H, W) image, rounded down to whole CUs per XCD."""
-        if self.share == 'full_chip':
+        if self.share != 'cu_range':
             return 0
         # the plan the decoder runs when it is asked to leave its idle CUs alone
         wgs = int(_lib.lib.ic_wino3x3_c128_workgroups(N, H // 4, W // 4, _lib.CONV3_LEAVE_IDLE_CUS))
@@ -83,7 +86,7 @@ class BranchStreams(object):
     def context_model_stream(self, N, H, W, C=32):
         n = self.idle_cus(N, H, W)
         self._auto_layers = self.auto_idle_layers(N, H, W, n, C) if n >= self.MIN_CUS else 0
-        if self.share == 'auto' and n < self.SERIAL_BELOW:
+        if self.share == 'serial':
             return self.main             # no second stream: the context model runs ahead of the decoder, both on the whole chip
         if n < self.MIN_CUS:
             return self._plain           # the decoder fills the chip in rounds: nothing to partition

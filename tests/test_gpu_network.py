@@ -361,10 +361,9 @@ def test_branch_streams_cu_range(cuda, configs, syn_weights, nets):
     import ctypes
     from imgcomp_cvpr_amd import bits, streams, weights as W, _lib
     ae, pc = nets
-    auto = streams.BranchStreams(cuda)                  # default: a second stream only where the decoder leaves >= 96 CUs idle
-    assert auto.context_model_stream(1, 512, 768) is auto.main and auto.decode_flags(auto.main) == 0
-    small = auto.context_model_stream(1, 256, 256)
-    assert small is not auto.main and small is not auto._plain and auto.decode_flags(small) & _lib.CONV3_LEAVE_IDLE_CUS
+    auto = streams.BranchStreams(cuda)                  # default: no second stream, the context model runs ahead of the decoder
+    assert auto.share == 'serial' and auto.context_model_stream(1, 512, 768) is auto.main and auto.decode_flags(auto.main) == 0
+    assert auto.context_model_stream(1, 256, 256) is auto.main
     auto.close()
     bs = streams.BranchStreams(cuda, share='cu_range')
     try:
