@@ -110,6 +110,11 @@ def main():
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--no_extras', action='store_true', help='headline only: no stage split, roofline, extra shapes (rocprofv3 runs)')
     p.add_argument('--pipelined', action='store_true', help='also run the informational three-pipelines-in-flight section')
+    p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                   help='process-group backend for N > 1 (nccl = RCCL; gloo lets two ranks share one GPU in the tests)')
+    p.add_argument('--device', type=int, default=None, help='HIP device index of this rank (default: LOCAL_RANK)')
+    p.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                   help='--mode train: weak = 32 crops per GPU; strong = cfg3\'s batch of 32 split over the ranks (train.py:150-153)')
     a = p.parse_args()
 
     import torch
@@ -119,10 +124,14 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     assert world == a.gpus, 'WORLD_SIZE {} != --gpus {}'.format(world, a.gpus)
     assert torch.cuda.is_available(), 'bench.py needs a HIP device'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    dev_index = local_rank if a.device is None else a.device
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        if a.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group('gloo')
 
     if a.mode == 'train':
         return train_main(a, dev, rank, world)
@@ -136,26 +145,25 @@ def main():
     torch.cuda.synchronize(dev)
     torch.cuda.set_stream(pipe.branch.main)      # CU-range streams are blocking with respect to the legacy default stream
 
-    def barrier():
-        if world > 1:
+    def barrier(collective):
+        # every rank calls run(..., collective=True) the same number of times (once: the contract's timed region); the
+        # rank-0-only extras below time with collective=False, i.e. a local synchronize and NO process-group call
+        if collective and world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def run(pl, steps, warmup):
+    def run(pl, steps, warmup, collective=False):
         for _ in range(warmup):
             pl.step()
-        barrier()
+        barrier(collective)
         t0 = time.perf_counter()
         for _ in range(steps):
             out = pl.step()
-        barrier()
+        barrier(collective)
         return time.perf_counter() - t0, out
 
-    elapsed, (bpp, x_out) = run(pipe, a.steps, a.warmup)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, (bpp, x_out) = run(pipe, a.steps, a.warmup, collective=True)
+    elapsed = max_over_ranks(torch, dist, elapsed, dev, world, a.backend)
     value = N * H * Wd * world * a.steps / elapsed / 1e6
 
     same_stream = pipe.serial or pipe.side is pipe.branch.main
@@ -348,6 +356,14 @@ def main():
         dist.destroy_process_group()
 
 
+def max_over_ranks(torch, dist, elapsed, dev, world, backend):
+    if world == 1:
+        return elapsed
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def plan_name(lib, _lib, N, h4, w4, flags):
     """which kernel(s) ic_conv3x3_c128_auto_f32 launches for this shape and these flags (the library's own plan query)."""
     if lib.ic_conv3x3_c128_pick_algo(N, h4, w4, flags) != 1:
@@ -398,16 +414,22 @@ def pipelined_section(torch, dev, a, N, H, Wd, pipe):
 
 
 def train_main(a, dev, rank, world):
-    """--mode train: BASELINE configs[2] -- ae_configs/cvpr/med + res_shallow, batch 32 of random 128x128 crops per GPU
-    (weak scaling: every rank its own 32 crops), one full training step per bench step: forward in training mode, MS-SSIM
-    loss, hand-written backward, RCCL gradient all-reduce of the three flat buckets, two Adam updates."""
+    """--mode train: BASELINE configs[2] -- ae_configs/cvpr/med + res_shallow, random 128x128 crops, one full training step per
+    bench step: forward in training mode, MS-SSIM loss, hand-written backward, RCCL gradient all-reduce of the three flat
+    buckets, two Adam updates.  --scaling weak: 32 crops per GPU (the global batch grows with N); --scaling strong: cfg3's
+    batch of 32 split over the ranks, what train.py does with --batch_size 32 (reference train.py:150-153 feeds one batch)."""
     import torch
     import torch.distributed as dist
     from imgcomp_cvpr_amd import config_parser as cp, weights as W, training
     ae_cfg, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'med'))
     pc_cfg, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
     wts = W.synthetic_weights(ae_cfg, pc_cfg)
-    N, H, Wd = 32, 128, 128
+    GLOBAL, H, Wd = 32, 128, 128
+    if a.scaling == 'strong':
+        assert GLOBAL % world == 0, 'strong scaling splits a batch of 32: --gpus must divide it'
+        N = GLOBAL // world
+    else:
+        N = GLOBAL
     tr = training.Trainer(ae_cfg, pc_cfg, wts, dev, num_itr_per_epoch=1000)
     x = torch.as_tensor(W.synthetic_image((N, 3, H, Wd), 'natural', seed=rank)).float().to(dev)
 
@@ -422,20 +444,18 @@ def train_main(a, dev, rank, world):
     for _ in range(a.steps):
         out = tr.step(x)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(torch, dist, time.perf_counter() - t0, dev, world, a.backend)
     if rank == 0:
         print(json.dumps({
-            'metric': 'training images/s (cfg3: cvpr/med + res_shallow, 128x128 crops, batch 32 per GPU)',
+            'metric': 'training images/s (cfg3: cvpr/med + res_shallow, 128x128 crops, {})'.format(
+                'batch 32 per GPU' if a.scaling == 'weak' else 'global batch 32 split over the GPUs'),
             'value': round(N * world * a.steps / elapsed, 2), 'unit': 'img/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': round(elapsed / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': round(elapsed / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': a.scaling, 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[2]: train step, ae_configs/cvpr/med + pc_configs/cvpr/res_shallow, {}x3x{}x{} '
                                    'per GPU, MS-SSIM loss, two Adam optimisers, data-parallel gradient all-reduce'.format(N, H, Wd),
-                       'batch_per_gpu': N, 'parallelism': 'dp{}'.format(world)},
+                       'batch_per_gpu': N, 'global_batch': N * world, 'parallelism': 'dp{}'.format(world),
+                       'sync_bn': bool(tr.graph.sync_bn) if hasattr(tr, 'graph') and hasattr(tr.graph, 'sync_bn') else None},
             'mpix_per_s': round(N * H * Wd * world * a.steps / elapsed / 1e6, 3),
             'last_step': {k: round(float(v), 5) for k, v in out.items()}}), flush=True)
     if world > 1:

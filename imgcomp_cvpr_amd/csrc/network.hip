@@ -186,21 +186,23 @@ extern "C" const char* ic_strerror(int code) {
 // CRC-32C (Castagnoli) of a HOST buffer: the checksum of TF-1 checkpoint tensors and table blocks
 // (tensorflow/core/lib/hash/crc32c.h; saver.py:46-100 writes them, tf_checkpoint.py reads/writes them).
 // Slicing-by-8 on the host; not a device function.
-static uint32_t g_crc_tab[8][256];
-static bool g_crc_init = false;
-static void crc_init() {
+struct CrcTab { uint32_t t[8][256]; };
+static constexpr CrcTab make_crc_tab() {
+    CrcTab r{};
     for (uint32_t i = 0; i < 256; ++i) {
         uint32_t c = i;
         for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
-        g_crc_tab[0][i] = c;
+        r.t[0][i] = c;
     }
     for (uint32_t i = 0; i < 256; ++i)
-        for (int t = 1; t < 8; ++t) g_crc_tab[t][i] = (g_crc_tab[t - 1][i] >> 8) ^ g_crc_tab[0][g_crc_tab[t - 1][i] & 0xff];
-    g_crc_init = true;
+        for (int t = 1; t < 8; ++t) r.t[t][i] = (r.t[t - 1][i] >> 8) ^ r.t[0][r.t[t - 1][i] & 0xff];
+    return r;
 }
+// built at compile time: a constant of the library, no lazily initialised process-wide state
+static constexpr CrcTab g_crc = make_crc_tab();
+#define g_crc_tab g_crc.t
 
 extern "C" uint32_t ic_crc32c(const void* data, size_t n, uint32_t crc) {
-    if (!g_crc_init) crc_init();
     const unsigned char* p = (const unsigned char*)data;
     uint32_t c = crc ^ 0xFFFFFFFFu;
     while (n >= 8) {

@@ -134,14 +134,29 @@ class _Network3D(object):
 
     def _pad_value_as_float(self, pad_value):
         """The C ABI takes the pad value by value.  A tensor (centers[0], reference probclass.py:59-61) is fetched from the
-        device ONCE per distinct storage + version: a .item() per image would stall the host until everything queued on
-        the stream -- the whole encoder -- has finished, before the decoder could be enqueued."""
-        if torch.is_tensor(pad_value):
-            key = (pad_value.data_ptr(), pad_value._version)
+        device once per distinct VALUE SOURCE: a .item() per image would stall the host until everything queued on the
+        stream -- the whole encoder -- has finished, before the decoder could be enqueued.
+          * bound to a training graph (test-in-train, train.py:122-126): the optimiser updates the centres through a raw
+            pointer, which neither moves the storage nor bumps torch's version counter, so the cache key is the graph's
+            own `version` (bumped by every apply_gradients) and the value is the graph's pinned copy of centres[0];
+          * unbound: keyed on the identity of the tensor that OWNS the storage (a weak reference: a fresh centres tensor at
+            a recycled address is a different owner) plus its version counter."""
+        if not torch.is_tensor(pad_value):
+            return float(pad_value)
+        g = self._train_graph
+        if g is not None:
+            key = ('graph', id(g), g.version)
             if getattr(self, '_pad_cache', (None, None))[0] != key:
-                self._pad_cache = (key, float(pad_value.item()))
+                self._pad_cache = (key, float(g._pad_value()))
             return self._pad_cache[1]
-        return float(pad_value)
+        owner = pad_value._base if pad_value._base is not None else pad_value
+        cached = getattr(self, '_pad_cache', None)
+        if (cached is not None and cached[0][0] == 'tensor' and cached[0][1]() is owner
+                and cached[0][2:] == (pad_value.data_ptr(), owner._version)):
+            return cached[1]
+        import weakref
+        self._pad_cache = (('tensor', weakref.ref(owner), pad_value.data_ptr(), owner._version), float(pad_value.item()))
+        return self._pad_cache[1]
 
     def bitcost(self, q, target_symbols, is_training, pad_value=0):
         """q: NCHW float32, target_symbols: NCHW int64 -> bit cost per symbol, NCHW

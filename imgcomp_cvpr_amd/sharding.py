@@ -14,6 +14,12 @@ def rank_and_world(group=None):
     return 0, 1
 
 
+def barrier(group=None):
+    """all ranks meet (no-op without a process group)"""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.barrier(group=group)
+
+
 def shard_indices(n_items, rank, world):
     """round-robin shard: indices rank, rank + world, ...  (every item exactly once over all ranks)."""
     if not (0 <= rank < world):

@@ -412,6 +412,16 @@ def ckpt_dir_for_log_dir(log_dir):
     return os.path.join(log_dir, _CKPT_DIR_NAME)
 
 
+def log_dir_for_restore(restore):
+    """--restore_continue: the log dir a restore path belongs to (saver.py `log_dir_from_ckpt_dir`: the ckpts/ dir's parent).
+    `restore` may be the ckpts/ dir, the log dir itself, or a checkpoint prefix / file inside ckpts/."""
+    restore = os.path.normpath(restore)
+    if os.path.isdir(restore):
+        return os.path.dirname(restore) if os.path.basename(restore) == _CKPT_DIR_NAME else restore
+    d = os.path.dirname(restore)
+    return os.path.dirname(d) if os.path.basename(d) == _CKPT_DIR_NAME else d
+
+
 def iteration_of_checkpoint(ckpt_path):
     m = re.search(r'-(\d+)', os.path.basename(ckpt_path))        # saver.py:130-135
     assert m is not None, 'Expected -(\\d+), got {}'.format(ckpt_path)
@@ -462,7 +472,8 @@ def is_training_state(name):
     """what continuing a training run needs on top of the model variables (the reference's Saver restores every variable
     of the graph: restore_manager.py:52-58): the step counter and the two Adam optimisers' slots and beta powers."""
     return name == 'global_step' or bool(re.search(r'/(Adam_AE|Adam_AE_1|Adam_PC|Adam_PC_1)$', name)) or \
-        bool(re.match(r'(Adam_AE|Adam_PC)/beta[12]_power$', name))
+        bool(re.match(r'beta[12]_power(_1)?$', name)) or \
+        bool(re.match(r'(Adam_AE|Adam_PC)/beta[12]_power$', name))          # TF's names; second form: files of round-2 builds
 
 
 def load_weights(path, itr=-1, training_state=False):

@@ -40,6 +40,9 @@ from . import weights as _weights
 from ._lib import lib, check, ptr
 
 BN_EPS = 1e-5
+# checkpoint names of the two Adam optimisers' beta-power accumulators (TF-1.x `_create_non_slot_variable`: named
+# `beta1_power` / `beta2_power`, no optimiser prefix, uniquified `_1` for the second optimiser of the graph)
+BETA_POWER_NAMES = {'Adam_AE': ('beta1_power', 'beta2_power'), 'Adam_PC': ('beta1_power_1', 'beta2_power_1')}
 BN_DECAY = 0.9
 _IMG_MEAN = (121.85369873, 113.58860779, 100.63715363)
 _IMG_VAR = (4746.37695312, 4454.13964844, 4812.234375)
@@ -980,8 +983,11 @@ class Trainer(object):
                 for n, m, v in zip(names, opt.m, opt.v):
                     out['{}/{}'.format(n, tag)] = m.detach().cpu().numpy()
                     out['{}/{}_1'.format(n, tag)] = v.detach().cpu().numpy()
-                out[tag + '/beta1_power'] = np.array(opt.b1 ** opt.t, np.float32)
-                out[tag + '/beta2_power'] = np.array(opt.b2 ** opt.t, np.float32)
+                # TF-1.x: `beta1_power` / `beta2_power` at the graph root, uniquified per optimiser in creation order
+                # (get_train_op creates Adam_AE first, train.py:339-349)
+                b1n, b2n = BETA_POWER_NAMES[tag]
+                out[b1n] = np.array(opt.b1 ** opt.t, np.float32)
+                out[b2n] = np.array(opt.b2 ** opt.t, np.float32)
         return out
 
     def restore_training_state(self, ckpt):
@@ -1000,7 +1006,7 @@ class Trainer(object):
                     found += 1
             if found:
                 # t from beta1_power = beta1 ** t when present, else the step counter
-                bp = ckpt.get(tag + '/beta1_power')
+                bp = ckpt.get(BETA_POWER_NAMES[tag][0], ckpt.get(tag + '/beta1_power'))     # second form: files written by round-2 builds
                 opt.t = int(round(math.log(float(np.asarray(bp).reshape(-1)[0])) / math.log(opt.b1))) if bp is not None and float(np.asarray(bp).reshape(-1)[0]) > 0 \
                     else self.global_step
         return self.global_step

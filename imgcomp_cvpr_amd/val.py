@@ -313,9 +313,13 @@ def main(argv=None):
         pc_config, _ = config_parser.parse(pc_p)
         weights = load_weights_for_job(job_dir, flags.weights, ae_config, pc_config, flags.restore_itr)
         out_dir = path.join(flags.log_dir_root, '{} {}'.format(log_date_from_log_dir(job_dir), dataset_name))
-        if flags.reset and path.isdir(out_dir) and sharding.rank_and_world()[0] == 0:
-            import shutil
-            shutil.rmtree(out_dir)
+        if flags.reset:
+            # rank 0 clears the directory; nobody writes into it before that is done (every rank passes the barrier,
+            # whether or not the directory existed: no rank-asymmetric collective)
+            if path.isdir(out_dir) and sharding.rank_and_world()[0] == 0:
+                import shutil
+                shutil.rmtree(out_dir)
+            sharding.barrier()
         avgs = validate(ae_config, pc_config, weights, image_paths, out_dir,
                         OutputFlags(flags.save_ours, -1, flags.real_bpp), device, host_metrics=bool(flags.host_metrics))
         if sharding.rank_and_world()[0] == 0:

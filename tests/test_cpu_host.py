@@ -287,6 +287,25 @@ def test_gradient_buckets_average_over_gloo_world2(tmp_path):
         assert 'rank {} buckets ok'.format(r) in o
 
 
+def test_train_command_line_is_the_references():
+    """code/train.py:475-502: every flag of the reference's command line parses, long and short forms."""
+    from imgcomp_cvpr_amd import train
+    p = train.build_arg_parser()
+    f = p.parse_args(['ae', 'pc', '-dtrain', 'a', '-dtest', 'b', '-dcodec', 'c', '-o', 'out', '-ltrain', '7', '-lsave', '8',
+                      '-ltest', '-1', '-lmeta', '-lgrads', '-t', '-r', 'dir', '-i', '5', '--restore_continue',
+                      '--restore_skip_vars', 'Adam,global_step', '--ckpt_interval', '0.5', '-d', 'text'])
+    assert (f.dataset_train, f.dataset_test, f.log_dir_root) == ('a', 'b', 'out')
+    assert (f.log_interval_train, f.log_interval_save, f.log_interval_test) == (7, 8, -1)
+    assert (f.restore, f.restore_itr, f.restore_continue, f.restore_skip_vars) == ('dir', 5, True, 'Adam,global_step')
+    f = p.parse_args(['ae', 'pc', '--from_identity', 'idt', '--log_interval_train', '3', '--log_interval_save', '4',
+                      '--log_interval_test', '5', '--dataset_train', 'x', '--dataset_test', 'y'])
+    assert (f.from_identity, f.log_interval_train, f.log_interval_save, f.log_interval_test) == ('idt', 3, 4, 5)
+    f = p.parse_args(['ae', 'pc', '--log_interval', '9', '--save_interval', '11'])         # round-2 spellings stay as aliases
+    assert (f.log_interval_train, f.log_interval_save, f.dataset_train, f.dataset_test) == (9, 11, 'imgnet_train', 'imgnet_test')
+    from imgcomp_cvpr_amd import tf_checkpoint as T
+    assert T.log_dir_for_restore('/a/b/ckpts') == '/a/b' and T.log_dir_for_restore('/a/b/ckpts/ckpt-5') == '/a/b'
+
+
 def test_train_host_logic(tmp_path):
     from imgcomp_cvpr_amd import train, training, config_parser as cp
     d1 = train.create_unique_log_dir(['ae_configs/cvpr/low', 'pc_configs/cvpr/res_shallow'], str(tmp_path))
@@ -537,6 +556,6 @@ def test_checkpoint_name_filters():
     for n in (w + '/Adam_AE', w + '/Adam_AE_1', w + '/Adam', 'global_step', 'Adam_AE/beta1_power', 'beta1_power'):
         assert not T.is_model_variable(n), n
     for n in (w + '/Adam_AE', w + '/Adam_AE_1', 'probclass3d/logits/conv3d_conv0_mask/biases/Adam_PC_1', 'global_step',
-              'Adam_PC/beta2_power'):
+              'Adam_PC/beta2_power', 'beta1_power', 'beta2_power', 'beta1_power_1', 'beta2_power_1'):
         assert T.is_training_state(n), n
     assert not T.is_training_state(w)

@@ -1,0 +1,57 @@
+"""-m gpu: bench.py as the driver launches it -- including N > 1, which round 2 shipped with a rank-asymmetric barrier that
+would have hung every multi-GPU point.  gpurun boxes have ONE GPU, so the two ranks of these tests share cuda:0 and the process
+group is gloo (`--backend gloo --device 0`); the collective sequence of every rank is the same as under RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _launch(nproc, port, extra, timeout=600):
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if nproc == 1:
+        cmd = [sys.executable, 'bench.py', '--gpus', '1'] + extra
+    else:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), 'bench.py', '--gpus', str(nproc), '--backend', 'gloo', '--device', '0'] + extra
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, universal_newlines=True)
+    assert p.returncode == 0, 'bench.py rc {}\n{}\n{}'.format(p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, 'expected ONE JSON line on rank 0, got {}: {}'.format(len(lines), p.stdout[-2000:])
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_inference(cuda):
+    """`bench.py --gpus 2`: returns, rank 0 prints one line, the rank-0-only extras (stage split, roofline, other shapes) run
+    without any process-group call while rank 1 waits at the final barrier."""
+    out = _launch(2, 29561, ['--steps', '3', '--warmup', '1', '--height', '128', '--width', '192'])
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['scaling'] == 'weak' and out['value'] > 0
+    assert out['roofline'] is not None and 0 < out['roofline']['frac'] <= 1
+    assert out['cpu_baseline'] is None                              # N = 1 only
+    assert len(out['shapes']) == 2
+
+
+def test_bench_two_ranks_training_weak_and_strong(cuda):
+    """`bench.py --mode train --gpus 2`: the data-parallel step (bucketed gradient all-reduce, cross-replica BatchNorm) under
+    both scalings; strong = cfg3's batch of 32 split 2 x 16."""
+    weak = _launch(2, 29562, ['--mode', 'train', '--steps', '2', '--warmup', '1'])
+    assert weak['n_gpus'] == 2 and weak['scaling'] == 'weak' and weak['config']['batch_per_gpu'] == 32
+    strong = _launch(2, 29563, ['--mode', 'train', '--steps', '2', '--warmup', '1', '--scaling', 'strong'])
+    assert strong['scaling'] == 'strong' and strong['config']['batch_per_gpu'] == 16 and strong['config']['global_batch'] == 32
+    assert all(v == v for v in strong['last_step'].values())          # finite losses
+
+
+def test_bench_single_rank_contract(cuda):
+    """the default launch: one JSON line carrying the contract's keys plus roofline / cpu_baseline"""
+    out = _launch(1, 0, ['--steps', '3', '--warmup', '1', '--height', '128', '--width', '192'])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in out, k
+    assert out['cpu_baseline']['kind'] == 'port' and out['cpu_baseline']['value'] > 0
+    assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(out['roofline'])

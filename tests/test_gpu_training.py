@@ -315,6 +315,18 @@ def test_train_entry_point(cuda, tmp_path):
     assert any(not np.array_equal(w2[k], final[k]) for k in w2)              # the earlier checkpoint
     tr2, hist2, _ = train.train(str(ae_over), pc_p, None, loader_fn, max_itr=1, restore=log_dir, device=str(cuda), verbose=False)
     assert np.isfinite(hist2[0]['d_loss_scaled'])
+    assert tr2.global_step == 4 and tr2.opt_ae.t == 4                          # continued: step counter and Adam's beta powers
+    # the reference's restore flags (restore_manager.py:23-58): an iteration, --from_identity (no global_step, no *Adam*),
+    # --restore_continue (same log dir), and the test-in-train evaluation every --log_interval_test iterations
+    tr3, hist3, ld3 = train.train(str(ae_over), pc_p, str(tmp_path / 'logs'), loader_fn, max_itr=2, restore=log_dir, restore_itr=2,
+                                  restore_continue=True, device=str(cuda), verbose=False, log_interval_test=1)
+    assert ld3 == log_dir and tr3.global_step == 4
+    assert all(np.isfinite(h['test_bpp']) and np.isfinite(h['test_psnr']) for h in hist3)
+    assert hist3[0]['test_bpp'] != hist3[1]['test_bpp'], 'test-in-train did not see the updated variables'
+    tr4, _, _ = train.train(str(ae_over), pc_p, None, loader_fn, max_itr=1, from_identity=log_dir, device=str(cuda), verbose=False)
+    assert tr4.global_step == 1 and tr4.opt_ae.t == 1 and float(tr4.opt_ae.m[0].abs().max()) > 0
+    with pytest.raises(ValueError):
+        train.train(str(ae_over), pc_p, None, loader_fn, max_itr=1, restore=os.path.join(str(tmp_path), 'nope'), device=str(cuda), verbose=False)
     ae = autoencoder.get_network_cls(tr.graph.ae_config)(tr.graph.ae_config).load_weights(wts, cuda)
     enc = ae.encode(torch.zeros((1, 3, 64, 64), device=cuda), is_training=False)       # inference on the trained variables
     assert bool(torch.isfinite(enc.z).all())
@@ -581,3 +593,42 @@ def test_two_rank_training_step_equals_single_rank(cuda):
     grads_l, _, mv_l = results[False]
     worst_l = max(rel_err(torch.as_tensor(grads_l[k]), torch.as_tensor(ref[k]).double()) for k in ref)
     assert worst_l > 10 * worst and not np.allclose(mv_l, ref_mv, rtol=1e-5), 'local statistics reproduce the full batch?'
+
+
+def test_inference_pad_value_follows_the_optimiser(cuda):
+    """the context model's pad value is centers[0] (probclass.py:59-61), a by-value argument of the C ABI that the
+    plugin object caches on the host.  The optimiser updates the centres through a raw pointer -- neither the storage nor
+    torch's version counter changes -- so the cache must follow the training graph's version, and an unbound object's cache
+    must not survive a load_weights whose new centres land on the recycled address."""
+    from imgcomp_cvpr_amd import autoencoder, probclass, training, config_parser as cp, weights as W
+    ae_config, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'low'))
+    pc_config, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
+    ae_config.distortion_to_minimize = 'mse'
+    ae_config.H_target = 0.5
+    wts = W.synthetic_weights(ae_config, pc_config)
+    x = dev(W.synthetic_image((2, 3, 64, 64), 'natural', 3), cuda)
+    ae = autoencoder.get_network_cls(ae_config)(ae_config)
+    pc = probclass.get_network_cls(pc_config)(pc_config, num_centers=ae_config.num_centers)
+    trainer = training.Trainer(ae_config, pc_config, wts, cuda, num_itr_per_epoch=1000)
+    trainer.graph.bind(ae, pc)
+    enc = ae.encode(x, is_training=False)
+    used = []
+    for _ in range(3):
+        pv = pc._pad_value_as_float(pc.auto_pad_value(ae))
+        c0 = float(trainer.graph.params['autoencoder/encoder/centers'][0])
+        assert pv == c0, 'inference bitcost pads with {} while centers[0] is {}'.format(pv, c0)
+        # ... and that value is what the kernel sees: the tensor form and the by-value form give the same bits
+        b_t = pc.bitcost(enc.qhard, enc.symbols, is_training=False, pad_value=pc.auto_pad_value(ae))
+        b_f = pc.bitcost(enc.qhard, enc.symbols, is_training=False, pad_value=c0)
+        assert torch.equal(b_t, b_f)
+        used.append(pv)
+        trainer.step(x)
+    assert len(set(used)) == 3, 'centers[0] did not move in three optimiser steps: the test would not notice a stale cache'
+    # unbound objects: a fresh set of centres (same shape: the allocator may hand out the same address, version 0 again)
+    ae2 = autoencoder.get_network_cls(ae_config)(ae_config).load_weights(wts, cuda)
+    pc2 = probclass.get_network_cls(pc_config)(pc_config, num_centers=ae_config.num_centers).load_weights(wts, cuda)
+    assert pc2._pad_value_as_float(pc2.auto_pad_value(ae2)) == float(wts['autoencoder/encoder/centers'][0])
+    w2 = dict(wts)
+    w2['autoencoder/encoder/centers'] = (wts['autoencoder/encoder/centers'] + 0.125).astype(np.float32)
+    ae2.load_weights(w2, cuda)
+    assert pc2._pad_value_as_float(pc2.auto_pad_value(ae2)) == float(w2['autoencoder/encoder/centers'][0])
