@@ -493,5 +493,7 @@ def load_weights(path, itr=-1, training_state=False):
             return load_weights(prefix + '.npz', training_state=training_state)
     else:
         prefix = path[:-len('.index')] if path.endswith('.index') else path
+    if not os.path.isfile(prefix + '.index'):
+        raise ValueError('Invalid ckpt dir: {}'.format(path))                   # restore_manager.py:52-58
     names = [n for n in list_variables(prefix) if keep(n)]
     return dict(read_bundle(prefix, names=names))

@@ -112,15 +112,15 @@ def test_cfg4_real_bpp_full_kodak_volume(cuda):
     dt = time.time() - t0
     print('cfg4: encode + on-device decode {:.2f} s = {:.2f} us per symbol'.format(dt, dt / sym.size * 1e6))
     # and against the cross-entropy the fully convolutional pass reports (ProbclassNetworkTesting, val.py:279-281 "up to 1 %"):
-    # recorded in the parity report; the bound is 3 x the 0.01 % measured in round 3
+    # recorded in the parity report; measured in round 3: 1.4e-6 relative
     bits_theory = checker.get_total_bit_cost(sym)
     assert_close(torch.tensor([float(nbits) / bits_theory]), torch.tensor([1.0], dtype=torch.float64),
-                 'cfg4 coded bits / cross-entropy bits, 196,608 symbols', 1e-3)
+                 'cfg4 coded bits / cross-entropy bits, 196,608 symbols', 1e-5)
     print('cfg4: {} symbols, {} bits coded, {:.1f} bits cross-entropy ({:+.4f} %)'.format(sym.size, nbits, bits_theory,
                                                                                         100.0 * (nbits - bits_theory) / bits_theory))
 
 
-CFG3_GRAD_RTOL = 5e-3          # tightened to ~3 x measured once the round-3 GPU run has reported (see the parity report)
+CFG3_GRAD_RTOL = 6e-5          # ~3 x the worst of the 15 tensors measured on the MI355X in round 3 (1.8e-5: the final encoder BatchNorm beta)
 CFG3_GRAD_RTOL_FLIPS = 5e-2
 
 
