@@ -25,6 +25,7 @@ CONV3_WINO_KSPLIT, CONV3_WINO_T16, CONV3_WINO_SEG1, CONV3_WINO_SEG2, CONV3_WINO_
 CONV3_LEAVE_IDLE_CUS = 0x10
 CONV3_NO_XCD_RUNS = 0x20
 CONV3_PACKED_TRANSFORM = 0x40
+CONV3_NO_STACK_KERNEL = 0x80
 PC_DECODE_PER_LAYER = 0x01
 PC_DECODE_RECOMPUTE = 0x02
 
@@ -84,6 +85,8 @@ PROTOTYPES = {
                                  c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     'ic_sum_f32': (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p]),
     'ic_ae_workspace_bytes': (c_size_t, [c_int] * 4),
+    'ic_ae_sync_pos_bytes': (c_size_t, [c_int] * 4),
+    'ic_ae_res_stack_sync_pos_bytes': (c_size_t, [c_int] * 3),
     'ic_ae_encode_f32': (c_int, [c_void_p, POINTER(c_void_p)] + [c_int] * 5 + [c_void_p] * 6 +
                          [c_int] * 3 + [c_void_p, c_size_t, c_int, c_void_p]),
     'ic_ae_decode_f32': (c_int, [c_void_p, POINTER(c_void_p)] + [c_int] * 3 + [c_void_p] +

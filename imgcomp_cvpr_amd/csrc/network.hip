@@ -3,6 +3,7 @@
 // One host call enqueues all 36 stages of encode (or decode) on the caller's stream: batch-1 inference
 // (val.py runs one image per step, code/val.py:157-158) is otherwise bound by per-op host overhead.
 #include "internal.h"
+#include "wino_common.h"
 #include <string.h>
 
 // ---- residual stack shared by encoder and decoder (autoencoder.py:224-234 / :252-262) ----
@@ -17,39 +18,82 @@ static inline int layer_flags(int flags, int li) {
     return f;
 }
 
-static int res_stack(const void* const* tab, int B, float* const bufs[5], int N, int H, int W, int flags,
-                     hipStream_t st, int* out_idx) {
-    int cur = 0, li = 0, rc;
+// One layer of the stack as the walk below visits it: the per-layer path launches it, the persistent path records it.
+struct StackWalk {
+    bool record; WnStackArgs* sa; int flags; int N, H, W; hipStream_t st; int li;
+    int conv(const float* x, const float* const* l, const float* r1, const float* r2, float* y, int relu) {
+        if (record) {
+            WnStackLayer& L = sa->layers[li];
+            L.x = x; L.wp = l[0] + ic_conv3x3_c128_packed_floats(); L.scale = l[1]; L.shift = l[2];
+            L.res1 = r1; L.res2 = r2; L.y = y; L.relu = relu; L.pad_ = 0;
+            ++li;
+            return IC_OK;
+        }
+        const int rc = ic_conv3x3_c128_auto_f32(x, l[0], l[1], l[2], r1, r2, y, N, H, W, relu, layer_flags(flags, li), st);
+        ++li;
+        return rc;
+    }
+};
+
+static int res_stack_walk(StackWalk& w, const void* const* tab, int B, float* const bufs[5], int* out_idx) {
+    int cur = 0, rc;
     float* T = bufs[4];
+    const float* const* t = (const float* const*)tab;
     for (int b = 0; b < B; ++b) {
         const int G = cur;
         for (int i = 0; i < 3; ++i) {
             int O = 1;
             while (O == G || O == cur) ++O;              // one of {1,2,3} is always free
-            const float* const* l1 = (const float* const*)tab + 3 * li;
-            const float* const* l2 = l1 + 3;
-            if ((rc = ic_conv3x3_c128_auto_f32(bufs[cur], l1[0], l1[1], l1[2], nullptr, nullptr, T, N, H, W, 1, layer_flags(flags, li), st)))
-                return rc;
-            if ((rc = ic_conv3x3_c128_auto_f32(T, l2[0], l2[1], l2[2], bufs[cur], i == 2 ? bufs[G] : nullptr,
-                                                 bufs[O], N, H, W, 0, layer_flags(flags, li + 1), st)))
-                return rc;
-            cur = O; li += 2;
+            const float* const* l1 = t + 3 * w.li;
+            if ((rc = w.conv(bufs[cur], l1, nullptr, nullptr, T, 1))) return rc;
+            if ((rc = w.conv(T, l1 + 3, bufs[cur], i == 2 ? bufs[G] : nullptr, bufs[O], 0))) return rc;
+            cur = O;
         }
     }
     // final block: both convs linear, + block input + stack input
     {
         int O = 1;
         while (O == cur) ++O;
-        const float* const* l1 = (const float* const*)tab + 3 * li;
-        const float* const* l2 = l1 + 3;
-        if ((rc = ic_conv3x3_c128_auto_f32(bufs[cur], l1[0], l1[1], l1[2], nullptr, nullptr, T, N, H, W, 0, layer_flags(flags, li), st)))
-            return rc;
-        if ((rc = ic_conv3x3_c128_auto_f32(T, l2[0], l2[1], l2[2], bufs[cur], bufs[0], bufs[O], N, H, W, 0, layer_flags(flags, li + 1), st)))
-            return rc;
+        const float* const* l1 = t + 3 * w.li;
+        if ((rc = w.conv(bufs[cur], l1, nullptr, nullptr, T, 0))) return rc;
+        if ((rc = w.conv(T, l1 + 3, bufs[cur], bufs[0], bufs[O], 0))) return rc;
         cur = O;
     }
     *out_idx = cur;
     return IC_OK;
+}
+
+// Segments per job if this shape's whole stack can run as ONE persistent launch (conv3x3_wino_stack.hip), else 0: the per-layer
+// plan must be NB-segment jobs only, in one resident round, and the caller must not have asked for a particular form, for idle
+// CUs (a concurrent branch on a CU-range stream could keep work-groups of a persistent launch from becoming resident together)
+// or for per-layer launches (IC_CONV3_NO_STACK_KERNEL).
+static int stack_kernel_nb(int N, int H, int W, int nlayers, int flags) {
+    if (flags & (IC_CONV3_NO_STACK_KERNEL | IC_CONV3_LEAVE_IDLE_CUS | IC_CONV3_PACKED_TRANSFORM)) return 0;
+    const int form = flags & IC_CONV3_FORM_MASK;
+    if (form != IC_CONV3_AUTO && form != IC_CONV3_WINO && !(form >= IC_CONV3_WINO_SEG1 && form <= IC_CONV3_WINO_SEG3)) return 0;
+    if (ic_conv3x3_c128_pick_algo(N, H, W, flags) != 1) return 0;
+    long long pl[5];
+    if (ic_wino3x3_c128_plan(N, H, W, flags & (IC_CONV3_FORM_MASK | IC_CONV3_LEAVE_IDLE_CUS), pl) != IC_OK) return 0;
+    if (pl[0] || pl[3] || pl[4] || !pl[1]) return 0;
+    return icx_wino_stack_fits(N, H, W, (int)pl[2], nlayers) ? (int)pl[2] : 0;
+}
+
+// sync: WN_STACK_SYNC_BYTES of the caller's workspace for the persistent form (nullptr: per-layer launches only)
+static int res_stack(const void* const* tab, int B, float* const bufs[5], int N, int H, int W, int flags,
+                     hipStream_t st, int* out_idx, unsigned* sync) {
+    const int nlayers = 6 * B + 2;
+    const int nb = sync ? stack_kernel_nb(N, H, W, nlayers, flags) : 0;
+    if (nb) {
+        WnStackArgs sa{};
+        StackWalk w{true, &sa, flags, N, H, W, st, 0};
+        int rc = res_stack_walk(w, tab, B, bufs, out_idx);
+        if (rc) return rc;
+        sa.flags = sync; sa.N = N; sa.H = H; sa.W = W; sa.grows = ic_cdiv(H, 4); sa.gcols = ic_cdiv(W, 32);
+        sa.nlayers = nlayers; sa.xcd_runs = (flags & IC_CONV3_NO_XCD_RUNS) ? 0 : 1;
+        return icx_wino_stack_launch(sa, nb, st);
+    }
+    StackWalk w{false, nullptr, flags, N, H, W, st, 0};
+    return res_stack_walk(w, tab, B, bufs, out_idx);
 }
 
 static size_t ae_ws_floats(int N, int H, int W, int C) {
@@ -57,10 +101,18 @@ static size_t ae_ws_floats(int N, int H, int W, int C) {
     // 5 x (N,128,H/4,W/4) + (N,64,H/2,W/2) + bottleneck (N,C+1,H/8,W/8)
     return (size_t)N * (5 * 8 * hw + 16 * hw + (size_t)(C + 1) * hw / 64);
 }
+// the persistent residual-stack kernel's sync area sits behind the activations, on a 256-byte boundary
+static size_t ae_sync_offset(int N, int H, int W, int C) { return (ae_ws_floats(N, H, W, C) * sizeof(float) + 255) & ~(size_t)255; }
 
 extern "C" size_t ic_ae_workspace_bytes(int N, int H, int W, int C) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
-    return ae_ws_floats(N, H, W, C) * sizeof(float);
+    return ae_sync_offset(N, H, W, C) + WN_STACK_SYNC_BYTES;
+}
+// byte offset, inside a workspace of ic_ae_workspace_bytes, of the sync area of the persistent residual-stack kernel; its first
+// 32-bit word is 0 after a call unless a hand-off between work-groups timed out (then: 1 + the layer; the outputs are invalid)
+extern "C" size_t ic_ae_sync_pos_bytes(int N, int H, int W, int C) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    return ae_sync_offset(N, H, W, C);
 }
 
 static void carve(void* ws, int N, int H, int W, float* bufs[5], float** half, float** bott) {
@@ -75,6 +127,9 @@ static void carve(void* ws, int N, int H, int W, float* bufs[5], float** half, f
 // ic_ae_encode_f32 for these layers only (3 pointers per conv).  Used by bench.py to time the dominant kernel in-step and by
 // tests; workspace: 5 x N x 128 x H x W floats (bufs[0] receives a copy of x).
 extern "C" size_t ic_ae_res_stack_workspace_bytes(int N, int H, int W) {
+    return N > 0 && H > 0 && W > 0 ? (size_t)5 * N * 128 * H * W * sizeof(float) + WN_STACK_SYNC_BYTES : 0;
+}
+extern "C" size_t ic_ae_res_stack_sync_pos_bytes(int N, int H, int W) {
     return N > 0 && H > 0 && W > 0 ? (size_t)5 * N * 128 * H * W * sizeof(float) : 0;
 }
 extern "C" int ic_ae_res_stack_f32(const float* x, const void* const* tab, int B, float* y, int N, int H, int W,
@@ -89,7 +144,7 @@ extern "C" int ic_ae_res_stack_f32(const float* x, const void* const* tab, int B
     hipError_t e = hipMemcpyAsync(bufs[0], x, n * sizeof(float), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return (int)e;
     int o, rc;
-    if ((rc = res_stack(tab, B, bufs, N, H, W, flags, st, &o))) return rc;
+    if ((rc = res_stack(tab, B, bufs, N, H, W, flags, st, &o, (unsigned*)((char*)workspace + ic_ae_res_stack_sync_pos_bytes(N, H, W))))) return rc;
     e = hipMemcpyAsync(y, bufs[o], n * sizeof(float), hipMemcpyDeviceToDevice, st);
     return e == hipSuccess ? IC_OK : (int)e;
 }
@@ -118,7 +173,7 @@ extern "C" int ic_ae_encode_f32(const float* x, const void* const* tab, int B, i
     if ((rc = ic_conv2d_mfma_bn_act_f32(half, t[3], t[4], t[5], bufs[0], N, 64, H / 2, W / 2, 128, 5, 5, 2, 0, 1, st)))
         return rc;
     int o;
-    if ((rc = res_stack(tab + 6, B, bufs, N, H / 4, W / 4, flags, st, &o))) return rc;
+    if ((rc = res_stack(tab + 6, B, bufs, N, H / 4, W / 4, flags, st, &o, (unsigned*)((char*)workspace + ae_sync_offset(N, H, W, C))))) return rc;
     // to_bn: 128 -> C(+1), 5x5 / 2, BN, linear
     const float* const* tb = t + 6 + 3 * nconv;
     const int Cb = C + (heatmap_on ? 1 : 0);
@@ -157,7 +212,7 @@ extern "C" int ic_ae_decode_f32(const float* q, const void* const* tab, int B, i
     a.N = N; a.Cin = C; a.H = H / 8; a.W = W / 8; a.Cout = 128; a.KH = 3; a.KW = 3; a.relu = 1;
     if ((rc = icx_conv2d(a, true, st))) return rc;
     int o;
-    if ((rc = res_stack(tab + 3, B, bufs, N, H / 4, W / 4, flags, st, &o))) return rc;
+    if ((rc = res_stack(tab + 3, B, bufs, N, H / 4, W / 4, flags, st, &o, (unsigned*)((char*)workspace + ae_sync_offset(N, H, W, C))))) return rc;
     const float* const* th = t + 3 + 3 * nconv;
     // h12: 128 -> 64, 5x5 transposed / 2, BN, ReLU
     if ((rc = ic_conv2d_mfma_bn_act_f32(bufs[o], th[0], th[1], th[2], half, N, 128, H / 4, W / 4, 64, 5, 5, 2, 1, 1, st)))

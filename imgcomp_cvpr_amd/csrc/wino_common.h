@@ -26,6 +26,22 @@ struct WnArgs {
     unsigned long long* prof;   // profiling builds (WN_PROF) only
 };
 
+// conv3x3_wino_stack.hip: a whole residual stack (<= WN_STACK_MAX_LAYERS convs on one shape) as one persistent launch.
+// The layer table travels in the kernel arguments (scalar loads by layer index, no table in device memory).
+#define WN_STACK_MAX_LAYERS 40
+#define WN_STACK_SYNC_BYTES 4096          // sync area in the caller's workspace: time-out word + <= 512 work-group flags
+struct WnStackLayer {
+    const float* x; const float* wp; const float* scale; const float* shift;
+    const float* res1; const float* res2; float* y;
+    int relu, pad_;
+};
+struct WnStackArgs {
+    unsigned* flags;            // sync area: the time-out word, then layers completed per work-group
+    int N, H, W, grows, gcols, nlayers, ngroups, xcd_runs;
+    unsigned mg_cols, mg_rows, spin_limit, pad_;
+    WnStackLayer layers[WN_STACK_MAX_LAYERS];
+};
+
 #ifdef __HIPCC__
 // A tile row of 16 tiles is 16 lanes = one DPP row.
 __device__ __forceinline__ float dpp_from_left(float edge, float v) {    // lane i <- v of lane i-1; row lane 0 keeps edge
@@ -48,3 +64,7 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
 
 // conv3x3_wino_tn.hip: launches the NB-segment kernel over tile groups [a.g0, a.g0 + a.ngroups); nb in {1, 2, 3}
 int icx_wino_tn_launch(const WnArgs& a, int nb, int scalar_transform, hipStream_t st);
+// conv3x3_wino_stack.hip: does the shape fit one resident round of nb-segment jobs / launch the persistent stack kernel
+// (fills the geometry reciprocals, zeroes the flags on the stream first)
+bool icx_wino_stack_fits(int N, int H, int W, int nb, int nlayers);
+int icx_wino_stack_launch(WnStackArgs& a, int nb, hipStream_t st);
