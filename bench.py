@@ -111,7 +111,7 @@ def main():
     p.add_argument('--no_extras', action='store_true', help='headline only: no stage split, roofline, extra shapes (rocprofv3 runs)')
     p.add_argument('--pipelined', action='store_true', help='also run the informational three-pipelines-in-flight section')
     p.add_argument('--plan_flags', type=lambda v: int(v, 0), default=0,
-                   help='IC_CONV3_* bits OR-ed into every encode / decode call (0x80 = IC_CONV3_NO_STACK_KERNEL: one launch per 3x3 layer)')
+                   help='IC_CONV3_* bits OR-ed into every encode / decode call (0x80 = IC_CONV3_STACK_KERNEL: each residual stack as one persistent launch)')
     p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                    help='process-group backend for N > 1 (nccl = RCCL; gloo lets two ranks share one GPU in the tests)')
     p.add_argument('--device', type=int, default=None, help='HIP device index of this rank (default: LOCAL_RANK)')

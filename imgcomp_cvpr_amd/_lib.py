@@ -25,7 +25,7 @@ CONV3_WINO_KSPLIT, CONV3_WINO_T16, CONV3_WINO_SEG1, CONV3_WINO_SEG2, CONV3_WINO_
 CONV3_LEAVE_IDLE_CUS = 0x10
 CONV3_NO_XCD_RUNS = 0x20
 CONV3_PACKED_TRANSFORM = 0x40
-CONV3_NO_STACK_KERNEL = 0x80
+CONV3_STACK_KERNEL = 0x80
 PC_DECODE_PER_LAYER = 0x01
 PC_DECODE_RECOMPUTE = 0x02
 

@@ -66,14 +66,14 @@ static int res_stack_walk(StackWalk& w, const void* const* tab, int B, float* co
 // Segments per job if this shape's whole stack can run as ONE persistent launch (conv3x3_wino_stack.hip), else 0: the per-layer
 // plan must be NB-segment jobs only, in one resident round, and the caller must not have asked for a particular form, for idle
 // CUs (a concurrent branch on a CU-range stream could keep work-groups of a persistent launch from becoming resident together)
-// or for per-layer launches (IC_CONV3_NO_STACK_KERNEL).
+// -- and must have asked for it (IC_CONV3_STACK_KERNEL): measured, the hand-off costs what the kernel boundary costs.
 static int stack_kernel_nb(int N, int H, int W, int nlayers, int flags) {
-    if (flags & (IC_CONV3_NO_STACK_KERNEL | IC_CONV3_LEAVE_IDLE_CUS | IC_CONV3_PACKED_TRANSFORM)) return 0;
+    if (!(flags & IC_CONV3_STACK_KERNEL) || (flags & (IC_CONV3_LEAVE_IDLE_CUS | IC_CONV3_PACKED_TRANSFORM))) return 0;
     const int form = flags & IC_CONV3_FORM_MASK;
     if (form != IC_CONV3_AUTO && form != IC_CONV3_WINO && !(form >= IC_CONV3_WINO_SEG1 && form <= IC_CONV3_WINO_SEG3)) return 0;
     if (ic_conv3x3_c128_pick_algo(N, H, W, flags) != 1) return 0;
     long long pl[5];
-    if (ic_wino3x3_c128_plan(N, H, W, flags & (IC_CONV3_FORM_MASK | IC_CONV3_LEAVE_IDLE_CUS), pl) != IC_OK) return 0;
+    if (ic_wino3x3_c128_plan(N, H, W, flags & IC_CONV3_FORM_MASK, pl) != IC_OK) return 0;
     if (pl[0] || pl[3] || pl[4] || !pl[1]) return 0;
     return icx_wino_stack_fits(N, H, W, (int)pl[2], nlayers) ? (int)pl[2] : 0;
 }

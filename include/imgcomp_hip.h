@@ -62,8 +62,10 @@ typedef void* ic_stream_t;
  * a side branch that needs its CUs for less than the whole residual stack */
 #define IC_CONV3_LEAVE_IDLE_LAYERS(n) (((n) & 0x7f) << 12)
 #define IC_CONV3_NO_XCD_RUNS      0x20   /* natural tile order instead of contiguous runs of tiles per XCD (A/B runs) */
-#define IC_CONV3_NO_STACK_KERNEL   0x80   /* whole-network / residual-stack calls: one launch per layer even where the stack could run as
-                                            one persistent launch (conv3x3_wino_stack.hip); A/B runs and tests */
+#define IC_CONV3_STACK_KERNEL      0x80   /* whole-network / residual-stack calls: where the stack's NB-segment jobs fit the chip in one
+                                            round, run its 6B+2 layers as ONE persistent launch (conv3x3_wino_stack.hip) instead of one
+                                            launch per layer.  Bit-identical; measured level with per-layer launches, so
+                                            it is an option, not the default */
 #define IC_CONV3_PACKED_TRANSFORM 0x40   /* NB-segment kernels: input transform on v_pk_add_f32 instead of single adds (A/B) */
 #define IC_CONV3_DIRECT_VARIANT(v) ((((v) + 1) & 0xf) << 8)   /* direct form: force tile variant v (0..9); tests */
 /* h13 (ic_deconv2d_bn_act_f32, 5x5/2 transposed, 64 -> <= 4): tiles per work-group, 0 = automatic; tests */
@@ -270,9 +272,9 @@ int ic_sum_f32(const float* v, long long count, float* partial, float* out_sum, 
  * on the CUs a partly filled round leaves free).
  */
 size_t ic_ae_workspace_bytes(int N, int H, int W, int C);
-/* Where a residual stack's NB-segment jobs fit the chip in one round (a Kodak map, a 256 x 256 image), its 6B+2 layers run as
- * ONE persistent launch whose work-groups hand activations to their neighbours through flags in the workspace
- * (conv3x3_wino_stack.hip; IC_CONV3_NO_STACK_KERNEL in `flags` keeps one launch per layer; outputs are bit-identical).
+/* With IC_CONV3_STACK_KERNEL in `flags`, a residual stack whose NB-segment jobs fit the chip in one round (a Kodak map, a
+ * 256 x 256 image) runs its 6B+2 layers as ONE persistent launch whose work-groups hand activations to their neighbours
+ * through flags in the workspace (conv3x3_wino_stack.hip; outputs are bit-identical to the per-layer launches).
  * Byte offset of that sync area inside the workspace: its first 32-bit word is 0 after a call unless a hand-off timed out
  * (1 + layer index; the call's outputs are invalid then).  reference: the hot loop is one image per run, val.py:157-158. */
 size_t ic_ae_sync_pos_bytes(int N, int H, int W, int C);

@@ -57,11 +57,11 @@ def test_persistent_stack_is_bit_identical_to_per_layer_launches(cuda, shape):
     tens, _ = _stack_inputs(cuda, B, seed=shape[1] * 1000 + shape[2])
     N, H, W = shape
     x = torch.relu(torch.randn((N, 128, H, W), generator=torch.Generator().manual_seed(7))).to(cuda)
-    ref, tw0 = _run_stack(cuda, x, tens, B, _lib.CONV3_NO_STACK_KERNEL)
+    ref, tw0 = _run_stack(cuda, x, tens, B, 0)
     assert tw0 == 0
     assert bool(torch.isfinite(ref).all()) and float(ref.abs().max()) > 0
     for rep in range(4):
-        got, tw = _run_stack(cuda, x, tens, B, 0)
+        got, tw = _run_stack(cuda, x, tens, B, _lib.CONV3_STACK_KERNEL)
         assert tw == 0, 'a hand-off of the persistent stack kernel timed out at layer {}'.format(tw - 1)
         assert torch.equal(got, ref), 'persistent stack != per-layer launches (run {}): {} of {} values differ, max {}'.format(
             rep, int((got != ref).sum()), ref.numel(), float((got - ref).abs().max()))
@@ -79,8 +79,8 @@ def test_persistent_stack_takes_the_shapes_it_should(cuda):
     B = 1
     tens, _ = _stack_inputs(cuda, B, seed=5)
     x = torch.relu(torch.randn((1, 128, 136, 240), generator=torch.Generator().manual_seed(3))).to(cuda)     # 272 groups: two launches per layer
-    a, tw = _run_stack(cuda, x, tens, B, 0)
-    b, _ = _run_stack(cuda, x, tens, B, _lib.CONV3_NO_STACK_KERNEL)
+    a, tw = _run_stack(cuda, x, tens, B, _lib.CONV3_STACK_KERNEL)
+    b, _ = _run_stack(cuda, x, tens, B, 0)
     assert tw == 0 and torch.equal(a, b)
 
 
@@ -90,7 +90,7 @@ def test_persistent_stack_against_the_oracle(cuda):
     B = 2
     tens, raw = _stack_inputs(cuda, B, seed=11)
     x = torch.relu(torch.randn((1, 128, 32, 48), generator=torch.Generator().manual_seed(1))).to(cuda)
-    got, tw = _run_stack(cuda, x, tens, B, 0)
+    got, tw = _run_stack(cuda, x, tens, B, _lib.CONV3_STACK_KERNEL)
     assert tw == 0
 
     def cba(t, i, relu):
