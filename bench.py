@@ -110,6 +110,8 @@ def main():
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--no_extras', action='store_true', help='headline only: no stage split, roofline, extra shapes (rocprofv3 runs)')
     p.add_argument('--pipelined', action='store_true', help='also run the informational three-pipelines-in-flight section')
+    p.add_argument('--calib_copy', action='store_true',
+                   help='after the timed steps: a 256 MiB device-to-device copy (rocprofv3 --pmc passes calibrate FETCH_SIZE / WRITE_SIZE on it)')
     p.add_argument('--plan_flags', type=lambda v: int(v, 0), default=0,
                    help='IC_CONV3_* bits OR-ed into every encode / decode call (0x80 = IC_CONV3_STACK_KERNEL: each residual stack as one persistent launch)')
     p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
@@ -168,6 +170,12 @@ def main():
     elapsed, (bpp, x_out) = run(pipe, a.steps, a.warmup, collective=True)
     elapsed = max_over_ranks(torch, dist, elapsed, dev, world, a.backend)
     value = N * H * Wd * world * a.steps / elapsed / 1e6
+    if a.calib_copy:
+        src = torch.randn(64 * 1024 * 1024, device=dev)
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        torch.cuda.synchronize(dev)
 
     same_stream = pipe.serial or pipe.side is pipe.branch.main
     cus = pipe.branch.idle_cus(N, H, Wd) if not same_stream and pipe.side is not pipe.branch._plain else 0
@@ -248,18 +256,21 @@ def main():
             dec_l['plan'] = {'first_launches': n_idle, 'first': dec_l['plan'],
                              'remaining_launches': dec_l['layers_timed'] - n_idle, 'remaining': plan_name(lib, _lib, N, h4, w4, 0)}
         extra['decoder_idle_layers'] = n_idle if pipe.dec_flags & _lib.CONV3_LEAVE_IDLE_CUS else None
-        # PMC counters cannot be read from inside this process: rocprofv3 --pmc passes over `bench.py --no_extras`
-        # (tools/profile.sh) write profiles/r02_conv3x3_traffic.json, keyed by kernel name and shape
+        # PMC counters cannot be read from inside this process: rocprofv3 --pmc passes over `bench.py --no_extras --calib_copy`
+        # (tools/profile_round.sh) are digested into profiles/rNN_counters.json, keyed by kernel name.  The numbers are only
+        # quoted when that file describes THIS step: same input shape and the same 3x3 kernel as the plan that just ran.
         traffic = traffic_src = None
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'r02_conv3x3_traffic.json')) as f:
-                tj = json.load(f)
-            ent = tj['kernels'].get(enc_l['plan']['kernel'])
-            if ent and tj['shape'] == [N, 128, h4, w4]:
-                traffic, traffic_src = ent['hbm_bytes_per_launch'], tj['source']
-                extra['conv3x3_l2_to_l1_bytes_per_launch'] = ent.get('l2_to_l1_bytes_per_launch')
-        except (IOError, OSError, KeyError, ValueError):
-            pass
+        counters = load_counters(ROOT)
+        k3 = enc_l['plan']['kernel']
+        if counters and counters.get('input_shape') == [N, 3, H, Wd] and k3 in counters.get('kernels', {}) \
+                and counters.get('plan_3x3') == k3:
+            ent = counters['kernels'][k3]
+            traffic, traffic_src = ent.get('hbm_bytes_per_launch'), counters.get('source')
+            extra['conv3x3_counters'] = {k: ent.get(k) for k in ('l2_to_l1_bytes_per_launch', 'valu_per_mfma', 'mfma_busy_us', 'avg_us_rocprof',
+                                                                   'mfma_busy_share', 'hbm_read_bytes_per_launch', 'hbm_write_bytes_per_launch')}
+        elif counters:
+            traffic_src = 'dropped: {} describes shape {} / 3x3 kernel {}, this run is {} / {}'.format(
+                counters.get('file'), counters.get('input_shape'), counters.get('plan_3x3'), [N, 3, H, Wd], k3)
         wino = lib.ic_conv3x3_c128_pick_algo(N, h4, w4, 0) == 1
         roofline = {'kernel': enc_l['plan']['kernel'] + ' (ic_conv3x3_c128_auto_f32, encoder residual stack, in-step)',
                     'algorithm': 'winograd F(2x2,3x3)' if wino else 'direct', 'bound': 'mfma',
@@ -278,6 +289,16 @@ def main():
                        'dense_algorithmic_frac': round(FLOP_PER_SYMBOL_PC * sym / (ms_pc * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                        'ms': round(ms_pc, 4), 'symbols': sym,
                        'note': 'achieved counts the live taps of the causal masks (36,912 FLOP/symbol); SURVEY 8(d) dense figure 47,520 alongside'}
+        # ---- the six 5x5 / stride-2 layers around the stacks, each alone on the stream, on the step's own activations ----
+        try:
+            go_e, _ = res_stack('enc', 0)
+            go_e()
+            stack_out_enc = yout.clone()
+            go_d, _ = res_stack('dec', 0)
+            go_d()
+            extra['layers_5x5'] = edge_layer_table(torch, lib, _lib, W, ae, ae_cfg, pipe.x, enc.qhard, stack_out_enc, yout, timed, st, N, H, Wd)
+        except Exception as ex:                                        # informational only
+            extra['layers_5x5'] = {'error': str(ex)[:300]}
         for e in ev:
             lib.ic_event_destroy(e)
 
@@ -357,6 +378,72 @@ def main():
     if world > 1:
         dist.barrier()                 # rank 0 is still timing the stage split / dominant kernel: leave together
         dist.destroy_process_group()
+
+
+def edge_layer_table(torch, lib, _lib, W, ae, ae_cfg, x, qhard, stack_out_enc, stack_out_dec, timed, st, N, H, Wd):
+    """h1, h2, to_bn (autoencoder.py:222,223,237) and from_bn, h12, h13 (:251,264,265) one by one through the generic C-ABI
+    entry points, each fed the tensor it sees inside the step.  Per layer: time, algorithmic FLOPs (dense, 2 FLOP per
+    MAC) against the fp32 MFMA peak, algorithmic bytes (input + output activation once) against the 8 TB/s HBM peak."""
+    E, D = W.ENC, W.DEC
+    C = int(ae_cfg.num_chan_bn)
+    Cb = C + (1 if bool(ae_cfg.heatmap) else 0)
+    dev = x.device
+    P = _lib.ptr
+    half = torch.empty((N, 64, H // 2, Wd // 2), device=dev)
+    quar = torch.empty((N, 128, H // 4, Wd // 4), device=dev)
+    half_d = torch.empty_like(half)
+    quar_d = torch.empty_like(quar)
+    bott = torch.empty((N, Cb, H // 8, Wd // 8), device=dev)
+    xo = torch.empty_like(x)
+    pl = ae._plan
+    px = float(N * H * Wd)
+    layers = [
+        ('h1', 'conv5s2_cin3_mfma_kernel', lambda: lib.ic_conv2d_bn_act_f32(P(x), P(pl[E + '/h1'][0]), P(pl[E + '/h1'][1]), P(pl[E + '/h1'][2]), None, None,
+                                                                           P(half), N, 3, H, Wd, 64, 5, 5, 2, 1, None, None, st),
+         2.0 * 75 * 64 * px / 4, 4.0 * (3 * px + 64 * px / 4)),
+        ('h2', 'conv_mfma_kernel', lambda: lib.ic_conv2d_mfma_bn_act_f32(P(half), P(pl[E + '/h2'][0]), P(pl[E + '/h2'][1]), P(pl[E + '/h2'][2]), P(quar),
+                                                                        N, 64, H // 2, Wd // 2, 128, 5, 5, 2, 0, 1, st),
+         2.0 * 25 * 64 * 128 * px / 16, 4.0 * (64 * px / 4 + 128 * px / 16)),
+        ('to_bn', 'conv_mfma_kernel', lambda: lib.ic_conv2d_mfma_bn_act_f32(P(stack_out_enc), P(pl[E + '/to_bn'][0]), P(pl[E + '/to_bn'][1]), P(pl[E + '/to_bn'][2]),
+                                                                           P(bott), N, 128, H // 4, Wd // 4, Cb, 5, 5, 2, 0, 0, st),
+         2.0 * 25 * 128 * Cb * px / 64, 4.0 * (128 * px / 16 + Cb * px / 64)),
+        ('from_bn', 'deconv3_mfma_kernel', lambda: lib.ic_deconv2d_bn_act_f32(P(qhard), P(pl[D + '/from_bn'][0]), P(pl[D + '/from_bn'][1]), P(pl[D + '/from_bn'][2]),
+                                                                             P(quar_d), N, C, H // 8, Wd // 8, 128, 3, 3, 1, None, None, 0, st),
+         2.0 * 9 * C * 128 * px / 64, 4.0 * (C * px / 64 + 128 * px / 16)),
+        ('h12', 'deconv5_mfma_kernel', lambda: lib.ic_conv2d_mfma_bn_act_f32(P(stack_out_dec), P(pl[D + '/h12'][0]), P(pl[D + '/h12'][1]), P(pl[D + '/h12'][2]),
+                                                                            P(half_d), N, 128, H // 4, Wd // 4, 64, 5, 5, 2, 1, 1, st),
+         2.0 * 25 * 128 * 64 * px / 16, 4.0 * (128 * px / 16 + 64 * px / 4)),
+        ('h13', 'deconv5_cout3_mfma_kernel', lambda: lib.ic_deconv2d_bn_act_f32(P(half_d), P(pl[D + '/h13'][0]), P(pl[D + '/h13'][1]), P(pl[D + '/h13'][2]),
+                                                                               P(xo), N, 64, H // 2, Wd // 2, 3, 5, 5, 0, None, None, 0, st),
+         2.0 * 25 * 64 * 3 * px / 4, 4.0 * (64 * px / 4 + 3 * px)),
+    ]
+    out, total = [], 0.0
+    for name, kernel, fn, flop, nbytes in layers:
+        _lib.check(fn(), name)                       # also produces the next layer's input (half -> h2, half_d -> h13)
+        us = timed(fn, 20, warm=3) * 1e3
+        total += us
+        tf, gbs = flop / us / 1e6, nbytes / us / 1e3
+        out.append({'layer': name, 'kernel': kernel, 'us': round(us, 2), 'algorithmic_tflops': round(tf, 1),
+                    'frac_of_mfma_peak': round(tf / PEAK_F32_MFMA_TFLOPS, 3), 'algorithmic_bytes': int(nbytes),
+                    'hbm_gb_per_s': round(gbs, 0), 'frac_of_hbm_peak': round(gbs / 8000.0, 3),
+                    'bound': 'mfma' if flop / (PEAK_F32_MFMA_TFLOPS * 1e6) > nbytes / 8e6 else 'hbm'})
+    return {'layers': out, 'total_us': round(total, 1),
+            'note': 'each layer alone on the stream on the tensor it sees in the step; FLOPs dense (SURVEY 8(d)), bytes = input + output once'}
+
+
+def load_counters(root):
+    """the newest profiles/rNN_counters.json (tools/profile_digest.py), or None"""
+    import glob
+    files = sorted(glob.glob(os.path.join(root, 'profiles', 'r[0-9][0-9]_counters.json')))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            c = json.load(f)
+        c['file'] = os.path.relpath(files[-1], root)
+        return c
+    except (IOError, OSError, ValueError):
+        return None
 
 
 def max_over_ranks(torch, dist, elapsed, dev, world, backend):

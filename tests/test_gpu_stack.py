@@ -87,6 +87,7 @@ def test_persistent_stack_takes_the_shapes_it_should(cuda):
 def test_persistent_stack_against_the_oracle(cuda):
     """and it is the right function: fp64 restatement of the stack (conv + folded BN [+ ReLU] + skips) on a Kodak-class map"""
     import torch.nn.functional as F
+    from imgcomp_cvpr_amd import _lib
     B = 2
     tens, raw = _stack_inputs(cuda, B, seed=11)
     x = torch.relu(torch.randn((1, 128, 32, 48), generator=torch.Generator().manual_seed(1))).to(cuda)

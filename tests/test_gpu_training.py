@@ -457,7 +457,7 @@ def test_reference_training_call_sites(cuda):
     assert float(pc.auto_pad_value(ae)) == float(trainer.graph.params['autoencoder/encoder/centers'][0])
     # continuing a run: global_step and the Adam slots travel through a checkpoint
     state = trainer.state_weights()
-    assert int(state['global_step']) == 1 and 'autoencoder/encoder/h1/weights/Adam_AE_1' in state and 'Adam_PC/beta2_power' in state
+    assert int(state['global_step']) == 1 and 'autoencoder/encoder/h1/weights/Adam_AE_1' in state and 'beta2_power_1' in state and 'beta1_power' in state
     tr2 = training.Trainer(ae_config, pc_config, {k: v for k, v in state.items() if k in wts}, cuda, num_itr_per_epoch=1000)
     assert tr2.restore_training_state(state) == 1 and tr2.opt_ae.t == 1 and tr2.opt_pc.t == 1
     a = trainer.step(x_train)
