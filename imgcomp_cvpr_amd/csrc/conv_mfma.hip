@@ -31,6 +31,7 @@ struct GArgs {
     int OH, OW, OS;         // output tensor extent, grid -> output stride (2 for transposed phases)
     int Cout, relu;
     int tiles_x, tiles_y;
+    int ncot;               // 32-channel tiles in the packed filter (its stride); the launch may cover fewer (live tiles only)
     unsigned long long* prof;   // tuning builds (CM_PROF) only
 };
 
@@ -72,8 +73,16 @@ struct GGeo {
 // every stage, and the WK partial accumulators are summed through LDS in the fixed order wk = 0..WK-1
 // (deterministic, position independent).  Split-K is for layers whose output is too small to fill the chip
 // with whole-K tiles (to_bn: 6144 pixels x 33 channels, K = 3200).
-template <int NTY, int NTX, int PS, int CIN, int WM, int WN, int WK, int PT, int TR, int TC, int RD>
-__device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph, float* __restrict__ lds) {
+// KEEP: instead of storing, leave the finished values (BN scale / shift and activation applied) in keep[PT]: the caller pairs
+// the two x-phases of a transposed convolution and writes them as whole 8-byte runs (deconv5_pair_kernel).
+// X1: Cout = 32 m + 1 (to_bn with the importance map: C + 1 = 33 channels).  The one channel beyond the last full tile does
+// not get a 32-row matrix tile of its own (31 of 32 rows zero, a second work-group per pixel tile: half of the layer's matrix
+// time in round 2): every wave also accumulates it on the vector unit, one fma per k-step next to the tile's MFMA -- the B
+// operand is already in the register, the weight comes as one 16-byte load per tap from that channel's row of the packed
+// fragments.  Sum order of that channel: per (K-slice, k parity) ascending chains, then parity 0 + parity 1, then the K-slices
+// in order -- fixed and position independent like the tiles' own.
+template <int NTY, int NTX, int PS, int CIN, int WM, int WN, int WK, int PT, int TR, int TC, int RD, bool KEEP = false, bool X1 = false>
+__device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph, float* __restrict__ lds, f32x16* keep = nullptr) {
 #ifdef CM_PROF
     const unsigned long long cm_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -93,7 +102,7 @@ __device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph,
     const int tx_ = b % a.tiles_x; b /= a.tiles_x;
     const int ty_ = b % a.tiles_y; const int n = b / a.tiles_y;
     const int cot = blockIdx.y * WM + wm;                 // this wave's 32-channel output tile
-    const int ncot = gridDim.y * WM;
+    const int ncot = a.ncot;
     const int gx0 = tx_ * TC, gy0 = ty_ * TR;
     const int IHW = a.IH * a.IW;
     const float* __restrict__ xin = a.x + (size_t)n * CIN * IHW;
@@ -157,6 +166,20 @@ __device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph,
     f32x4 ring[RD];
 #pragma unroll
     for (int t = 0; t < RD - 2; ++t) ring[t] = wload(wk_u, t);
+    // X1: the extra channel's weights for this lane's k parity -- row 0 of the fragments of tile (Cout - 1) / 32: floats
+    // [0..3] (parity 0) and [128..131] (parity 1) of each 256-float fragment
+    static_assert(!X1 || (PT == 1 && WM == 1 && WN == 1), "extra channel: one pixel tile per wave");
+    const int cotx_u = X1 ? (a.Cout - 1) / 32 : 0;
+    const unsigned xlane = (unsigned)(lane >> 5) * 512u;
+    auto xload = [&](int c8, int t) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, xlane, c8 * cstep + t * wstep + cotx_u * 1024, 0));
+    };
+    f32x4 xring[X1 ? RD : 1];
+    float accx = 0.f;
+    if constexpr (X1) {
+#pragma unroll
+        for (int t = 0; t < RD - 2; ++t) xring[t] = xload(wk_u, t);
+    }
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
         const float v = xin[goff[i]];
@@ -191,6 +214,10 @@ __device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph,
                 const int tn = t + RD - 2;
                 if (tn < NT) ring[tn % RD] = wload(c8, tn);
                 else ring[tn % RD] = wload(c8n, tn - NT);
+                if constexpr (X1) {
+                    if (tn < NT) xring[tn % RD] = xload(c8, tn);
+                    else xring[tn % RD] = xload(c8n, tn - NT);
+                }
             }
             if (t + 1 < NT) {
                 const int tapoff = ((t + 1) / NTX) * S + ((t + 1) % NTX);
@@ -205,11 +232,16 @@ __device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph,
 #pragma unroll
                 for (int p = 0; p < PT; ++p)
                     acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[t & 1][ks][p], acc[p], 0, 0, 0);
+                // volatile asm: left to the compiler, the whole fma chain sinks behind the K loop and drags every B operand
+                // of the chunk along in registers (256 VGPR + 112 AGPR, one wave per SIMD)
+                if constexpr (X1) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(accx) : "v"(xring[t % RD][ks]), "v"(bq[t & 1][ks][0]));
             }
 #pragma unroll
             for (int i = 0; i < 4 * PT; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // 1 MFMA
                 if (i == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // the tap's filter request
+                if (X1 && i == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // ... and the extra channel's
+                if (X1) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);         // the extra channel's fma of this k-step
                 if (t + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // 1 LDS read of the next tap
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -250,6 +282,40 @@ __device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph,
                 acc[p][rr] = sum;                          // compacted: slot rr now holds register wk*RPW + rr
             }
     }
+    if constexpr (X1) {
+        // pixel j of the tile: parity 0 + parity 1 (lanes j and j + 32), then the K-slices in order through LDS
+        const float half_sum = accx + __shfl_xor(accx, 32);
+        if (WK > 1) {
+            __syncthreads();                               // the reduction scratch above is read: reuse its first floats
+            if (lane < 32) lds[wk * 32 + lane] = half_sum;
+            __syncthreads();
+        }
+        if (wk == 0 && lane < 32) {
+            float sum = WK > 1 ? 0.f : half_sum;
+            if (WK > 1) {
+#pragma unroll
+                for (int k2 = 0; k2 < WK; ++k2) sum += lds[k2 * 32 + lane];
+            }
+            const int cx = a.Cout - 1;
+            const int q = lane, gy = gy0 + q / TC, gx = gx0 + q % TC;
+            if (gy < a.GH && gx < a.GW) {
+                float v = fmaf(sum, a.scale[cx], a.shift[cx]);
+                if (a.relu) v = fmaxf(v, 0.f);
+                y[((size_t)n * a.Cout + cx) * OHW + (size_t)(gy * a.OS + ph.py) * a.OW + (gx * a.OS + ph.px)] = v;
+            }
+        }
+    }
+    if constexpr (KEEP) {
+        static_assert(!KEEP || WK == 1, "paired phases: whole-K waves");
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = fmaf(acc[p][r], bsc[r], bsh[r]);
+                keep[p][r] = a.relu ? fmaxf(v, 0.f) : v;
+            }
+        return;
+    }
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
         const int q = 32 * (PT * wn + p) + j;
@@ -261,7 +327,7 @@ __device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph,
                 const int r = (WK > 1 ? wk * RPW : 0) + rr;
                 const int crow = (r & 3) + 8 * (r >> 2);
                 const int co = 32 * cot + crow + 4 * kh;
-                if (co < a.Cout) {
+                if (co < (X1 ? a.Cout - 1 : a.Cout)) {
                     float v = fmaf(acc[p][rr], bsc[rr], bsh[rr]);
                     if (a.relu) v = fmaxf(v, 0.f);
                     y[pix + (size_t)crow * OHW] = v;
@@ -283,6 +349,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const GArgs a, const GPh
     conv_mfma_body<NTY, NTX, PS, CIN, WM, WN, WK, PT, TR, TC, RD>(a, ph, lds);
 }
 
+template <int NTY, int NTX, int PS, int CIN, int WM, int WN, int WK, int PT, int TR, int TC, int RD>
+__global__ __launch_bounds__(256) void conv_mfma_x1_kernel(const GArgs a, const GPhase ph) {
+    __shared__ float lds[GGeo<NTY, NTX, PS, WK, TR, TC>::LDSF];
+    conv_mfma_body<NTY, NTX, PS, CIN, WM, WN, WK, PT, TR, TC, RD, false, true>(a, ph, lds);
+}
+
 // all four output phases of a 5x5 / stride-2 transposed convolution in ONE launch (blockIdx.z = phase): 1.5 k
 // work-groups of unequal length that the dispatcher packs onto the CUs as slots free up.
 struct GPhases4 { GPhase p[4]; };
@@ -294,6 +366,50 @@ __global__ __launch_bounds__(256) void deconv5_mfma_kernel(const GArgs a, const 
         case 1: conv_mfma_body<2, 3, 1, CIN, WM, WN, 1, PT, TR, TC, 3>(a, ph.p[1], lds); break;
         case 2: conv_mfma_body<3, 2, 1, CIN, WM, WN, 1, PT, TR, TC, 3>(a, ph.p[2], lds); break;
         default: conv_mfma_body<3, 3, 1, CIN, WM, WN, 1, PT, TR, TC, 3>(a, ph.p[3], lds); break;
+    }
+}
+
+// The same layer with the two x-phases of an output row pair computed by ONE work-group, one after the other on the same
+// pixel tile (blockIdx.z = py): lane j then holds the outputs (2 gy + py, 2 gx) and (2 gy + py, 2 gx + 1) of its pixel and
+// writes them as one 8-byte store -- consecutive lanes fill whole cache lines.  With a work-group per phase (the kernel
+// above) every store instruction writes every other float of its lines and the two halves of a line come from different
+// work-groups at different times: rocprofv3 counted 46.7 MB written for a 25.2 MB output (profiles/r03_counters.txt).
+typedef float f32x2g __attribute__((ext_vector_type(2)));
+template <int CIN, int WM, int WN, int PT, int TR, int TC>
+__global__ __launch_bounds__(256) void deconv5_pair_kernel(const GArgs a, const GPhases4 ph) {
+    __shared__ float lds[GGeo<3, 3, 1, 1, TR, TC>::LDSF];
+    f32x16 v0[PT], v1[PT];
+    const int py = blockIdx.z;
+    if (py == 0) {               // taps 2x2 then 2x3
+        conv_mfma_body<2, 2, 1, CIN, WM, WN, 1, PT, TR, TC, 4, true>(a, ph.p[0], lds, v0);
+        conv_mfma_body<2, 3, 1, CIN, WM, WN, 1, PT, TR, TC, 3, true>(a, ph.p[1], lds, v1);
+    } else {                     // taps 3x2 then 3x3
+        conv_mfma_body<3, 2, 1, CIN, WM, WN, 1, PT, TR, TC, 3, true>(a, ph.p[2], lds, v0);
+        conv_mfma_body<3, 3, 1, CIN, WM, WN, 1, PT, TR, TC, 3, true>(a, ph.p[3], lds, v1);
+    }
+    // same decomposition as the body's: tile, channel tile, pixel of this lane
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave % WM, wn = (wave / WM) % WN;
+    int b = ic_xcd_run(blockIdx.x, gridDim.x);
+    const int tx_ = b % a.tiles_x; b /= a.tiles_x;
+    const int ty_ = b % a.tiles_y; const int n = b / a.tiles_y;
+    const int cot = blockIdx.y * WM + wm;
+    const int j = lane & 31, kh = lane >> 5;
+    const size_t OHW = (size_t)a.OH * a.OW;
+    float* __restrict__ y = a.y + ((size_t)n * a.Cout + 32 * cot + 4 * kh) * OHW;
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int q = 32 * (PT * wn + p) + j;
+        const int gy = ty_ * TR + q / TC, gx = tx_ * TC + q % TC;
+        if (gy < a.GH && gx < a.GW) {
+            const size_t pix = (size_t)(gy * 2 + py) * a.OW + gx * 2;           // OW = 2 GW: 8-byte aligned
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int crow = (r & 3) + 8 * (r >> 2);
+                if (32 * cot + crow + 4 * kh < a.Cout)
+                    *(f32x2g*)(y + pix + (size_t)crow * OHW) = f32x2g{v0[p][r], v1[p][r]};
+            }
+        }
     }
 }
 
@@ -369,7 +485,7 @@ extern "C" int ic_conv2d_mfma_bn_act_f32(const float* x, const float* w_packed, 
     const int ncot = ncot_for(Cout);
     GArgs a{};
     a.x = x; a.scale = scale; a.shift = shift; a.y = y;
-    a.N = N; a.IH = H; a.IW = W; a.Cout = Cout; a.relu = relu; a.prof = g_cm_prof;
+    a.N = N; a.IH = H; a.IW = W; a.Cout = Cout; a.relu = relu; a.prof = g_cm_prof; a.ncot = ncot;
     if (!transposed) {
         GPhase ph{};
         ph.wp = w_packed; ph.py = 0; ph.px = 0;
@@ -378,15 +494,19 @@ extern "C" int ic_conv2d_mfma_bn_act_f32(const float* x, const float* w_packed, 
         if (KH == 3) {              // from_bn's adjoint: as to_bn, 9 taps
             a.tiles_x = ic_cdiv(a.GW, 16); a.tiles_y = ic_cdiv(a.GH, 2);
             hipLaunchKernelGGL((conv_mfma_kernel<3, 3, 2, 128, 1, 1, 4, 1, 2, 16, 3>),
-                               dim3(a.tiles_x * a.tiles_y * N, ncot), dim3(256), 0, st, a, ph);
+                               dim3(a.tiles_x * a.tiles_y * N, ic_cdiv(Cout, 32)), dim3(256), 0, st, a, ph);   // live channel tiles only
         } else if (Cin == 64) {     // h2: 4 channel tiles x 32 pixels per work-group
             a.tiles_x = ic_cdiv(a.GW, 16); a.tiles_y = ic_cdiv(a.GH, 2);
             hipLaunchKernelGGL((conv_mfma_kernel<5, 5, 2, 64, 4, 1, 1, 1, 2, 16, 5>),
                                dim3(a.tiles_x * a.tiles_y * N, ncot / 4), dim3(256), 0, st, a, ph);
         } else {                    // to_bn: 1 channel tile x 32 pixels x 4 K-slices per work-group
             a.tiles_x = ic_cdiv(a.GW, 16); a.tiles_y = ic_cdiv(a.GH, 2);
-            hipLaunchKernelGGL((conv_mfma_kernel<5, 5, 2, 128, 1, 1, 4, 1, 2, 16, 5>),
-                               dim3(a.tiles_x * a.tiles_y * N, ncot), dim3(256), 0, st, a, ph);
+            if (Cout % 32 == 1 && Cout > 1)     // C + 1 channels with the importance map: the odd one rides on the vector unit
+                hipLaunchKernelGGL((conv_mfma_x1_kernel<5, 5, 2, 128, 1, 1, 4, 1, 2, 16, 5>),
+                                   dim3(a.tiles_x * a.tiles_y * N, (Cout - 1) / 32), dim3(256), 0, st, a, ph);
+            else
+                hipLaunchKernelGGL((conv_mfma_kernel<5, 5, 2, 128, 1, 1, 4, 1, 2, 16, 5>),
+                                   dim3(a.tiles_x * a.tiles_y * N, ic_cdiv(Cout, 32)), dim3(256), 0, st, a, ph);
         }
     } else {                        // h12: four phases, 2 channel tiles x 2 pixel groups of 32 per work-group
         a.GH = H; a.GW = W; a.OH = 2 * H; a.OW = 2 * W; a.OS = 2;
@@ -403,8 +523,13 @@ extern "C" int ic_conv2d_mfma_bn_act_f32(const float* x, const float* w_packed, 
                 off += (size_t)nch * nty * ntx * ncot * 256;
             }
         a.tiles_x = ic_cdiv(a.GW, 16); a.tiles_y = ic_cdiv(a.GH, 4);
+#ifdef CM_UNPAIRED      // tuning builds: the round-2 form, a work-group per phase
         hipLaunchKernelGGL((deconv5_mfma_kernel<128, 2, 2, 1, 4, 16>),
                            dim3(a.tiles_x * a.tiles_y * N, ncot / 2, 4), dim3(256), 0, st, a, ph);
+#else
+        hipLaunchKernelGGL((deconv5_pair_kernel<128, 2, 2, 1, 4, 16>),
+                           dim3(a.tiles_x * a.tiles_y * N, ncot / 2, 2), dim3(256), 0, st, a, ph);
+#endif
     }
     IC_LAUNCH_CHECK();
     return IC_OK;

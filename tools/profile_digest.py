@@ -1,80 +1,161 @@
 #!/usr/bin/env python
 """Turn the rocprofv3 outputs of tools/profile_round.sh (gpurun_out/prof_*) into the files committed under profiles/:
-   python tools/profile_digest.py r02"""
+       python tools/profile_digest.py r03
+   rNN_bench_kernel_stats.csv / rNN_pc_kernel_stats.csv / rNN_train_kernel_stats.csv   rocprofv3 --stats tables (copied)
+   rNN_*_line_under_rocprof.json                                                       the JSON line the profiled command printed
+   rNN_counters.json / rNN_counters.txt      per kernel of the bench step: launches per step, average duration (trace), the PMC
+                                             passes (SQ / FETCH_SIZE / WRITE_SIZE / L2), HBM bytes calibrated on the 256 MiB copy of
+                                             the same pass, MFMA-pipe busy time and its share of the launch -- what bench.py quotes
+All passes profile the same command (the bench step in the shipped schedule), so one table covers every kernel of the step."""
 import csv, json, os, re, shutil, sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, 'gpurun_out')
 P = os.path.join(ROOT, 'profiles')
+SIMDS, CLOCK_GHZ = 1024, 2.4
+COPY_BYTES = 268435456.0          # the calibration copy: 64 Mi floats read + 64 Mi floats written
+
+
+def short(name):
+    """kernel name as bench.py's plan names it: no 'void ', no argument list, template args reduced to the leading integers"""
+    k = name.replace('void ', '').split('(')[0].strip()
+    m = re.match(r'([\w:]+)<(.*)>$', k)
+    if m:
+        ints = [a.strip() for a in m.group(2).split(',')]
+        lead = []
+        for a_ in ints:
+            if re.match(r'^-?\d+$', a_):
+                lead.append(a_)
+            else:
+                break
+        base = m.group(1)
+        if base == 'wino3x3_c128_tn_kernel' or base == 'wino3x3_c128_stack_kernel':
+            return '{}<{}>'.format(base, lead[0])
+        if base.startswith('wino3x3_c128'):
+            return base
+        return base + ('<{}>'.format(', '.join(ints)) if ints else '')
+    return k
+
+
+CAL = {}          # counter -> value of the LARGEST copy dispatch of its pass (the 256 MiB calibration copy; small copies abound)
 
 
 def per_kernel(path):
     acc, calls = defaultdict(lambda: defaultdict(float)), defaultdict(set)
+    per_dispatch = defaultdict(lambda: defaultdict(float))
     with open(path) as f:
         for r in csv.DictReader(f):
-            k = r['Kernel_Name'].split('(')[0].replace('void ', '')
+            k = short(r['Kernel_Name'])
             acc[k][r['Counter_Name']] += float(r['Counter_Value'])
             calls[k].add(r['Dispatch_Id'])
+            if 'copyBuffer' in k:
+                per_dispatch[r['Counter_Name']][r['Dispatch_Id']] += float(r['Counter_Value'])
+    for c, d in per_dispatch.items():
+        CAL[c] = max(d.values())
     return {k: {c: v / len(calls[k]) for c, v in acc[k].items()} for k in acc}, {k: len(v) for k, v in calls.items()}
 
 
 def find(d, suffix, prefix=''):
-    for fn in sorted(os.listdir(os.path.join(G, d))):
-        if fn.endswith(suffix) and fn.startswith(prefix):
-            return os.path.join(G, d, fn)
+    dd = os.path.join(G, d)
+    if not os.path.isdir(dd):
+        return None
+    for root, _, files in os.walk(dd):
+        for fn in sorted(files):
+            if fn.endswith(suffix) and fn.startswith(prefix):
+                return os.path.join(root, fn)
     return None
 
 
+def bench_line(d):
+    log = os.path.join(G, d, 'stdout.log')
+    if not os.path.exists(log):
+        return None
+    m = re.findall(r'^\{"metric".*\}$', open(log).read(), flags=re.M)
+    return json.loads(m[-1]) if m else None
+
+
 for t in ('bench', 'pc', 'train'):
-    src = find('prof_' + t, 'kernel_stats.csv', t + '_')
+    src = find('prof_' + t, 'kernel_stats.csv')
     if src:
         shutil.copy(src, os.path.join(P, '{}_{}_kernel_stats.csv'.format(tag, t)))
-    log = os.path.join(G, 'prof_' + t, 'stdout.log')
-    if os.path.exists(log):
-        m = re.findall(r'^\{"metric".*\}$', open(log).read(), flags=re.M)
-        if m:
-            open(os.path.join(P, '{}_{}_line_under_rocprof.json'.format(tag, t)), 'w').write(m[-1] + '\n')
+    line = bench_line('prof_' + t)
+    if line:
+        json.dump(line, open(os.path.join(P, '{}_{}_line_under_rocprof.json'.format(tag, t)), 'w'))
 
-traffic = {'shape': [1, 128, 128, 192], 'source': 'profiles/{}_wino_pmc.txt: rocprofv3 --pmc passes over tools/run_layer.py (tools/profile_round.sh), one counter group per pass'.format(tag),
-           'kernels': {}}
-lines = ['rocprofv3 --pmc passes, one 3x3 128->128 layer on the Kodak residual-stack shape (1,128,128,192), 20 back-to-back launches per pass,',
-         'per-launch averages.  FETCH_SIZE / WRITE_SIZE are in KiB (TCC_EA0 requests x 64 B / 1024).  Calibration in the same pass: a 256 MiB',
-         'device-to-device copy (64 Mi floats read, 64 Mi written).', '']
-for form, kname in (('seg3', 'wino3x3_c128_tn_kernel<3, false, true>'), ('wholek', 'wino3x3_c128_shared_kernel<true>')):
-    ent = {}
-    lines.append('== form {} : kernel {}'.format(form, kname))
-    for grp in ('fetch', 'write', 'l2', 'ea', 'sq'):
-        path = find('prof_l_{}_{}'.format(form, grp), 'counter_collection.csv')
-        if not path:
-            continue
-        vals, calls = per_kernel(path)
-        k = vals.get(kname, {})
-        cal = vals.get('__amd_rocclr_copyBuffer', {})
-        for c, v in sorted(k.items()):
-            lines.append('   {:28s} {:16.1f}'.format(c, v) + ('      [256 MiB copy: {:.1f}]'.format(cal[c]) if c in cal else ''))
-            ent[c] = v
-            if c in cal:
-                ent['calib_copy_' + c] = cal[c]
-    if 'FETCH_SIZE' in ent:
-        # gfx950: FETCH_SIZE tallies 128-byte fabric reads at 64 B (MI355X_MICROARCH.md, HBM section); the 256 MiB copy of the same
-        # pass calibrates it: bytes = counter KiB * 1024 * (268435456 / (calib KiB * 1024))
-        f = 268435456.0 / (ent['calib_copy_FETCH_SIZE'] * 1024.0)
-        w = 268435456.0 / (ent['calib_copy_WRITE_SIZE'] * 1024.0)
-        rd, wr = ent['FETCH_SIZE'] * 1024.0 * f, ent['WRITE_SIZE'] * 1024.0 * w
-        l2l1 = ent['TCP_TCC_READ_REQ_sum'] * (268435456.0 / ent['calib_copy_TCP_TCC_READ_REQ_sum'])
-        kkey = re.sub(r'<(\d+), \w+, \w+>', r'<\1>', kname).replace('<true>', '')      # bench.py's plan names
-        traffic['kernels'][kkey] = {
-            'fetch_counter_kib': ent['FETCH_SIZE'], 'write_counter_kib': ent['WRITE_SIZE'], 'fetch_calibration_factor': round(f, 3),
-            'write_calibration_factor': round(w, 3), 'hbm_read_bytes_per_launch': int(rd), 'hbm_write_bytes_per_launch': int(wr),
-            'hbm_bytes_per_launch': int(rd + wr), 'l2_to_l1_bytes_per_launch': int(l2l1),
-            'l2_hit_rate': round(ent['TCC_HIT_sum'] / (ent['TCC_HIT_sum'] + ent['TCC_MISS_sum']), 3),
-            'mfma_per_launch': int(ent.get('SQ_INSTS_MFMA', 0)), 'valu_per_mfma': round(ent.get('SQ_INSTS_VALU', 0) / max(ent.get('SQ_INSTS_MFMA', 1), 1), 2),
-            'mfma_busy_share_of_wave_cycles': round(ent.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(4.0 * ent.get('SQ_WAVE_CYCLES', 1), 1), 3)}
-        lines.append('   -> HBM read {:.1f} MB + written {:.1f} MB per launch (calibrated x{:.2f} / x{:.2f}); L2 -> L1 {:.1f} MB; L2 hit rate {:.2f}'.format(
-            rd / 1e6, wr / 1e6, f, w, l2l1 / 1e6, traffic['kernels'][kkey]['l2_hit_rate']))
+# ---- per-kernel durations of the bench step from the kernel trace ----
+trace = find('prof_bench', 'kernel_trace.csv')
+dur, cnt = defaultdict(float), defaultdict(int)
+if trace:
+    with open(trace) as f:
+        for r in csv.DictReader(f):
+            k = short(r['Kernel_Name'])
+            dur[k] += (float(r['End_Timestamp']) - float(r['Start_Timestamp'])) / 1e3
+            cnt[k] += 1
+line = bench_line('prof_bench') or {}
+steps = int(line.get('steps', 20)) + int(line.get('warmup', 5))
+cfg = line.get('config', {})
+out = {'source': 'profiles/{}_counters.txt: rocprofv3 --kernel-trace and --pmc passes over `python bench.py --steps 20 --warmup 5 --no_extras '
+                 '--calib_copy` (tools/profile_round.sh), one counter group per pass'.format(tag),
+       'input_shape': [cfg.get('batch_per_gpu'), 3, cfg.get('height'), cfg.get('width')], 'branch_sharing': line.get('branch_sharing'),
+       'steps_profiled': steps, 'value_under_rocprof': line.get('value'), 'kernels': {}}
+groups = {}
+for grp in ('sq', 'fetch', 'write', 'l2'):
+    path = find('prof_b_' + grp, 'counter_collection.csv')
+    if path:
+        groups[grp] = per_kernel(path)
+lines = ['rocprofv3 passes over the bench step (python bench.py --steps 20 --warmup 5 --no_extras --calib_copy), per-launch averages per kernel.',
+         'FETCH_SIZE / WRITE_SIZE are in KiB; the 256 MiB device copy at the end of the same pass calibrates them (gfx950: FETCH_SIZE tallies',
+         '128-byte fabric reads at 64 B -> x2, MI355X_MICROARCH.md "HBM"; WRITE_SIZE exact).  mfma_busy_us = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs',
+         '/ 2.4 GHz.  avg_us = kernel-trace duration.', '']
+names = sorted(dur, key=lambda k: -dur[k])
+cal = dict(CAL)
+f_fetch = COPY_BYTES / (cal['FETCH_SIZE'] * 1024.0) if cal.get('FETCH_SIZE') else 2.0
+f_write = COPY_BYTES / (cal['WRITE_SIZE'] * 1024.0) if cal.get('WRITE_SIZE') else 1.0
+f_req = COPY_BYTES / cal['TCP_TCC_READ_REQ_sum'] if cal.get('TCP_TCC_READ_REQ_sum') else 128.0
+out['calibration'] = {'fetch_factor': round(f_fetch, 3), 'write_factor': round(f_write, 3), 'bytes_per_tcp_tcc_read_req': round(f_req, 1)}
+for k in names:
+    if 'copyBuffer' in k or cnt[k] < steps // 2:
+        continue
+    ent = {'launches_per_step': round(cnt[k] / float(steps), 2), 'avg_us_rocprof': round(dur[k] / cnt[k], 2),
+           'share_of_kernel_time': round(dur[k] / sum(dur.values()), 4)}
+    c = {}
+    for grp, (vals, _) in groups.items():
+        c.update(vals.get(k, {}))
+    if c:
+        ent['counters'] = {n: round(v, 1) for n, v in sorted(c.items())}
+        if 'FETCH_SIZE' in c:
+            ent['hbm_read_bytes_per_launch'] = int(c['FETCH_SIZE'] * 1024.0 * f_fetch)
+        if 'WRITE_SIZE' in c:
+            ent['hbm_write_bytes_per_launch'] = int(c['WRITE_SIZE'] * 1024.0 * f_write)
+        if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
+            ent['hbm_bytes_per_launch'] = ent['hbm_read_bytes_per_launch'] + ent['hbm_write_bytes_per_launch']
+            ent['hbm_gb_per_s'] = round(ent['hbm_bytes_per_launch'] / ent['avg_us_rocprof'] / 1e3, 0)
+        if 'TCP_TCC_READ_REQ_sum' in c:
+            ent['l2_to_l1_bytes_per_launch'] = int(c['TCP_TCC_READ_REQ_sum'] * f_req)
+        if c.get('TCC_HIT_sum') is not None and c.get('TCC_MISS_sum') is not None and c['TCC_HIT_sum'] + c['TCC_MISS_sum'] > 0:
+            ent['l2_hit_rate'] = round(c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum']), 3)
+        if c.get('SQ_INSTS_MFMA'):
+            ent['mfma_per_launch'] = int(c['SQ_INSTS_MFMA'])
+            # SQ_INSTS_VALU counts the MFMAs too (they are VALU-class): vector instructions BESIDE the matrix pipe = the difference
+            ent['valu_per_mfma'] = round((c.get('SQ_INSTS_VALU', 0) - c['SQ_INSTS_MFMA']) / c['SQ_INSTS_MFMA'], 2)
+            ent['valu_incl_mfma_per_mfma'] = round(c.get('SQ_INSTS_VALU', 0) / c['SQ_INSTS_MFMA'], 2)
+        if c.get('SQ_VALU_MFMA_BUSY_CYCLES'):
+            ent['mfma_busy_us'] = round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / SIMDS / CLOCK_GHZ / 1e3, 2)
+            ent['mfma_busy_share'] = round(ent['mfma_busy_us'] / ent['avg_us_rocprof'], 3)
+    out['kernels'][k] = ent
+    lines.append('== {}   ({} per step, avg {} us, {:.1f} % of the step\'s kernel time)'.format(k, ent['launches_per_step'], ent['avg_us_rocprof'],
+                                                                                          100 * ent['share_of_kernel_time']))
+    for n, v in sorted(ent.get('counters', {}).items()):
+        lines.append('   {:28s} {:16.1f}'.format(n, v) + ('      [256 MiB copy: {:.1f}]'.format(cal[n]) if n in cal else ''))
+    for n in ('hbm_read_bytes_per_launch', 'hbm_write_bytes_per_launch', 'hbm_gb_per_s', 'l2_to_l1_bytes_per_launch', 'l2_hit_rate', 'valu_per_mfma',
+              'mfma_busy_us', 'mfma_busy_share'):
+        if n in ent:
+            lines.append('   -> {:30s} {}'.format(n, ent[n]))
     lines.append('')
-open(os.path.join(P, tag + '_wino_pmc.txt'), 'w').write('\n'.join(lines) + '\n')
-json.dump(traffic, open(os.path.join(P, tag + '_conv3x3_traffic.json'), 'w'), indent=1)
-print('\n'.join(lines))
+k3 = [k for k in out['kernels'] if k.startswith('wino3x3_c128') or k.startswith('conv3x3_c128')]
+out['plan_3x3'] = ' + '.join(sorted(k3, key=lambda k: -out['kernels'][k]['launches_per_step'])) if k3 else None
+open(os.path.join(P, tag + '_counters.txt'), 'w').write('\n'.join(lines) + '\n')
+json.dump(out, open(os.path.join(P, tag + '_counters.json'), 'w'), indent=1)
+print('\n'.join(lines[:400]))
