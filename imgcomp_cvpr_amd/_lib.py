@@ -84,6 +84,7 @@ PROTOTYPES = {
     'ic_pc_decode_f32': (c_int, [c_void_p, c_longlong, c_int, POINTER(c_void_p), c_void_p, c_int, c_int, c_float,
                                  c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     'ic_sum_f32': (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p]),
+    'ic_mean_f32': (c_int, [c_void_p, c_longlong, c_float, c_void_p, c_void_p, c_void_p]),
     'ic_ae_workspace_bytes': (c_size_t, [c_int] * 4),
     'ic_ae_sync_pos_bytes': (c_size_t, [c_int] * 4),
     'ic_ae_res_stack_sync_pos_bytes': (c_size_t, [c_int] * 3),
@@ -93,6 +94,14 @@ PROTOTYPES = {
                          [c_int] * 3 + [c_void_p, c_size_t, c_int, c_void_p]),
     'ic_ae_res_stack_workspace_bytes': (c_size_t, [c_int] * 3),
     'ic_ae_res_stack_f32': (c_int, [c_void_p, POINTER(c_void_p), c_int, c_void_p] + [c_int] * 3 + [c_void_p, c_size_t, c_int, c_void_p]),
+    'ic_peer_region_bytes': (c_size_t, []),
+    'ic_peer_max_values': (c_int, []),
+    'ic_peer_max_world': (c_int, []),
+    'ic_peer_region_create': (c_int, [c_void_p, c_void_p]),
+    'ic_peer_region_open': (c_int, [c_void_p, c_void_p]),
+    'ic_peer_region_close': (c_int, [c_void_p]),
+    'ic_peer_region_destroy': (c_int, [c_void_p]),
+    'ic_peer_allreduce_f64': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_uint32, c_void_p, c_void_p]),
     'ic_bn_workspace_bytes': (c_size_t, [c_int]),
     'ic_bn_stats_f32': (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p, c_void_p]),
     'ic_bn_train_stats_f32': (c_int, [c_void_p] * 5 + [c_float] * 2 + [c_void_p] * 4 + [c_int] * 3 + [c_void_p, c_void_p]),

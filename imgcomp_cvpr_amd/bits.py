@@ -14,12 +14,12 @@ def num_pixels_in_input_batch(input_batch):
 
 def bitcost_to_bpp(bit_cost, input_batch):
     """sum(bit_cost) / num_pixels -> 0-d float32 device tensor (reference code/bits.py:4-14).
-    The sum is a deterministic two-stage tree reduction on the device (ic_sum_f32)."""
+    Sum and division are one deterministic two-stage tree reduction on the device (ic_mean_f32)."""
     assert bit_cost.dim() == input_batch.dim() == 4, 'Expected NChw and N3HW'
     _lib.require_cuda(bit_cost, 'bit_cost')
     bit_cost = bit_cost.contiguous()
-    partial = torch.empty(1024, dtype=torch.float32, device=bit_cost.device)
-    out = torch.empty(1, dtype=torch.float32, device=bit_cost.device)
-    check(lib.ic_sum_f32(ptr(bit_cost), bit_cost.numel(), ptr(partial), ptr(out),
-                         _lib.current_stream(bit_cost.device)), 'ic_sum_f32')
-    return out[0] / float(num_pixels_in_input_batch(input_batch))
+    buf = torch.empty(1024 + 1, dtype=torch.float32, device=bit_cost.device)          # [partial sums | result]
+    out = buf[1024:]
+    check(lib.ic_mean_f32(ptr(bit_cost), bit_cost.numel(), float(num_pixels_in_input_batch(input_batch)), ptr(buf), ptr(out),
+                          _lib.current_stream(bit_cost.device)), 'ic_mean_f32')
+    return out[0]

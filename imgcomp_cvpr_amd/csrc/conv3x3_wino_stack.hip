@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void wino3x3_c128_stack_kerne
     constexpr int SLOT = 4 * NB * 4 * 64;
     __shared__ f32x4 ring[3 * SLOT];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63, kq = lane >> 4, tj = lane & 15;
+    const int lane = threadIdx.x & 63, kq = lane >> 4;
     const int b = a.xcd_runs ? ic_xcd_run(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const int hc = b & 1, job = b >> 1;
     const int ct = 4 * hc + wave;

@@ -1641,7 +1641,7 @@ __global__ __launch_bounds__(256) void sum_stage1(const float* __restrict__ v, l
     }
     if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
 }
-__global__ __launch_bounds__(256) void sum_stage2(const float* __restrict__ partial, int n, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void sum_stage2(const float* __restrict__ partial, int n, float* __restrict__ out, float denom) {
     __shared__ float sh[256];
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
@@ -1651,7 +1651,7 @@ __global__ __launch_bounds__(256) void sum_stage2(const float* __restrict__ part
         if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = sh[0];
+    if (threadIdx.x == 0) out[0] = denom != 0.f ? sh[0] / denom : sh[0];       // IEEE division: what `sum / n` computes in fp32
 }
 
 extern "C" int ic_sum_f32(const float* v, long long count, float* partial, float* out_sum, ic_stream_t stream) {
@@ -1659,7 +1659,19 @@ extern "C" int ic_sum_f32(const float* v, long long count, float* partial, float
     long long g = (count + 255) / 256;
     const int blocks = (int)(g > 1024 ? 1024 : g);
     hipLaunchKernelGGL(sum_stage1, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, count, partial);
-    hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, blocks, out_sum);
+    hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, blocks, out_sum, 0.f);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
+// sum(v) / denom in the same two launches (bits.py:4-14: bpp = sum(bits) / num_pixels; the division rides in stage 2
+// instead of a separate elementwise launch behind it)
+extern "C" int ic_mean_f32(const float* v, long long count, float denom, float* partial, float* out, ic_stream_t stream) {
+    IC_CHECK_ARG(v && partial && out && count > 0 && denom != 0.f);
+    long long g = (count + 255) / 256;
+    const int blocks = (int)(g > 1024 ? 1024 : g);
+    hipLaunchKernelGGL(sum_stage1, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, count, partial);
+    hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, blocks, out, denom);
     IC_LAUNCH_CHECK();
     return IC_OK;
 }

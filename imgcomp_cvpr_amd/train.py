@@ -291,6 +291,9 @@ def build_arg_parser():
     p.add_argument('--max_itr', type=int, default=1000, help='iterations to run (the reference runs until interrupted)')
     p.add_argument('--no_sync_bn', action='store_const', const=True,
                    help='data parallel: BatchNorm statistics per rank instead of over the whole (split) batch')
+    p.add_argument('--sync_bn_p2p', action='store_const', const=True,
+                   help='data parallel: exchange the BatchNorm moments over peer-mapped memory (one small launch per layer) '
+                        'instead of an RCCL all-reduce per layer')
     return p
 
 
@@ -320,7 +323,7 @@ def main(argv=None):
           flags.log_dir_root, loader_fn, flags.max_itr, flags.log_interval_train, flags.log_interval_save, flags.restore,
           log_interval_test=flags.log_interval_test, test_loader_fn=test_loader_fn, restore_itr=flags.restore_itr,
           restore_continue=bool(flags.restore_continue), restore_skip_vars=flags.restore_skip_vars,
-          from_identity=flags.from_identity, sync_bn=False if flags.no_sync_bn else None)
+          from_identity=flags.from_identity, sync_bn=False if flags.no_sync_bn else ('p2p' if flags.sync_bn_p2p else None))
 
 
 if __name__ == '__main__':

@@ -24,10 +24,12 @@ The step can be driven two ways, one code path underneath:
     filter-gradient kernels, their values are returned by the *_regularization_loss() accessors);
   * TrainGraph.forward_backward(x) / Trainer.step(x), which is exactly that sequence.
 
-BatchNorm under data parallelism: cross-replica statistics by default (sync_bn) -- the reference normalises over its whole
-batch on one device (autoencoder.py:115-125), so 8 ranks x 4 crops must see the statistics of all 32.  Per layer and
-direction the ranks all-reduce 2 C float64 sums (ic_bn_moments_f32 / ic_bn_backward_reduce_f32).  sync_bn=False keeps the
-statistics local to a rank (a per-tower replication of the TF graph).
+BatchNorm under data parallelism: cross-replica statistics by default (sync_bn=None / True) -- the reference normalises over
+its whole batch on one device (autoencoder.py:115-125), so 8 ranks x 4 crops must see the statistics of all 32.  Per layer and
+direction the ranks sum 2 C float64 values (ic_bn_moments_f32 / ic_bn_backward_reduce_f32): 140 exchanges per step, each on the
+critical path.  sync_bn=True / None: an RCCL all-reduce each; sync_bn='p2p': one small launch each over peer-mapped memory
+(peer.py, xGMI stores + flags, summed in rank order); sync_bn=False keeps the statistics local to a rank (a per-tower
+replication of the TF graph: no exchange at all, but 8 x 4 crops are then not the reference's 32).
 """
 import math
 from collections import OrderedDict
@@ -318,6 +320,14 @@ class TrainGraph(object):
 
     def _allreduce_sums(self, sums):
         import torch.distributed as dist
+        if self.sync_bn == 'p2p':
+            # one small launch over peer-mapped memory instead of a collective-library call (peer.py / csrc/peer_exchange.hip);
+            # the exchange is created on first use -- its set-up is a collective: every rank gets here in the same layer
+            if getattr(self, '_peer', None) is None:
+                from . import peer
+                self._peer = peer.PeerExchange(self.dev, self.pg)
+            self._peer.allreduce_f64(sums)
+            return
         if _is_gloo(self.pg):
             _staged_all_reduce(sums, self.pg)
         else:

@@ -254,6 +254,8 @@ int ic_pc_decode_f32(const uint8_t* bitstream, long long nbytes, int first_sym, 
 /* bits -> sum(bits) (bits.py:4-14 numerator); deterministic two-stage reduction.
  * partial: >= 1024 floats of scratch.  out_sum: 1 float. */
 int ic_sum_f32(const float* v, long long count, float* partial, float* out_sum, ic_stream_t stream);
+/* sum(v) / denom with the same reduction (bits.bitcost_to_bpp: bits.py:4-14 whole); the fp32 division is IEEE */
+int ic_mean_f32(const float* v, long long count, float denom, float* partial, float* out, ic_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Whole-network entry points for the CVPR autoencoder (autoencoder.py:218-268): one host call
@@ -400,6 +402,25 @@ int ic_event_create(void** ev);
 int ic_event_destroy(void* ev);
 int ic_event_record(void* ev, ic_stream_t stream);
 int ic_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
+
+/* ---------------------------------------------------------------------------------------------
+ * Cross-replica sums over peer-mapped device memory (csrc/peer_exchange.hip): what cross-replica BatchNorm exchanges once per
+ * layer and direction when one batch is split over the GPUs of a node (reference: single-device batch statistics,
+ * autoencoder.py:106-125; train.py:150-153).  One process per GPU; the 64-byte handles travel between the processes by any
+ * means (the Python host uses the process group).  Set-up calls allocate / map memory; ic_peer_allreduce_f64 is one launch.
+ * --------------------------------------------------------------------------------------------- */
+size_t ic_peer_region_bytes(void);
+int ic_peer_max_values(void);      /* doubles per exchange */
+int ic_peer_max_world(void);
+int ic_peer_region_create(void** region, void* ipc_handle_64);        /* zeroed fine-grained region on the current device */
+int ic_peer_region_open(const void* ipc_handle_64, void** mapped);    /* a peer's region, mapped into this process */
+int ic_peer_region_close(void* mapped);
+int ic_peer_region_destroy(void* region);
+/* vals[n] (device, float64): in place -> the sum over `world` ranks in rank order (bit-identical on every rank).
+ * regions_host[world]: every rank's region as mapped here (regions_host[rank] = own); seq = 1, 2, 3 ... the same on every rank;
+ * status: device int, set to 1 if a peer's flag did not arrive within the spin bound (vals are left unchanged then). */
+int ic_peer_allreduce_f64(double* vals, int n, void* const* regions_host, int rank, int world, unsigned seq, int* status,
+                          ic_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -576,7 +576,7 @@ def test_two_rank_training_step_equals_single_rank(cuda):
     ref_mv = g.params['autoencoder/encoder/h2/BatchNorm/moving_variance'].cpu().numpy()
     ctx = mp.get_context('spawn')
     results = {}
-    for sync_bn, port in ((True, 29541), (False, 29542)):
+    for sync_bn, port in ((True, 29541), (False, 29542), ('p2p', 29543)):
         q = ctx.Queue()
         procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, x_np, wts, over, sync_bn, q)) for r in range(2)]
         for p_ in procs:
@@ -590,6 +590,11 @@ def test_two_rank_training_step_equals_single_rank(cuda):
     assert worst < 5e-5, 'sync BatchNorm: 2 x 2 != 1 x 4, worst bucket error {:.3e}'.format(worst)
     assert np.allclose(mv, ref_mv, rtol=1e-5, atol=1e-7)               # the moving averages see the whole batch too
     assert abs(out2['pc_loss'] - out1['pc_loss']) < 5e-2 * abs(out1['pc_loss']) + 1e-3      # (losses are per-rank means over half the batch)
+    # the hand-written exchange over peer-mapped memory (peer.py) sums the same float64 moments in rank order: same result
+    grads_p, _, mv_p = results['p2p']
+    worst_p = max(rel_err(torch.as_tensor(grads_p[k]), torch.as_tensor(ref[k]).double()) for k in ref)
+    assert worst_p < 5e-5 and np.allclose(mv_p, ref_mv, rtol=1e-5, atol=1e-7), 'p2p sync BatchNorm: worst bucket error {:.3e}'.format(worst_p)
+    assert all(np.array_equal(grads_p[k], grads[k]) for k in ref), 'p2p exchange and all-reduce disagree (both sum in rank order)'
     grads_l, _, mv_l = results[False]
     worst_l = max(rel_err(torch.as_tensor(grads_l[k]), torch.as_tensor(ref[k]).double()) for k in ref)
     assert worst_l > 10 * worst and not np.allclose(mv_l, ref_mv, rtol=1e-5), 'local statistics reproduce the full batch?'
@@ -632,3 +637,122 @@ def test_inference_pad_value_follows_the_optimiser(cuda):
     w2['autoencoder/encoder/centers'] = (wts['autoencoder/encoder/centers'] + 0.125).astype(np.float32)
     ae2.load_weights(w2, cuda)
     assert pc2._pad_value_as_float(pc2.auto_pad_value(ae2)) == float(w2['autoencoder/encoder/centers'][0])
+
+
+def _peer_worker(rank, world, port, backend, device_index, out_q):
+    import torch.distributed as dist
+    from imgcomp_cvpr_amd import peer
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(device_index)
+    dev_ = torch.device('cuda', device_index)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev_)
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        px = peer.PeerExchange(dev_)
+        ok = True
+        last = None
+        for it in range(200):
+            n = 1 + (it * 37) % px.max_values
+            t = torch.arange(n, dtype=torch.float64, device=dev_) * (rank + 1) + it * 0.5 + rank * 1e-3
+            want = sum(torch.arange(n, dtype=torch.float64) * (r + 1) + it * 0.5 + r * 1e-3 for r in range(world))
+            px.allreduce_f64(t)
+            got = t.cpu()
+            ok = ok and bool(torch.equal(got, want))       # float64 sums in rank order: exactly the host's sum in the same order
+            last = got
+        px.check_status()
+        out_q.put((rank, ok, last.numpy()))
+        dist.barrier()
+        px.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_peer(world, backend, devices, port):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_peer_worker, args=(r, world, port, backend, devices[r], q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p_ in procs:
+        p_.join(timeout=120)
+        assert p_.exitcode == 0
+    assert all(ok for _, ok, _ in res), 'a peer exchange returned a wrong sum'
+    assert all(np.array_equal(res[0][2], r[2]) for r in res), 'ranks hold different sums'
+
+
+def test_peer_exchange_two_processes_one_gpu(cuda):
+    """csrc/peer_exchange.hip between two PROCESSES (inter-process memory handles, flags, slot rotation, 200 exchanges of varying
+    length): both ranks on this box's one GPU -- the protocol and the mapping are the ones used between GPUs, the fabric is not."""
+    _run_peer(2, 'gloo', [0, 0], 29551)
+
+
+def test_peer_exchange_between_gpus(cuda):
+    """the same between real GPUs over xGMI, one process per GPU (RCCL process group for the handle exchange).  Self-skipping:
+    gpurun boxes have one GPU; the driver's multi-GPU node runs it."""
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip('needs >= 2 GPUs (have {})'.format(n))
+    w = min(n, 8)
+    _run_peer(w, 'nccl', list(range(w)), 29552)
+
+
+def _sync_bn_rccl_worker(rank, world, port, x_np, wts, ae_over, mode, out_q):
+    import torch.distributed as dist
+    from imgcomp_cvpr_amd import training, config_parser as cp
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(rank)
+    dev_ = torch.device('cuda', rank)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev_)
+    try:
+        ae, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'low'))
+        pc, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
+        for k, v in ae_over.items():
+            setattr(ae, k, v)
+        g = training.TrainGraph(ae, pc, wts, dev_, sync_bn=mode)
+        n = x_np.shape[0] // world
+        g.forward_backward(torch.as_tensor(x_np[rank * n:(rank + 1) * n]).float().to(dev_))
+        torch.cuda.synchronize()
+        if rank == 0:
+            out_q.put({k: v.cpu().numpy() for k, v in g.flat_grads.items()})
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sync_bn_over_rccl_and_p2p_between_gpus(cuda):
+    """cross-replica BatchNorm where it runs in production: one process per GPU, RCCL gradient buckets, the moments exchanged by
+    RCCL all-reduce (sync_bn=True) and by the peer-memory kernel (sync_bn='p2p') -- both must reproduce the single-rank step on
+    the whole batch.  Self-skipping below two GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs >= 2 GPUs')
+    import torch.multiprocessing as mp
+    from imgcomp_cvpr_amd import training, config_parser as cp, weights as W
+    ae, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'low'))
+    pc, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
+    over = {'distortion_to_minimize': 'mse', 'H_target': 0.5}
+    for k, v in over.items():
+        setattr(ae, k, v)
+    wts = W.synthetic_weights(ae, pc)
+    x_np = W.synthetic_image((4, 3, 64, 64), 'natural', 9)
+    g = training.TrainGraph(ae, pc, wts, cuda)
+    g.forward_backward(dev(x_np, cuda))
+    torch.cuda.synchronize()
+    ref = {k: v.cpu().numpy() for k, v in g.flat_grads.items()}
+    ctx = mp.get_context('spawn')
+    for mode, port in ((True, 29571), ('p2p', 29572)):
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_sync_bn_rccl_worker, args=(r, 2, port, x_np, wts, over, mode, q)) for r in range(2)]
+        for p_ in procs:
+            p_.start()
+        grads = q.get(timeout=600)
+        for p_ in procs:
+            p_.join(timeout=120)
+            assert p_.exitcode == 0
+        worst = max(rel_err(torch.as_tensor(grads[k]), torch.as_tensor(ref[k]).double()) for k in ref)
+        assert worst < 5e-5, 'sync_bn={!r} over {} GPUs: worst bucket error {:.3e}'.format(mode, 2, worst)
