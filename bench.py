@@ -94,6 +94,26 @@ class Pipeline(object):
         return bpp, x_out
 
 
+class InFlight(object):
+    """n independent batch-1 pipelines -- own network objects, workspaces, input image and stream each; step i runs on pipeline
+    i % n.  The images of an evaluation set are independent (val.py:157-158 loops over them), so the launches of one image fill
+    the kernel-boundary bubbles of the others: every step is still ONE image through the whole path."""
+
+    def __init__(self, torch, first, dev, n, ae_config, seed0):
+        self.torch, self.n, self.i = torch, n, 0
+        self.pipes = [first] + [Pipeline(dev, ae_config, 'serial', seed=seed0 + 1000 * k).set_input(first.N, first.H, first.Wd)
+                                for k in range(1, n)]
+        for pl in self.pipes[1:]:
+            pl.ae.plan_flags = first.ae.plan_flags
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(n)]
+
+    def step(self):
+        k = self.i % self.n
+        self.i += 1
+        with self.torch.cuda.stream(self.streams[k]):
+            return self.pipes[k].step()
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
@@ -110,6 +130,8 @@ def main():
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--no_extras', action='store_true', help='headline only: no stage split, roofline, extra shapes (rocprofv3 runs)')
     p.add_argument('--pipelined', action='store_true', help='also run the informational three-pipelines-in-flight section')
+    p.add_argument('--in_flight', type=int, default=4,
+                   help='independent batch-1 images in flight on their own streams (serial arrangement only); 1 = one image at a time')
     p.add_argument('--calib_copy', action='store_true',
                    help='after the timed steps: a 256 MiB device-to-device copy (rocprofv3 --pmc passes calibrate FETCH_SIZE / WRITE_SIZE on it)')
     p.add_argument('--plan_flags', type=lambda v: int(v, 0), default=0,
@@ -167,7 +189,9 @@ def main():
         barrier(collective)
         return time.perf_counter() - t0, out
 
-    elapsed, (bpp, x_out) = run(pipe, a.steps, a.warmup, collective=True)
+    n_flight = a.in_flight if (pipe.serial and a.in_flight > 1) else 1
+    sched = InFlight(torch, pipe, dev, n_flight, a.ae_config, rank) if n_flight > 1 else pipe
+    elapsed, (bpp, x_out) = run(sched, a.steps, a.warmup, collective=True)
     elapsed = max_over_ranks(torch, dist, elapsed, dev, world, a.backend)
     value = N * H * Wd * world * a.steps / elapsed / 1e6
     if a.calib_copy:
@@ -179,7 +203,8 @@ def main():
 
     same_stream = pipe.serial or pipe.side is pipe.branch.main
     cus = pipe.branch.idle_cus(N, H, Wd) if not same_stream and pipe.side is not pipe.branch._plain else 0
-    extra = {'branch_sharing': share, 'context_model_stream_cus': cus, 'bpp_synthetic': round(float(bpp), 5)}
+    extra = {'branch_sharing': share, 'context_model_stream_cus': cus, 'bpp_synthetic': round(float(bpp), 5),
+             'images_in_flight': n_flight}
     roofline = roofline_pc = None
     if rank == 0 and not a.no_extras:
         st = _lib.current_stream(dev)
@@ -199,6 +224,10 @@ def main():
             _lib.check(lib.ic_event_elapsed_ms(ev[0], ev[1], ctypes.byref(ms)))
             return ms.value / reps
 
+        # ---- the same step with ONE image at a time (rounds 1-2 reported this as `value`) ----
+        if n_flight > 1:
+            dt1, _ = run(pipe, 20, 3)
+            extra['one_image_at_a_time'] = {'value': round(N * H * Wd * 20 / dt1 / 1e6, 3), 'unit': 'Mpix/s', 'ms_per_step': round(dt1 / 20 * 1e3, 4)}
         # ---- stage split (each stage alone on the stream) ----
         enc = ae.encode(pipe.x, False)
         ms_enc = timed(lambda: ae.encode(pipe.x, False), 10)
@@ -317,16 +346,19 @@ def main():
             if (n2, h2, w2) == (N, H, Wd):
                 continue
             ps = Pipeline(dev, a.ae_config, share, seed=rank).set_input(n2, h2, w2)
-            dt, _ = run(ps, 30, 5)
+            dt1, _ = run(ps, 30, 5)
+            sch = InFlight(torch, ps, dev, n_flight, a.ae_config, rank) if n_flight > 1 else ps
+            dt, _ = run(sch, 30, 5) if n_flight > 1 else (dt1, None)
             flop = n2 * h2 * w2 * (FLOP_PER_PX_ENC * 16.0 / 36.0 + FLOP_PER_PX_DEC * 16.0 / 36.0)
             shapes.append({'batch': n2, 'height': h2, 'width': w2, 'value': round(n2 * h2 * w2 * 30 / dt / 1e6, 3), 'unit': 'Mpix/s',
-                           'ms_per_step': round(dt / 30 * 1e3, 4),
+                           'ms_per_step': round(dt / 30 * 1e3, 4), 'images_in_flight': n_flight,
+                           'one_image_at_a_time': {'value': round(n2 * h2 * w2 * 30 / dt1 / 1e6, 3), 'ms_per_step': round(dt1 / 30 * 1e3, 4)},
                            'executed_frac_of_mfma_peak_whole_step': round(flop * 30 / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                            'plan_3x3': plan_name(lib, _lib, n2, h2 // 4, w2 // 4, 0)['kernel']})
             ps.branch.close()
         extra['shapes'] = shapes
         if a.pipelined:
-            extra['pipelined_3_streams'] = pipelined_section(torch, dev, a, N, H, Wd, pipe)
+            extra['in_flight_sweep'] = pipelined_section(torch, dev, a, N, H, Wd, pipe)
 
     # ---- CPU baseline: the oracle on the host cores (rank 0, N == 1 only) ----
     cpu = None
@@ -352,8 +384,12 @@ def main():
         C = int(ae_cfg.num_chan_bn)
         flop_step = N * H * Wd * (FLOP_PER_PX_ENC + FLOP_PER_PX_DEC + FLOP_PER_SYMBOL_PC * C / 64.0)
         if same_stream:
-            sched_text = ('one image at a time: encode, context-model bitcost, decode(qhard) in that order on one stream, every '
-                          'launch on the whole chip (val.py:85-89 evaluates bitcost and reconstruction in one session.run)')
+            sched_text = ('encode, context-model bitcost, decode(qhard) of an image in that order on one stream, every launch on the whole '
+                          'chip (val.py:85-89 evaluates bitcost and reconstruction in one session.run); ' +
+                          ('one image at a time' if n_flight == 1 else
+                           '{} independent batch-1 images in flight, one stream each, steps issued round-robin (val.py:157-158 loops over '
+                           'independent images): each step is one image, the launches of one image fill the kernel-boundary bubbles '
+                           'of the others'.format(n_flight)))
         else:
             sched = ('a stream limited to the {} CUs the decoder leaves idle'.format(cus) if cus else
                      'a second stream next to the decoder (which fills the chip)')
@@ -474,33 +510,41 @@ def plan_name(lib, _lib, N, h4, w4, flags):
 
 
 def pipelined_section(torch, dev, a, N, H, Wd, pipe):
-    """Extra, NOT the contract value: the same step with three independent batch-1 pipelines in flight."""
+    """Extra, NOT the contract value: the same step with 2 / 3 independent batch-1 images in flight on their own streams (what a
+    val.py loop over the 24 Kodak images can do: the images are independent).  Kernels of one image fill the launch-boundary
+    bubbles of the other."""
     from imgcomp_cvpr_amd import bits
-    try:
-        pipes = [Pipeline(dev, a.ae_config, 'full_chip', seed=0).set_input(N, H, Wd) for _ in range(3)]
-        streams_ = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    out = {}
+    for ns in (2, 3, 4, 6):
+        try:
+            pipes = [Pipeline(dev, a.ae_config, 'serial', seed=i).set_input(N, H, Wd) for i in range(ns)]
+            streams_ = [torch.cuda.Stream(device=dev) for _ in range(ns)]
 
-        def one(pl):
-            e = pl.ae.encode(pl.x, is_training=False)
-            b = pl.pc.bitcost(e.qbar, e.symbols, is_training=False, pad_value=pl.pad_value)
-            bits.bitcost_to_bpp(b, pl.x)
-            return pl.ae.decode(e.qhard, is_training=False)
-        torch.cuda.synchronize(dev)
-        for i in range(6):
-            with torch.cuda.stream(streams_[i % 3]):
-                one(pipes[i % 3])
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        n_img = 36
-        for i in range(n_img):
-            with torch.cuda.stream(streams_[i % 3]):
-                one(pipes[i % 3])
-        torch.cuda.synchronize(dev)
-        dt3 = time.perf_counter() - t1
-        return {'value': round(N * H * Wd * n_img / dt3 / 1e6, 3), 'unit': 'Mpix/s', 'ms_per_image': round(dt3 / n_img * 1e3, 4),
-                'images': n_img, 'note': 'three independent batch-1 pipelines in flight on one GPU; not the contract value'}
-    except Exception as ex:                                       # informational only
-        return {'error': str(ex)[:200]}
+            def one(pl):
+                e = pl.ae.encode(pl.x, is_training=False)
+                b = pl.pc.bitcost(e.qbar, e.symbols, is_training=False, pad_value=pl.pad_value)
+                bits.bitcost_to_bpp(b, pl.x)
+                return pl.ae.decode(e.qhard, is_training=False)
+            torch.cuda.synchronize(dev)
+            for i in range(2 * ns):
+                with torch.cuda.stream(streams_[i % ns]):
+                    one(pipes[i % ns])
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            n_img = 12 * ns
+            for i in range(n_img):
+                with torch.cuda.stream(streams_[i % ns]):
+                    one(pipes[i % ns])
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t1
+            out['{}_images_in_flight'.format(ns)] = {'value': round(N * H * Wd * n_img / dt / 1e6, 3), 'unit': 'Mpix/s',
+                                                      'ms_per_image': round(dt / n_img * 1e3, 4), 'images': n_img}
+            for pl in pipes:
+                pl.branch.close()
+        except Exception as ex:                                       # informational only
+            out['{}_images_in_flight'.format(ns)] = {'error': str(ex)[:200]}
+    out['note'] = 'independent batch-1 images on their own streams on one GPU; not the contract value'
+    return out
 
 
 def train_main(a, dev, rank, world):

@@ -142,30 +142,47 @@ def _downsample2_t(img):
 
 def msssim_nchw_uint8_device(x, y):
     """x, y: uint8 NCHW torch tensors on the device -> python float (float32-rounded like msssim_nchw_uint8)."""
+    return msssim_from_scale_values(msssim_scale_values_device(x, y).tolist())       # one device -> host transfer
+
+
+def msssim_scale_values_device(x, y):
+    """the device half of msssim_nchw_uint8_device: the per-scale contrast terms and the last scale's SSIM as ONE float64 device
+    tensor, nothing waited for (val.py keeps several images in flight and reads the values later)"""
     import torch
     assert x.dtype == torch.uint8 and y.dtype == torch.uint8, 'Expected uint8 input'
     if x.shape != y.shape:
         raise RuntimeError('Input images must have the same shape ({} vs. {}).'.format(tuple(x.shape), tuple(y.shape)))
     im1 = x.permute(0, 2, 3, 1).to(torch.float64)
     im2 = y.permute(0, 2, 3, 1).to(torch.float64)
-    w = _MSSSIM_WEIGHTS
     mssim, mcs = [], []
-    for _ in range(len(w)):
+    for _ in range(len(_MSSSIM_WEIGHTS)):
         s, c = _ssim_and_cs_t(im1, im2)
         mssim.append(s)
         mcs.append(c)
         im1, im2 = _downsample2_t(im1), _downsample2_t(im2)
-    vals = torch.stack(mcs[:-1] + [mssim[-1]]).tolist()                # one device -> host transfer
+    return torch.stack(mcs[:-1] + [mssim[-1]])
+
+
+def msssim_from_scale_values(vals):
+    """the host half: prod(mcs ** w) * mssim_last ** w_last, float32-rounded like msssim_nchw_uint8"""
+    w = _MSSSIM_WEIGHTS
     out = 1.0
     for v, wt in zip(vals[:-1], w[:-1]):
         out *= v ** wt
     return float(np.float32(out * vals[-1] ** w[-1]))
 
 
-def psnr_uint8_device(a, b):
+def mse_uint8_device(a, b):
     import torch
     assert a.dtype == torch.uint8 and b.dtype == torch.uint8, 'Expected uint8 input'
-    mse = float(((a.to(torch.float64) - b.to(torch.float64)) ** 2).mean())
+    return ((a.to(torch.float64) - b.to(torch.float64)) ** 2).mean()
+
+
+def psnr_from_mse(mse):
     if mse == 0:
         return float('inf')
     return float(np.float32(10.0 * np.log10(255.0 ** 2 / mse)))
+
+
+def psnr_uint8_device(a, b):
+    return psnr_from_mse(float(mse_uint8_device(a, b)))

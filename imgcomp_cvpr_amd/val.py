@@ -172,20 +172,35 @@ class Fetcher(object):
         self._streams = streams.BranchStreams(self.device)
 
     def __call__(self, img_chw_uint8, want_symbols=False, want_image=False):
+        return self.collect(self.enqueue(img_chw_uint8, want_symbols, want_image))
+
+    def enqueue(self, img_chw_uint8, want_symbols=False, want_image=False):
+        """launch the whole path for one image on this fetcher's stream WITHOUT waiting for it: validate() keeps several
+        fetchers busy at once (the images are independent), collect() turns the device results into Python values."""
         x_uint8 = torch.as_tensor(img_chw_uint8)[None]
         outer, main = torch.cuda.current_stream(self.device), self._streams.main
         main.wait_stream(outer)
         with torch.cuda.stream(main):
-            otp = self._measure(x_uint8, want_symbols, want_image)
-        outer.wait_stream(main)
+            return self._measure(x_uint8, want_symbols, want_image)
+
+    def collect(self, pending):
+        main = self._streams.main
+        with torch.cuda.stream(main):
+            sc = pending['scalars']
+            otp = {'bpp': float(sc['bpp'])}                                       # .item(): waits for this stream only
+            otp['ms-ssim'] = sc['ms-ssim'] if isinstance(sc['ms-ssim'], float) else metrics.msssim_from_scale_values(sc['ms-ssim'].tolist())
+            otp['psnr'] = sc['psnr'] if isinstance(sc['psnr'], float) else metrics.psnr_from_mse(float(sc['psnr']))
+            for k, v in pending['arrays'].items():
+                otp[k] = v.cpu().numpy()
+        torch.cuda.current_stream(self.device).wait_stream(main)
         return otp
 
     def _measure(self, x_uint8, want_symbols, want_image):
-        x_uint8_dev = x_uint8.to(self.device)
+        x_uint8_dev = x_uint8.to(self.device, non_blocking=True)
         x = x_uint8_dev.float()
         enc = self.ae.encode(x, is_training=False)
-        # decoder and context model are independent consumers of the encoder output: two streams, the context model on
-        # the CUs the decoder's 3x3 launches leave idle (streams.py)
+        # decoder and context model are independent consumers of the encoder output: with a CU-range arrangement (streams.py) the
+        # context model runs on a second stream beside the decoder; in the default serial arrangement `side` is this stream
         cur = torch.cuda.current_stream(self.device)
         side = self._streams.context_model_stream(x.shape[0], x.shape[2], x.shape[3], int(self.ae.config.num_chan_bn))
         side.wait_stream(cur)
@@ -195,19 +210,20 @@ class Fetcher(object):
         x_out = self.ae.decode(enc.qhard, is_training=False, plan_flags=self._streams.decode_flags(side))
         cur.wait_stream(side)
         x_out_uint8_dev = x_out.to(torch.uint8)                    # tf.cast truncates (val.py:91)
+        arrays = {}
         if self.host_metrics:
             x_out_uint8 = x_out_uint8_dev.cpu().numpy()
             ms, ps = metrics.msssim_nchw_uint8(x_uint8.numpy(), x_out_uint8), metrics.psnr_uint8(x_uint8.numpy(), x_out_uint8)
         else:
-            # the same float64 computation on the device: 0.5 s of numpy per Kodak image would dwarf the 3.6 ms GPU path
-            ms = metrics.msssim_nchw_uint8_device(x_uint8_dev, x_out_uint8_dev)
-            ps = metrics.psnr_uint8_device(x_uint8_dev, x_out_uint8_dev)
-        otp = {'bpp': float(bpp), 'ms-ssim': float(ms), 'psnr': float(ps)}
+            # the same float64 computation on the device: 0.5 s of numpy per Kodak image would dwarf the 2.4 ms GPU path
+            # (device tensors, nothing waited for here: collect() finishes them on the host)
+            ms = metrics.msssim_scale_values_device(x_uint8_dev, x_out_uint8_dev)
+            ps = metrics.mse_uint8_device(x_uint8_dev, x_out_uint8_dev)
         if want_symbols:
-            otp['sym'] = enc.symbols.cpu().numpy()
+            arrays['sym'] = enc.symbols
         if want_image:
-            otp['img_out'] = x_out_uint8_dev.cpu().numpy()
-        return otp
+            arrays['img_out'] = x_out_uint8_dev
+        return {'scalars': {'bpp': bpp, 'ms-ssim': ms, 'psnr': ps}, 'arrays': arrays}
 
     def real_bpp(self, symbols, num_pixels):
         if self._bpp_fetcher is None:
@@ -217,18 +233,26 @@ class Fetcher(object):
         return self._bpp_fetcher.get_bpp(symbols, num_pixels)
 
 
-def validate(ae_config, pc_config, weights, image_paths, out_dir, flags, device='cuda', verbose=True, host_metrics=False):
-    """-> dict of averages; writes out_dir/measures.csv (rank 0)."""
+def validate(ae_config, pc_config, weights, image_paths, out_dir, flags, device='cuda', verbose=True, host_metrics=False,
+             in_flight=4):
+    """-> dict of averages; writes out_dir/measures.csv (rank 0).
+    in_flight: images of this rank processed concurrently, each by its own Fetcher (networks, workspace, stream): the images
+    are independent (the reference runs one per sess.run, val.py:157-158), and the launches of one fill the kernel-boundary
+    bubbles of the others (bench.py: 158 -> 166 Mpix/s on Kodak-sized images with 4).  --real_bpp codes one image at a time."""
+    from collections import deque
     rank, world = sharding.rank_and_world()
-    fetcher = Fetcher(ae_config, pc_config, weights, device, host_metrics=host_metrics)
+    n_f = 1 if (flags.real_bpp or host_metrics) else max(1, int(in_flight))
+    fetchers = [Fetcher(ae_config, pc_config, weights, device, host_metrics=host_metrics) for _ in range(n_f)]
+    fetcher = fetchers[0]
     pad = fetcher.ae.get_subsampling_factor()
     local = []
-    for idx in sharding.shard_indices(len(image_paths), rank, world):
-        p = image_paths[idx]
-        img = load_image_chw(p, pad)
-        otp = fetcher(img, want_symbols=flags.real_bpp, want_image=flags.save_ours)
+    pending = deque()
+
+    def finish():
+        idx, p, img, f, h = pending.popleft()
+        otp = f.collect(h)
         if flags.real_bpp:
-            bpp_real, bpp_theory = fetcher.real_bpp(otp.pop('sym'), bpp_helpers.num_pixels_in_image(img))
+            bpp_real, bpp_theory = f.real_bpp(otp.pop('sym'), bpp_helpers.num_pixels_in_image(img))
             otp['bpp_real'], otp['bpp_theory'] = bpp_real, bpp_theory
             if verbose:
                 print('BPP: Real         {:.5f}\n     Theoretical: {:.5f} [{:5.1f}% of real]\n'
@@ -239,6 +263,16 @@ def validate(ae_config, pc_config, weights, image_paths, out_dir, flags, device=
         if flags.save_ours:
             save_img(path.basename(p), otp.pop('img_out'), out_dir)
         local.append((idx, (path.basename(p), otp)))
+
+    for k, idx in enumerate(sharding.shard_indices(len(image_paths), rank, world)):
+        p = image_paths[idx]
+        img = load_image_chw(p, pad)
+        f = fetchers[k % n_f]
+        if len(pending) == n_f:
+            finish()                                  # the oldest image ran on this fetcher: its buffers are free again
+        pending.append((idx, p, img, f, f.enqueue(img, want_symbols=flags.real_bpp, want_image=flags.save_ours)))
+    while pending:
+        finish()
     merged = sharding.gather_in_order(local, len(image_paths))
     agg = ValuesAggregator('bpp', 'ms-ssim', 'psnr')
     if rank == 0:
@@ -291,6 +325,7 @@ def main(argv=None):
     p.add_argument('--restore_itr', type=int, default=-1, help='Restore the newest checkpoint with iteration <= this '
                                                                '(val.py:215-217); -1 = newest.')
     p.add_argument('--device', default=None)
+    p.add_argument('--in_flight', type=int, default=4, help='images processed concurrently per GPU, one stream each (1 = one at a time)')
     flags, unknown = p.parse_known_args(argv)
     if unknown:
         print('Unknown flags: {}'.format(unknown))
@@ -321,7 +356,8 @@ def main(argv=None):
                 shutil.rmtree(out_dir)
             sharding.barrier()
         avgs = validate(ae_config, pc_config, weights, image_paths, out_dir,
-                        OutputFlags(flags.save_ours, -1, flags.real_bpp), device, host_metrics=bool(flags.host_metrics))
+                        OutputFlags(flags.save_ours, -1, flags.real_bpp), device, host_metrics=bool(flags.host_metrics),
+                        in_flight=flags.in_flight)
         if sharding.rank_and_world()[0] == 0:
             print('Validation completed: {} | {}'.format(out_dir, avgs))
     print('*** All given job_ids validated.')

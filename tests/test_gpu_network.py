@@ -276,6 +276,15 @@ def test_val_entry_point(cuda, tmp_path, configs, syn_weights):
         assert 0 < float(bpp) < 10 and 0 < float(msssim) <= 1 and float(psnr) > 0
     saved = np.asarray(Image.open(str(out / 'imgs' / 'img00.png')))
     assert saved.shape == (184, 208, 3)          # padded to the subsampling factor
+    # several images in flight (one Fetcher + stream each) give exactly the rows of one image at a time, in order
+    for i, (h, w) in enumerate(((64, 96), (120, 72), (88, 88), (64, 96), (56, 200)), start=2):
+        im = W.synthetic_image((1, 3, h, w), 'natural', seed=i)[0].transpose(1, 2, 0)
+        Image.fromarray(im).save(str(imgs / 'img{:02d}.png'.format(i)))
+    rows_by_mode = {}
+    for n in (1, 3):
+        val.main([str(root), '0515_1103', str(imgs), '--weights', 'synthetic', '--reset', '--in_flight', str(n)])
+        rows_by_mode[n] = (out / 'measures.csv').read_text()
+    assert rows_by_mode[1] == rows_by_mode[3] and len(rows_by_mode[1].strip().split('\n')) == 8
     # --real_bpp leg on a small image: arithmetic-coded size vs theoretical vs loss (val.py:163-174)
     ae_cfg, pc_cfg = configs
     f = val.Fetcher(ae_cfg, pc_cfg, syn_weights, cuda)
