@@ -97,14 +97,16 @@ class Pipeline(object):
 class InFlight(object):
     """n independent batch-1 pipelines -- own network objects, workspaces, input image and stream each; step i runs on pipeline
     i % n.  The images of an evaluation set are independent (val.py:157-158 loops over them), so the launches of one image fill
-    the kernel-boundary bubbles of the others: every step is still ONE image through the whole path."""
+    the kernel-boundary bubbles of the others -- and a launch no longer has to fill the chip alone, so the 3x3 layers run the
+    form with the least CU-time (IC_CONV3_IN_FLIGHT).  Every step is still ONE image through the whole path."""
 
     def __init__(self, torch, first, dev, n, ae_config, seed0):
         self.torch, self.n, self.i = torch, n, 0
-        self.pipes = [first] + [Pipeline(dev, ae_config, 'serial', seed=seed0 + 1000 * k).set_input(first.N, first.H, first.Wd)
-                                for k in range(1, n)]
-        for pl in self.pipes[1:]:
-            pl.ae.plan_flags = first.ae.plan_flags
+        from imgcomp_cvpr_amd import _lib
+        self.pipes = [Pipeline(dev, ae_config, 'serial', seed=seed0 + 1000 * k).set_input(first.N, first.H, first.Wd) for k in range(n)]
+        for pl in self.pipes:
+            # the plan hint: n independent calls of this shape are in flight (IC_CONV3_IN_FLIGHT, include/imgcomp_hip.h)
+            pl.ae.plan_flags = first.ae.plan_flags | _lib.CONV3_IN_FLIGHT(n)
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(n)]
 
     def step(self):

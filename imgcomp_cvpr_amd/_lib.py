@@ -26,6 +26,10 @@ CONV3_LEAVE_IDLE_CUS = 0x10
 CONV3_NO_XCD_RUNS = 0x20
 CONV3_PACKED_TRANSFORM = 0x40
 CONV3_STACK_KERNEL = 0x80
+
+
+def CONV3_IN_FLIGHT(n):
+    return (min(int(n), 15) & 0xf) << 19
 PC_DECODE_PER_LAYER = 0x01
 PC_DECODE_RECOMPUTE = 0x02
 

@@ -885,6 +885,11 @@ static WinoPlan wino_plan(long long groups, bool even_w, int flags) {
     // automatic: the full rounds of 256 tile groups run whole-K; the remainder r takes the cheapest of {whole-K, K-split,
     // NB-segment jobs as a second launch}.  Odd widths have the per-wave whole-K kernel and K-split only; next to a caller's
     // CU-range stream (leave_idle) only the one-work-group-per-CU forms whose work-groups stay below 256 qualify.
+    // the caller keeps n independent launches of this shape in flight: when they cover the chip together, every one of them runs
+    // the form with the lowest CU-time per tile group (whole-K: one work-group per group for 37.5 us; NB = 3 segments: 1.33 CUs
+    // per group for 30 us + its boundary) -- measured on Kodak-sized images, 4 in flight: 183 against 168 Mpix/s (bench.py)
+    const int in_flight = (flags >> 19) & 0xf;
+    if (in_flight >= 2 && in_flight * groups >= 256 && !leave_idle) { p.whole = groups; return p; }
     const long long r = groups % 256, full = groups - r;
     double best = whole_cost(r);
     p.whole = groups;

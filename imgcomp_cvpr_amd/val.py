@@ -31,7 +31,7 @@ from os import path
 import numpy as np
 import torch
 
-from . import autoencoder, bits, bpp_helpers, config_parser, metrics, probclass, sharding, streams
+from . import _lib, autoencoder, bits, bpp_helpers, config_parser, metrics, probclass, sharding, streams
 from . import weights as _weights
 
 OutputFlags = namedtuple('OutputFlags', ['save_ours', 'ckpt_step', 'real_bpp'])
@@ -161,12 +161,13 @@ class ValuesAggregator(object):
 class Fetcher(object):
     """builds the networks once, then maps one padded uint8 CHW image to its measures."""
 
-    def __init__(self, ae_config, pc_config, weights, device, host_metrics=False):
+    def __init__(self, ae_config, pc_config, weights, device, host_metrics=False, plan_flags=0):
         self.device = torch.device(device)
         self.host_metrics = host_metrics        # True: MS-SSIM / PSNR in numpy on the host, as the reference does
         self.ae = autoencoder.get_network_cls(ae_config)(ae_config).load_weights(weights, self.device)
         self.pc = probclass.get_network_cls(pc_config)(pc_config, num_centers=ae_config.num_centers).load_weights(
             weights, self.device)
+        self.ae.plan_flags = int(plan_flags)          # e.g. _lib.CONV3_IN_FLIGHT(n): validate() keeps n fetchers busy at once
         self.pc_config = pc_config
         self._bpp_fetcher = None
         self._streams = streams.BranchStreams(self.device)
@@ -242,7 +243,8 @@ def validate(ae_config, pc_config, weights, image_paths, out_dir, flags, device=
     from collections import deque
     rank, world = sharding.rank_and_world()
     n_f = 1 if (flags.real_bpp or host_metrics) else max(1, int(in_flight))
-    fetchers = [Fetcher(ae_config, pc_config, weights, device, host_metrics=host_metrics) for _ in range(n_f)]
+    fetchers = [Fetcher(ae_config, pc_config, weights, device, host_metrics=host_metrics,
+                        plan_flags=_lib.CONV3_IN_FLIGHT(n_f) if n_f > 1 else 0) for _ in range(n_f)]
     fetcher = fetchers[0]
     pad = fetcher.ae.get_subsampling_factor()
     local = []
