@@ -5,20 +5,27 @@ A "step" is one pass of the hot path over one batch of synthetic input: BASELINE
 (Kodak-shaped image 1x3x512x768, ae_configs/cvpr/low + pc_configs/cvpr/res_shallow, batch 1):
     encode (normalise, 35 convs, importance map, quantiser) -> context-model bit cost for all symbols
     in parallel + bpp -> decode(qhard) (35 convs, de-normalise, clip)          [val.py:85-89 wiring]
-Inputs and weights are resident in HBM before the timed region.  Data: seeded synthetic image and
+Inputs and weights are resident in HBM before the timed region.  Data: seeded synthetic images and
 random-init weights (no network for Kodak or the 0515_1103 checkpoint).
+
+Schedule (--in_flight n, default 4): the images of an evaluation set are independent (val.py:157-158 runs one per sess.run), so
+n of them are in flight at a time, each a batch-1 step on its own stream with its own network objects and workspace; steps are
+issued round-robin and EVERY step is still one image through the whole path.  The launches of one image fill the kernel-boundary
+bubbles of the others, and a 3x3 launch no longer has to fill the chip alone (IC_CONV3_IN_FLIGHT: the plan takes the form with
+the least CU-time).  --in_flight 1 is one image at a time (what rounds 1-2 reported; kept in the line as `one_image_at_a_time`).
 
   python bench.py --gpus N --steps K --warmup W            (--mode train: one cfg3 training step per step)
 N > 1 is launched by torch.distributed.run, one rank per GPU; the path shards by image (independent
 units, no data-path collective), so every rank runs the same per-GPU workload: weak scaling.
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement) with extra objects:
-  roofline               -- the dominant kernel (3x3 128->128 conv on the fp32 matrix cores), timed IN-STEP: HIP events on
-                            the launch stream around the 32-layer residual stack of the encoder / of the decoder, cycling
-                            the 32 real packed filters, / 32.  `achieved` = FLOPs the matrix pipe executes (Winograd:
+  roofline               -- the dominant kernel (3x3 128->128 conv on the fp32 matrix cores), timed IN-STEP: HIP events around
+                            the 32-layer residual stack of the encoder / of the decoder on the step's own activations, n stacks
+                            in flight like the step, / launches.  `achieved` = FLOPs the matrix pipe executes (Winograd:
                             16/36 of the direct form's) / that time; `frac` = achieved / 157.3 TFLOP/s, <= 1 by
-                            construction; the direct-form (SURVEY 8(d) algorithmic) figure is kept under `direct_equivalent_*`
+                            construction; `alone` = one launch at a time (a kernel trace's duration of the launch)
   roofline_context_model -- the same for the masked-3D-conv context model, standalone
+  layers_5x5             -- the six 5x5 / stride-2 layers, each alone, against both roofs
   shapes                 -- the north_star's 256x256 shape (batch 1 and 8) through the same step
   cpu_baseline           -- the CPU oracle (torch fp32 restatement of the reference) timed on a bounded sample of the same
                             workload (rank 0, N = 1 only)
@@ -240,12 +247,15 @@ def main():
                       'ms_decode_with_step_flags': round(ms_dec_shared, 4)})
 
         # ---- dominant kernel, in-step: the 32-layer residual stack with its own 32 filters through the library's own launch
-        # sequence (ic_ae_res_stack_f32 = the res_stack of network.hip that encode / decode run), HIP events around it ----
+        # sequence (ic_ae_res_stack_f32 = the res_stack of network.hip that encode / decode run), HIP events around it.
+        # With n images in flight the step's 3x3 launches overlap across streams, so the stack is timed the same way: n stacks,
+        # one per stream, events on the main stream around all of them -> the time in which the chip completes one launch.
+        # The same stack alone on one stream (one launch at a time, what a kernel trace shows as the launch's duration) is
+        # reported beside it. ----
         h4, w4 = H // 4, Wd // 4
         n4 = N * 128 * h4 * w4
-        yout = torch.empty((N, 128, h4, w4), device=dev)
         rs_need = lib.ic_ae_res_stack_workspace_bytes(N, h4, w4)
-        rs_ws = torch.empty(rs_need, dtype=torch.uint8, device=dev)
+        step_flags = a.plan_flags | (_lib.CONV3_IN_FLIGHT(n_flight) if n_flight > 1 else 0)
 
         def res_stack(which, flags):
             # the stack's REAL input: the first buffer of the autoencoder's workspace still holds it after a call (kept for the
@@ -256,31 +266,70 @@ def main():
             else:
                 ae.decode(enc.qhard, False)
             xin = ae._ws.view(torch.float32)[:n4].clone()
+            yo = torch.empty((N, 128, h4, w4), device=dev)
+            ws_ = torch.empty(rs_need, dtype=torch.uint8, device=dev)
             tens = []
             for sname in conv3_scopes(W, ae_cfg, which):
                 tens += list(ae._plan[sname])
             tab = _lib.ptr_table(tens)
             B = int(ae_cfg.arch_param_B)
 
-            def go():
-                _lib.check(lib.ic_ae_res_stack_f32(_lib.ptr(xin), tab, B, _lib.ptr(yout), N, h4, w4, _lib.ptr(rs_ws), rs_need, flags, st))
+            def go(sth=None):
+                _lib.check(lib.ic_ae_res_stack_f32(_lib.ptr(xin), tab, B, _lib.ptr(yo), N, h4, w4, _lib.ptr(ws_), rs_need, flags,
+                                                   st if sth is None else sth))
+            go.keep = (xin, yo, ws_, tens, tab)
+            go.out = yo
             return go, len(tens) // 3
+
+        def timed_concurrent(gos, reps, warm=2):
+            """gos[i] runs on its own stream; events on the main stream bracket all of them"""
+            main = torch.cuda.current_stream(dev)
+            strs = [torch.cuda.Stream(device=dev) for _ in gos]
+            handles = [ctypes.c_void_p(s_.cuda_stream) for s_ in strs]
+
+            def burst(n):
+                for s_ in strs:
+                    s_.wait_stream(main)
+                for _ in range(n):
+                    for g_, h_ in zip(gos, handles):
+                        g_(h_)
+                for s_ in strs:
+                    main.wait_stream(s_)
+            burst(warm)
+            torch.cuda.synchronize(dev)
+            _lib.check(lib.ic_event_record(ev[0], st))
+            burst(reps)
+            _lib.check(lib.ic_event_record(ev[1], st))
+            ms = ctypes.c_float()
+            _lib.check(lib.ic_event_elapsed_ms(ev[0], ev[1], ctypes.byref(ms)))
+            return ms.value / (reps * len(gos))
 
         def layer_entry(which, flags):
             go, nl = res_stack(which, flags)
-            ms = timed(go, 10) / nl
+            ms_alone = timed(go, 10) / nl
+            if n_flight > 1:
+                gos = [go] + [res_stack(which, flags)[0] for _ in range(n_flight - 1)]
+                ms = timed_concurrent(gos, 6) / nl
+            else:
+                ms = ms_alone
             flop_direct = CONV3_FLOP_PER_OUT_PX * N * h4 * w4
             wino = lib.ic_conv3x3_c128_pick_algo(N, h4, w4, flags) == 1
             executed = flop_direct * (16.0 / 36.0 if wino else 1.0)
-            return {'avg_launch_us': round(ms * 1e3, 2), 'layers_timed': nl,
-                    'achieved': round(executed / (ms * 1e-3) / 1e12, 2),
-                    'frac': round(executed / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                    'direct_equivalent_tflops': round(flop_direct / (ms * 1e-3) / 1e12, 2),
-                    'direct_equivalent_frac': round(flop_direct / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                    'executed_flop_per_launch': executed, 'plan': plan_name(lib, _lib, N, h4, w4, flags)}
+            plan = plan_name(lib, _lib, N, h4, w4, flags)
+            ent = {'avg_launch_us': round(ms * 1e3, 2), 'layers_timed': nl, 'stacks_in_flight': n_flight,
+                   'achieved': round(executed / (ms * 1e-3) / 1e12, 2),
+                   'frac': round(executed / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                   'direct_equivalent_tflops': round(flop_direct / (ms * 1e-3) / 1e12, 2),
+                   'direct_equivalent_frac': round(flop_direct / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                   'executed_flop_per_launch': executed, 'plan': plan,
+                   # one launch at a time: the duration a kernel trace shows for the launch, on the CUs it occupies
+                   'alone': {'avg_launch_us': round(ms_alone * 1e3, 2), 'cus': plan['cus'],
+                             'frac_of_chip': round(executed / (ms_alone * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                             'frac_of_occupied_cus': round(executed / (ms_alone * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS * 256.0 / max(plan['cus'], 1), 4)}}
+            return ent, go
 
-        enc_l = layer_entry('enc', 0)
-        dec_l = layer_entry('dec', pipe.dec_flags)
+        enc_l, go_enc = layer_entry('enc', step_flags)
+        dec_l, go_dec = layer_entry('dec', step_flags | pipe.dec_flags)
         n_idle = (pipe.dec_flags >> 12) & 0x7f
         if pipe.dec_flags & _lib.CONV3_LEAVE_IDLE_CUS and 0 < n_idle < dec_l['layers_timed']:
             # mixed stack: the first n_idle launches keep off the context model's CUs, the rest take the whole chip
@@ -302,14 +351,16 @@ def main():
         elif counters:
             traffic_src = 'dropped: {} describes shape {} / 3x3 kernel {}, this run is {} / {}'.format(
                 counters.get('file'), counters.get('input_shape'), counters.get('plan_3x3'), [N, 3, H, Wd], k3)
-        wino = lib.ic_conv3x3_c128_pick_algo(N, h4, w4, 0) == 1
+        wino = lib.ic_conv3x3_c128_pick_algo(N, h4, w4, step_flags) == 1
         roofline = {'kernel': enc_l['plan']['kernel'] + ' (ic_conv3x3_c128_auto_f32, encoder residual stack, in-step)',
                     'algorithm': 'winograd F(2x2,3x3)' if wino else 'direct', 'bound': 'mfma',
                     'achieved': enc_l['achieved'], 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': enc_l['frac'],
                     'traffic': traffic, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': traffic_src,
                     'algorithmic_bytes_per_launch': int(3 * 512 * N * h4 * w4 + (1048576 if wino else 589824)),
                     'launches_per_step': 2 * (6 * int(ae_cfg.arch_param_B) + 2),
-                    'note': 'achieved = FLOPs the matrix pipe executes (Winograd: 16/36 of the direct form) / in-step launch time',
+                    'note': 'achieved = FLOPs the matrix pipe executes (Winograd: 16/36 of the direct form) / the time in which the chip '
+                            'completes one launch of the stack: HIP events around {} stacks in flight, one per stream, as in the step; '
+                            '`encoder.alone` = the same launch with nothing beside it (its duration in a kernel trace, on plan.cus of 256 CUs)'.format(n_flight),
                     'encoder': enc_l, 'decoder': dec_l}
         sym = N * int(ae_cfg.num_chan_bn) * (H // 8) * (Wd // 8)
         roofline_pc = {'kernel': 'context model, 4 masked conv3d layers + cross-entropy (ic_pc_bitcost_f32), standalone',
@@ -322,12 +373,9 @@ def main():
                        'note': 'achieved counts the live taps of the causal masks (36,912 FLOP/symbol); SURVEY 8(d) dense figure 47,520 alongside'}
         # ---- the six 5x5 / stride-2 layers around the stacks, each alone on the stream, on the step's own activations ----
         try:
-            go_e, _ = res_stack('enc', 0)
-            go_e()
-            stack_out_enc = yout.clone()
-            go_d, _ = res_stack('dec', 0)
-            go_d()
-            extra['layers_5x5'] = edge_layer_table(torch, lib, _lib, W, ae, ae_cfg, pipe.x, enc.qhard, stack_out_enc, yout, timed, st, N, H, Wd)
+            go_enc()
+            go_dec()
+            extra['layers_5x5'] = edge_layer_table(torch, lib, _lib, W, ae, ae_cfg, pipe.x, enc.qhard, go_enc.out, go_dec.out, timed, st, N, H, Wd)
         except Exception as ex:                                        # informational only
             extra['layers_5x5'] = {'error': str(ex)[:300]}
         for e in ev:

@@ -87,25 +87,45 @@ for t in ('bench', 'pc', 'train'):
 # ---- per-kernel durations of the bench step from the kernel trace ----
 trace = find('prof_bench', 'kernel_trace.csv')
 dur, cnt = defaultdict(float), defaultdict(int)
+wgs, all_k = {}, []
 if trace:
     with open(trace) as f:
         for r in csv.DictReader(f):
             k = short(r['Kernel_Name'])
-            dur[k] += (float(r['End_Timestamp']) - float(r['Start_Timestamp'])) / 1e3
+            b, e = float(r['Start_Timestamp']), float(r['End_Timestamp'])
+            dur[k] += (e - b) / 1e3
             cnt[k] += 1
+            wgs[k] = int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z']) // max(
+                int(r['Workgroup_Size_X']) * int(r['Workgroup_Size_Y']) * int(r['Workgroup_Size_Z']), 1)
+            all_k.append((b, e, k))
 line = bench_line('prof_bench') or {}
 steps = int(line.get('steps', 20)) + int(line.get('warmup', 5))
 cfg = line.get('config', {})
+# launches of different images overlap (bench.py --in_flight): concurrency = sum of the kernel durations inside the span of the
+# steps / that span.  A kernel's share of the chip's time per launch is avg_us / concurrency.
+# (steady state only: the window from the middle 3x3 launch of the run to the last one -- the first steps load code objects)
+k3s = sorted(t for t in all_k if t[2].startswith(('wino3x3', 'conv3x3_c128')))
+span_us = in_span = 0.0
+if len(k3s) >= 4:
+    w0, w1 = k3s[len(k3s) // 2][0], max(t[1] for t in k3s)
+    span_us = (w1 - w0) / 1e3
+    in_span = sum((min(e, w1) - max(b, w0)) / 1e3 for b, e, k in all_k if e > w0 and b < w1 and 'copyBuffer' not in k)
+concurrency = in_span / span_us if span_us > 0 else 1.0
 out = {'source': 'profiles/{}_counters.txt: rocprofv3 --kernel-trace and --pmc passes over `python bench.py --steps 20 --warmup 5 --no_extras '
                  '--calib_copy` (tools/profile_round.sh), one counter group per pass'.format(tag),
        'input_shape': [cfg.get('batch_per_gpu'), 3, cfg.get('height'), cfg.get('width')], 'branch_sharing': line.get('branch_sharing'),
-       'steps_profiled': steps, 'value_under_rocprof': line.get('value'), 'kernels': {}}
+       'steps_profiled': steps, 'value_under_rocprof': line.get('value'), 'images_in_flight': line.get('images_in_flight'),
+       'span_of_the_steps_us': round(span_us, 1), 'sum_of_kernel_durations_us': round(in_span, 1), 'concurrency': round(concurrency, 3),
+       'kernels': {}}
 groups = {}
 for grp in ('sq', 'fetch', 'write', 'l2'):
     path = find('prof_b_' + grp, 'counter_collection.csv')
     if path:
         groups[grp] = per_kernel(path)
 lines = ['rocprofv3 passes over the bench step (python bench.py --steps 20 --warmup 5 --no_extras --calib_copy), per-launch averages per kernel.',
+         'Images in flight: {}; launches of different images overlap: sum of kernel durations / span of the steps = {:.3f} (concurrency);'.format(
+             line.get('images_in_flight'), concurrency),
+         'avg_us is a launch\'s own duration (first work-group start to last work-group end), avg_us / concurrency its share of the chip\'s time.',
          'FETCH_SIZE / WRITE_SIZE are in KiB; the 256 MiB device copy at the end of the same pass calibrates them (gfx950: FETCH_SIZE tallies',
          '128-byte fabric reads at 64 B -> x2, MI355X_MICROARCH.md "HBM"; WRITE_SIZE exact).  mfma_busy_us = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs',
          '/ 2.4 GHz.  avg_us = kernel-trace duration.', '']
@@ -119,7 +139,8 @@ for k in names:
     if 'copyBuffer' in k or cnt[k] < steps // 2:
         continue
     ent = {'launches_per_step': round(cnt[k] / float(steps), 2), 'avg_us_rocprof': round(dur[k] / cnt[k], 2),
-           'share_of_kernel_time': round(dur[k] / sum(dur.values()), 4)}
+           'share_of_kernel_time': round(dur[k] / sum(dur.values()), 4), 'work_groups': wgs.get(k),
+           'avg_us_over_concurrency': round(dur[k] / cnt[k] / concurrency, 2)}
     c = {}
     for grp, (vals, _) in groups.items():
         c.update(vals.get(k, {}))
@@ -145,8 +166,8 @@ for k in names:
             ent['mfma_busy_us'] = round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / SIMDS / CLOCK_GHZ / 1e3, 2)
             ent['mfma_busy_share'] = round(ent['mfma_busy_us'] / ent['avg_us_rocprof'], 3)
     out['kernels'][k] = ent
-    lines.append('== {}   ({} per step, avg {} us, {:.1f} % of the step\'s kernel time)'.format(k, ent['launches_per_step'], ent['avg_us_rocprof'],
-                                                                                          100 * ent['share_of_kernel_time']))
+    lines.append('== {}   ({} per step, {} work-groups, avg {} us, / concurrency {} us, {:.1f} % of the step\'s kernel time)'.format(
+        k, ent['launches_per_step'], ent['work_groups'], ent['avg_us_rocprof'], ent['avg_us_over_concurrency'], 100 * ent['share_of_kernel_time']))
     for n, v in sorted(ent.get('counters', {}).items()):
         lines.append('   {:28s} {:16.1f}'.format(n, v) + ('      [256 MiB copy: {:.1f}]'.format(cal[n]) if n in cal else ''))
     for n in ('hbm_read_bytes_per_launch', 'hbm_write_bytes_per_launch', 'hbm_gb_per_s', 'l2_to_l1_bytes_per_launch', 'l2_hit_rate', 'valu_per_mfma',
