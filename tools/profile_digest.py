@@ -76,7 +76,7 @@ def bench_line(d):
     return json.loads(m[-1]) if m else None
 
 
-for t in ('bench', 'pc', 'train'):
+for t in ('bench', 'alone', 'bench1', 'pc', 'train'):
     src = find('prof_' + t, 'kernel_stats.csv')
     if src:
         shutil.copy(src, os.path.join(P, '{}_{}_kernel_stats.csv'.format(tag, t)))
@@ -98,6 +98,15 @@ if trace:
             wgs[k] = int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z']) // max(
                 int(r['Workgroup_Size_X']) * int(r['Workgroup_Size_Y']) * int(r['Workgroup_Size_Z']), 1)
             all_k.append((b, e, k))
+# the same kernels one image at a time (tools/profile_round.sh `alone`): a launch's duration with nothing beside it
+dur1, cnt1 = defaultdict(float), defaultdict(int)
+trace1 = find('prof_alone', 'kernel_trace.csv')
+if trace1:
+    with open(trace1) as f:
+        for r in csv.DictReader(f):
+            k = short(r['Kernel_Name'])
+            dur1[k] += (float(r['End_Timestamp']) - float(r['Start_Timestamp'])) / 1e3
+            cnt1[k] += 1
 line = bench_line('prof_bench') or {}
 steps = int(line.get('steps', 20)) + int(line.get('warmup', 5))
 cfg = line.get('config', {})
@@ -125,7 +134,8 @@ for grp in ('sq', 'fetch', 'write', 'l2'):
 lines = ['rocprofv3 passes over the bench step (python bench.py --steps 20 --warmup 5 --no_extras --calib_copy), per-launch averages per kernel.',
          'Images in flight: {}; launches of different images overlap: sum of kernel durations / span of the steps = {:.3f} (concurrency);'.format(
              line.get('images_in_flight'), concurrency),
-         'avg_us is a launch\'s own duration (first work-group start to last work-group end), avg_us / concurrency its share of the chip\'s time.',
+         'avg_us is a launch\'s duration one image at a time (pass `alone`: the same kernels, nothing beside them); in flight = its duration',
+         'in the shipped schedule under the tracer (first work-group start to last work-group end), / concurrency = its share of the chip\'s time.',
          'FETCH_SIZE / WRITE_SIZE are in KiB; the 256 MiB device copy at the end of the same pass calibrates them (gfx950: FETCH_SIZE tallies',
          '128-byte fabric reads at 64 B -> x2, MI355X_MICROARCH.md "HBM"; WRITE_SIZE exact).  mfma_busy_us = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs',
          '/ 2.4 GHz.  avg_us = kernel-trace duration.', '']
@@ -138,7 +148,9 @@ out['calibration'] = {'fetch_factor': round(f_fetch, 3), 'write_factor': round(f
 for k in names:
     if 'copyBuffer' in k or cnt[k] < steps // 2:
         continue
-    ent = {'launches_per_step': round(cnt[k] / float(steps), 2), 'avg_us_rocprof': round(dur[k] / cnt[k], 2),
+    ent = {'launches_per_step': round(cnt[k] / float(steps), 2),
+           'avg_us_rocprof': round(dur1[k] / cnt1[k], 2) if cnt1.get(k) else round(dur[k] / cnt[k], 2),     # alone (one image at a time)
+           'avg_us_in_flight': round(dur[k] / cnt[k], 2),
            'share_of_kernel_time': round(dur[k] / sum(dur.values()), 4), 'work_groups': wgs.get(k),
            'avg_us_over_concurrency': round(dur[k] / cnt[k] / concurrency, 2)}
     c = {}
@@ -165,13 +177,18 @@ for k in names:
         if c.get('SQ_VALU_MFMA_BUSY_CYCLES'):
             ent['mfma_busy_us'] = round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / SIMDS / CLOCK_GHZ / 1e3, 2)
             ent['mfma_busy_share'] = round(ent['mfma_busy_us'] / ent['avg_us_rocprof'], 3)
+            if wgs.get(k) and wgs[k] < 256:
+                # one work-group per CU on fewer than all CUs (the whole-K 3x3 form on a Kodak map: 192): the busy cycles are
+                # counted chip-wide, the launch only occupies work_groups / 256 of the chip
+                ent['mfma_busy_share_of_occupied_cus'] = round(ent['mfma_busy_share'] * 256.0 / wgs[k], 3)
     out['kernels'][k] = ent
-    lines.append('== {}   ({} per step, {} work-groups, avg {} us, / concurrency {} us, {:.1f} % of the step\'s kernel time)'.format(
-        k, ent['launches_per_step'], ent['work_groups'], ent['avg_us_rocprof'], ent['avg_us_over_concurrency'], 100 * ent['share_of_kernel_time']))
+    lines.append('== {}   ({} per step, {} work-groups, avg {} us alone, {} us in flight, / concurrency {} us, {:.1f} % of the step\'s kernel time)'.format(
+        k, ent['launches_per_step'], ent['work_groups'], ent['avg_us_rocprof'], ent['avg_us_in_flight'], ent['avg_us_over_concurrency'],
+        100 * ent['share_of_kernel_time']))
     for n, v in sorted(ent.get('counters', {}).items()):
         lines.append('   {:28s} {:16.1f}'.format(n, v) + ('      [256 MiB copy: {:.1f}]'.format(cal[n]) if n in cal else ''))
     for n in ('hbm_read_bytes_per_launch', 'hbm_write_bytes_per_launch', 'hbm_gb_per_s', 'l2_to_l1_bytes_per_launch', 'l2_hit_rate', 'valu_per_mfma',
-              'mfma_busy_us', 'mfma_busy_share'):
+              'mfma_busy_us', 'mfma_busy_share', 'mfma_busy_share_of_occupied_cus'):
         if n in ent:
             lines.append('   -> {:30s} {}'.format(n, ent[n]))
     lines.append('')

@@ -7,7 +7,14 @@
 set +e
 t=tools/profile.sh
 STEP="python bench.py --steps 20 --warmup 5 --no_extras --calib_copy"
+# the step as shipped (4 images in flight; under the tracer the streams overlap less than untraced: the digest reports the
+# concurrency it saw), the SAME kernels one image at a time (the plan hint of the in-flight schedule forced: each launch's
+# duration with nothing beside it -- what bench.py reports as `alone`), and the one-at-a-time schedule of rounds 1-2
+ALONE="$STEP --in_flight 1 --plan_flags 0x200000"
 timeout 320 $t trace bench $STEP
+timeout 320 $t trace alone $ALONE
+timeout 320 $t trace bench1 $STEP --in_flight 1
+STEP=$ALONE          # counter passes serialise the launches anyway: profile the step's kernels one image at a time
 timeout 320 $t pmc b_sq "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" $STEP
 timeout 320 $t pmc b_fetch "FETCH_SIZE" $STEP
 timeout 320 $t pmc b_write "WRITE_SIZE" $STEP
