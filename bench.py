@@ -8,7 +8,7 @@ A "step" is one pass of the hot path over one batch of synthetic input: BASELINE
 Inputs and weights are resident in HBM before the timed region.  Data: seeded synthetic images and
 random-init weights (no network for Kodak or the 0515_1103 checkpoint).
 
-Schedule (--in_flight n, default 4): the images of an evaluation set are independent (val.py:157-158 runs one per sess.run), so
+Schedule (--in_flight n, default 6): the images of an evaluation set are independent (val.py:157-158 runs one per sess.run), so
 n of them are in flight at a time, each a batch-1 step on its own stream with its own network objects and workspace; steps are
 issued round-robin and EVERY step is still one image through the whole path.  The launches of one image fill the kernel-boundary
 bubbles of the others, and a 3x3 launch no longer has to fill the chip alone (IC_CONV3_IN_FLIGHT: the plan takes the form with
@@ -115,6 +115,11 @@ class InFlight(object):
             # the plan hint: n independent calls of this shape are in flight (IC_CONV3_IN_FLIGHT, include/imgcomp_hip.h)
             pl.ae.plan_flags = first.ae.plan_flags | _lib.CONV3_IN_FLIGHT(n)
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(n)]
+        # set-up, not warm-up: every pipeline allocates its workspaces and output buffers on its first pass
+        for pl, s_ in zip(self.pipes, self.streams):
+            with torch.cuda.stream(s_):
+                pl.step()
+        torch.cuda.synchronize(dev)
 
     def step(self):
         k = self.i % self.n
@@ -139,7 +144,7 @@ def main():
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--no_extras', action='store_true', help='headline only: no stage split, roofline, extra shapes (rocprofv3 runs)')
     p.add_argument('--pipelined', action='store_true', help='also run the informational three-pipelines-in-flight section')
-    p.add_argument('--in_flight', type=int, default=4,
+    p.add_argument('--in_flight', type=int, default=6,
                    help='independent batch-1 images in flight on their own streams (serial arrangement only); 1 = one image at a time')
     p.add_argument('--calib_copy', action='store_true',
                    help='after the timed steps: a 256 MiB device-to-device copy (rocprofv3 --pmc passes calibrate FETCH_SIZE / WRITE_SIZE on it)')

@@ -239,7 +239,7 @@ def validate(ae_config, pc_config, weights, image_paths, out_dir, flags, device=
     """-> dict of averages; writes out_dir/measures.csv (rank 0).
     in_flight: images of this rank processed concurrently, each by its own Fetcher (networks, workspace, stream): the images
     are independent (the reference runs one per sess.run, val.py:157-158), and the launches of one fill the kernel-boundary
-    bubbles of the others (bench.py: 158 -> 166 Mpix/s on Kodak-sized images with 4).  --real_bpp codes one image at a time."""
+    bubbles of the others, and a 3x3 launch need not fill the chip alone (bench.py: 158 -> 183 Mpix/s on Kodak-sized images with 4).  --real_bpp codes one image at a time."""
     from collections import deque
     rank, world = sharding.rank_and_world()
     n_f = 1 if (flags.real_bpp or host_metrics) else max(1, int(in_flight))
