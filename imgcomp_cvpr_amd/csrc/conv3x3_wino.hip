@@ -405,9 +405,16 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
             const unsigned lo0 = inside ? (unsigned)((4 * kh * HW + oy * W + ox) * 4) : WN_OOB;
             const unsigned lo1 = inside && row1 ? lo0 + 4u * W : WN_OOB;
 #ifndef WN_EPD
-#define WN_EPD 6
+#define WN_EPD 6          // operand slots of the epilogue pipeline
+#define WN_EPA 5          // channels requested ahead
+#define WN_EPU 1          // channels finished per scheduling region
 #endif
-            constexpr int EPD = WN_EPD;
+            // Round 3, measured with -DWN_PROF on a Kodak map (8.35 k clocks of epilogue per wave): two or four channels per
+            // scheduling region (more independent chains for the one resident wave) change nothing -- 8.62 k / 8.42 k.  The
+            // epilogue of a lock-step round is a bandwidth burst: every work-group stores its 64 KB and reads one or two
+            // residuals of the same size within the same ~3.5 us (25-38 MB: 7-11 TB/s demanded), not an issue-bound loop.
+            constexpr int EPD = WN_EPD, EPA = WN_EPA, EPU = WN_EPU;
+            static_assert(EPA + EPU <= EPD && 16 % EPU == 0, "a slot is refilled only after its channel has been finished");
             float sc[EPD], sh[EPD];
             f32x2 ra0[EPD], ra1[EPD], rb0[EPD], rb1[EPD];
             const float relu_lo = a.relu ? 0.f : -__builtin_inff();
@@ -423,31 +430,37 @@ __device__ __forceinline__ void wino_body(const WnArgs& a, int n, int gy, int gx
                 rb1[sl] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r2r, lo1, so, 0));
             };
 #pragma unroll
-            for (int r = 0; r < EPD - 1; ++r) fetch(r);
+            for (int r = 0; r < EPA; ++r) fetch(r);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (r + EPD - 1 < 16) fetch(r + EPD - 1);
-                const int cr = (r & 3) + 8 * (r >> 2), sl = r % EPD;
-                float t0[4], t1[4];
+            for (int r0_ = 0; r0_ < 16; r0_ += EPU) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float m0 = acc[j][r], m1 = acc[4 + j][r], m2 = acc[8 + j][r], m3 = acc[12 + j][r];
-                    t0[j] = m0 + m1 + m2;
-                    t1[j] = m1 - m2 - m3;
+                for (int u = 0; u < EPU; ++u)
+                    if (r0_ + u + EPA < 16) fetch(r0_ + u + EPA);
+#pragma unroll
+                for (int u = 0; u < EPU; ++u) {
+                    const int r = r0_ + u;
+                    const int cr = (r & 3) + 8 * (r >> 2), sl = r % EPD;
+                    float t0[4], t1[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float m0 = acc[j][r], m1 = acc[4 + j][r], m2 = acc[8 + j][r], m3 = acc[12 + j][r];
+                        t0[j] = m0 + m1 + m2;
+                        t1[j] = m1 - m2 - m3;
+                    }
+                    float o00 = t0[0] + t0[1] + t0[2], o01 = t0[1] - t0[2] - t0[3];
+                    float o10 = t1[0] + t1[1] + t1[2], o11 = t1[1] - t1[2] - t1[3];
+                    o00 = fmaf(o00, sc[sl], sh[sl]); o01 = fmaf(o01, sc[sl], sh[sl]);
+                    o10 = fmaf(o10, sc[sl], sh[sl]); o11 = fmaf(o11, sc[sl], sh[sl]);
+                    o00 = fmaxf(o00, relu_lo); o01 = fmaxf(o01, relu_lo); o10 = fmaxf(o10, relu_lo); o11 = fmaxf(o11, relu_lo);
+                    f32x2 q0 = {o00, o01}, q1 = {o10, o11};
+                    q0 += ra0[sl]; q1 += ra1[sl];
+                    q0 += rb0[sl]; q1 += rb1[sl];
+                    const int so = (32 * cot + cr) * HW * 4;
+                    // WT: a launch that is one round of work-groups stores write-through (sc1): nothing is left dirty in the L2s
+                    // for the kernel boundary to write back (measured on the NB-segment kernel: 1 us per layer)
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q0), yr, lo0, so, WT ? 16 : 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q1), yr, lo1, so, WT ? 16 : 0);
                 }
-                float o00 = t0[0] + t0[1] + t0[2], o01 = t0[1] - t0[2] - t0[3];
-                float o10 = t1[0] + t1[1] + t1[2], o11 = t1[1] - t1[2] - t1[3];
-                o00 = fmaf(o00, sc[sl], sh[sl]); o01 = fmaf(o01, sc[sl], sh[sl]);
-                o10 = fmaf(o10, sc[sl], sh[sl]); o11 = fmaf(o11, sc[sl], sh[sl]);
-                o00 = fmaxf(o00, relu_lo); o01 = fmaxf(o01, relu_lo); o10 = fmaxf(o10, relu_lo); o11 = fmaxf(o11, relu_lo);
-                f32x2 q0 = {o00, o01}, q1 = {o10, o11};
-                q0 += ra0[sl]; q1 += ra1[sl];
-                q0 += rb0[sl]; q1 += rb1[sl];
-                const int so = (32 * cot + cr) * HW * 4;
-                // WT: a launch that is one round of work-groups stores write-through (sc1): nothing is left dirty in the L2s for
-                // the kernel boundary to write back (measured on the NB-segment kernel: 1 us per layer)
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q0), yr, lo0, so, WT ? 16 : 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q1), yr, lo1, so, WT ? 16 : 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
