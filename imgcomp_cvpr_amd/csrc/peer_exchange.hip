@@ -108,7 +108,7 @@ extern "C" int ic_peer_allreduce_f64(double* vals, int n, void* const* regions_h
     IC_CHECK_ARG(vals && regions_host && status && n > 0 && world > 0 && rank >= 0 && rank < world && seq != 0u);
     if (n > PX_MAXN || world > PX_MAX_WORLD) return IC_ERR_UNSUPPORTED;
     PxArgs a{};
-    a.vals = vals; a.rank = rank; a.world = world; a.n = n; a.seq = seq; a.spin_limit = 1u << 22; a.status = status;
+    a.vals = vals; a.rank = rank; a.world = world; a.n = n; a.seq = seq; a.spin_limit = 1u << 20;          // ~ a second of polling a.status = status;
     for (int r = 0; r < world; ++r) {
         IC_CHECK_ARG(regions_host[r] != nullptr);
         a.region[r] = (char*)regions_host[r];

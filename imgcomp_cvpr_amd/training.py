@@ -327,6 +327,9 @@ class TrainGraph(object):
                 from . import peer
                 self._peer = peer.PeerExchange(self.dev, self.pg)
             self._peer.allreduce_f64(sums)
+            self._peer_calls = getattr(self, '_peer_calls', 0) + 1
+            if self._peer_calls % 1024 == 1:
+                self._peer.check_status()                  # (synchronises: once per ~7 steps) a stalled peer raises instead of training on
             return
         if _is_gloo(self.pg):
             _staged_all_reduce(sums, self.pg)

@@ -659,6 +659,8 @@ def _peer_worker(rank, world, port, backend, device_index, out_q):
             t = torch.arange(n, dtype=torch.float64, device=dev_) * (rank + 1) + it * 0.5 + rank * 1e-3
             want = sum(torch.arange(n, dtype=torch.float64) * (r + 1) + it * 0.5 + r * 1e-3 for r in range(world))
             px.allreduce_f64(t)
+            if it % 20 == 0:
+                px.check_status()                          # a time-out ends the test at once instead of 200 bounded spins
             got = t.cpu()
             ok = ok and bool(torch.equal(got, want))       # float64 sums in rank order: exactly the host's sum in the same order
             last = got
