@@ -413,3 +413,42 @@ def test_branch_streams_cu_range(cuda, configs, syn_weights, nets):
         assert _lib.lib.ic_stream_create_cu_range(max(bs.n_cus - 8, 0), 16, ctypes.byref(h)) != 0
     finally:
         bs.close()
+
+
+def test_images_in_flight_plan_hint(cuda, nets, configs, syn_weights):
+    """IC_CONV3_IN_FLIGHT(n): with n independent calls in flight the 3x3 plan takes whole-K jobs as soon as n launches together cover
+    the chip (a Kodak map: 192 work-groups from n = 2 on), small maps keep their one-launch plan; the outputs do not depend on it
+    (same operations per output in every Winograd form), neither do they when several images really are in flight on streams."""
+    import ctypes
+    from imgcomp_cvpr_amd import autoencoder, weights as W, _lib
+    lib = _lib.lib
+    pl = (ctypes.c_longlong * 5)()
+    _lib.check(lib.ic_wino3x3_c128_plan(1, 128, 192, _lib.CONV3_IN_FLIGHT(4), pl))
+    assert list(pl) == [192, 0, 0, 0, 0] and int(lib.ic_wino3x3_c128_workgroups(1, 128, 192, _lib.CONV3_IN_FLIGHT(4))) == 192
+    _lib.check(lib.ic_wino3x3_c128_plan(1, 128, 192, _lib.CONV3_IN_FLIGHT(1), pl))
+    assert list(pl)[:3] == [0, 192, 3]                              # one call at a time: NB = 3 segment jobs on every CU
+    _lib.check(lib.ic_wino3x3_c128_plan(1, 64, 64, _lib.CONV3_IN_FLIGHT(4), pl))
+    assert list(pl)[:3] == [0, 32, 1]                               # 4 x 32 tile groups do not cover the chip
+    _lib.check(lib.ic_wino3x3_c128_plan(1, 64, 64, _lib.CONV3_IN_FLIGHT(8), pl))
+    assert list(pl) == [32, 0, 0, 0, 0]
+    ae_cfg, _ = configs
+    ae, _pc = nets
+    n = 3
+    xs = [dev(W.synthetic_image((1, 3, 128, 192), 'natural', seed=20 + i), cuda) for i in range(n)]
+    ref = []
+    for x in xs:
+        e = ae.encode(x, False)
+        ref.append((e.symbols.clone(), e.z.clone(), ae.decode(e.qhard, False).clone()))
+    aes = [autoencoder.get_network_cls(ae_cfg)(ae_cfg).load_weights(syn_weights, cuda) for _ in range(n)]
+    strs = [torch.cuda.Stream(device=cuda) for _ in range(n)]
+    torch.cuda.synchronize()
+    outs = [None] * n
+    for rep in range(3):
+        for i in range(n):
+            with torch.cuda.stream(strs[i]):
+                aes[i].plan_flags = _lib.CONV3_IN_FLIGHT(n)
+                e = aes[i].encode(xs[i], False)
+                outs[i] = (e.symbols, e.z, aes[i].decode(e.qhard, False))
+    torch.cuda.synchronize()
+    for (s0, z0, o0), (s1, z1, o1) in zip(ref, outs):
+        assert torch.equal(s0, s1) and torch.equal(z0, z1) and torch.equal(o0, o1)
