@@ -902,7 +902,9 @@ static WinoPlan wino_plan(long long groups, bool even_w, int flags) {
     // the form with the lowest CU-time per tile group (whole-K: one work-group per group for 37.5 us; NB = 3 segments: 1.33 CUs
     // per group for 30 us + its boundary) -- measured on Kodak-sized images, 4 in flight: 183 against 168 Mpix/s (bench.py)
     const int in_flight = (flags >> 19) & 0xf;
-    if (in_flight >= 2 && in_flight * groups >= 256 && !leave_idle) { p.whole = groups; return p; }
+    // (launches of >= 128 groups only: on a 64 x 64 map -- 32 work-groups of 36 us each -- the layer chain of one image gets too
+    // long to be covered by the other images: 66 against 108 Mpix/s at 8 in flight)
+    if (in_flight >= 2 && groups >= 128 && !leave_idle) { p.whole = groups; return p; }
     const long long r = groups % 256, full = groups - r;
     double best = whole_cost(r);
     p.whole = groups;

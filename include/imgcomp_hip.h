@@ -70,7 +70,8 @@ typedef void* ic_stream_t;
 /* the caller keeps n (2..15) INDEPENDENT calls of this shape in flight on different streams (the images of an evaluation set,
  * val.py:157-158): a launch no longer has to fill the chip by itself, so the plan takes the form that costs the least CU-time --
  * 32 x 32 whole-K jobs, whose 192 work-groups for a Kodak map leave a quarter of the chip to the neighbouring stream's launch
- * instead of idle -- whenever n launches together cover the chip.  n = 0 / 1: plan for one launch at a time. */
+ * instead of idle -- for launches of at least 128 tile groups (smaller maps keep the one-launch plan: their work-groups are short
+ * and the overlap alone fills the chip).  n = 0 / 1: plan for one launch at a time. */
 #define IC_CONV3_IN_FLIGHT(n)     (((n) & 0xf) << 19)   /* NB-segment kernels: input transform on v_pk_add_f32 instead of single adds (A/B) */
 #define IC_CONV3_DIRECT_VARIANT(v) ((((v) + 1) & 0xf) << 8)   /* direct form: force tile variant v (0..9); tests */
 /* h13 (ic_deconv2d_bn_act_f32, 5x5/2 transposed, 64 -> <= 4): tiles per work-group, 0 = automatic; tests */
