@@ -108,7 +108,8 @@ if trace1:
             dur1[k] += (float(r['End_Timestamp']) - float(r['Start_Timestamp'])) / 1e3
             cnt1[k] += 1
 line = bench_line('prof_bench') or {}
-steps = int(line.get('steps', 20)) + int(line.get('warmup', 5))
+n_if = int(line.get('images_in_flight') or 1)
+steps = int(line.get('steps', 20)) + int(line.get('warmup', 5)) + (n_if if n_if > 1 else 0)      # + one set-up pass per pipeline
 cfg = line.get('config', {})
 # launches of different images overlap (bench.py --in_flight): concurrency = sum of the kernel durations inside the span of the
 # steps / that span.  A kernel's share of the chip's time per launch is avg_us / concurrency.
