@@ -644,7 +644,7 @@ def train_main(a, dev, rank, world):
             'config': {'workload': 'BASELINE configs[2]: train step, ae_configs/cvpr/med + pc_configs/cvpr/res_shallow, {}x3x{}x{} '
                                    'per GPU, MS-SSIM loss, two Adam optimisers, data-parallel gradient all-reduce'.format(N, H, Wd),
                        'batch_per_gpu': N, 'global_batch': N * world, 'parallelism': 'dp{}'.format(world),
-                       'sync_bn': bool(tr.graph.sync_bn) if hasattr(tr, 'graph') and hasattr(tr.graph, 'sync_bn') else None},
+                       'cross_replica_batchnorm': tr.graph._bn_world() > 1},
             'mpix_per_s': round(N * H * Wd * world * a.steps / elapsed / 1e6, 3),
             'last_step': {k: round(float(v), 5) for k, v in out.items()}}), flush=True)
     if world > 1:
