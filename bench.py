@@ -249,7 +249,9 @@ def main():
         ms_dec = timed(lambda: ae.decode(enc.qhard, False), 10)
         ms_dec_shared = timed(lambda: ae.decode(enc.qhard, False, plan_flags=pipe.dec_flags), 10) if pipe.dec_flags else ms_dec
         extra.update({'ms_encode': round(ms_enc, 4), 'ms_pc_bitcost': round(ms_pc, 4), 'ms_decode': round(ms_dec, 4),
-                      'ms_decode_with_step_flags': round(ms_dec_shared, 4)})
+                      'ms_decode_with_step_flags': round(ms_dec_shared, 4),
+                      'stage_split_note': 'each stage of ONE image alone on one stream (one-image-at-a-time plan): their sum is the '
+                                          'one_image_at_a_time step, not ms_per_step of {} images in flight'.format(n_flight)})
 
         # ---- dominant kernel, in-step: the 32-layer residual stack with its own 32 filters through the library's own launch
         # sequence (ic_ae_res_stack_f32 = the res_stack of network.hip that encode / decode run), HIP events around it.
