@@ -83,7 +83,26 @@ class Pipeline(object):
         self.dec_flags = self.branch.decode_flags(self.side)
         return self
 
+    def capture(self):
+        """record one step of this pipeline into a HIP graph (static input, static outputs): a step is then ONE replay -- the
+        ~150 launches of an image cost the host one call instead of ~0.35 ms of enqueueing"""
+        torch = self.torch
+        for _ in range(2):
+            self._step_eager()                         # first-use allocations happen outside the capture
+        torch.cuda.synchronize(self.dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._graph_out = self._step_eager()
+        self._graph = g
+        return self
+
     def step(self):
+        if getattr(self, '_graph', None) is not None:
+            self._graph.replay()
+            return self._graph_out
+        return self._step_eager()
+
+    def _step_eager(self):
         from imgcomp_cvpr_amd import bits
         torch = self.torch
         cur = torch.cuda.current_stream(self.dev)
@@ -107,7 +126,7 @@ class InFlight(object):
     the kernel-boundary bubbles of the others -- and a launch no longer has to fill the chip alone, so the 3x3 layers run the
     form with the least CU-time (IC_CONV3_IN_FLIGHT).  Every step is still ONE image through the whole path."""
 
-    def __init__(self, torch, first, dev, n, ae_config, seed0):
+    def __init__(self, torch, first, dev, n, ae_config, seed0, graphs=False):
         self.torch, self.n, self.i = torch, n, 0
         from imgcomp_cvpr_amd import _lib
         self.pipes = [Pipeline(dev, ae_config, 'serial', seed=seed0 + 1000 * k).set_input(first.N, first.H, first.Wd) for k in range(n)]
@@ -120,6 +139,9 @@ class InFlight(object):
             with torch.cuda.stream(s_):
                 pl.step()
         torch.cuda.synchronize(dev)
+        if graphs:
+            for pl in self.pipes:
+                pl.capture()
 
     def step(self):
         k = self.i % self.n
@@ -146,6 +168,7 @@ def main():
     p.add_argument('--pipelined', action='store_true', help='also run the informational three-pipelines-in-flight section')
     p.add_argument('--in_flight', type=int, default=6,
                    help='independent batch-1 images in flight on their own streams (serial arrangement only); 1 = one image at a time')
+    p.add_argument('--graphs', type=int, default=0, help='1: every in-flight pipeline replays its step from a captured HIP graph')
     p.add_argument('--calib_copy', action='store_true',
                    help='after the timed steps: a 256 MiB device-to-device copy (rocprofv3 --pmc passes calibrate FETCH_SIZE / WRITE_SIZE on it)')
     p.add_argument('--plan_flags', type=lambda v: int(v, 0), default=0,
@@ -204,7 +227,7 @@ def main():
         return time.perf_counter() - t0, out
 
     n_flight = a.in_flight if (pipe.serial and a.in_flight > 1) else 1
-    sched = InFlight(torch, pipe, dev, n_flight, a.ae_config, rank) if n_flight > 1 else pipe
+    sched = InFlight(torch, pipe, dev, n_flight, a.ae_config, rank, graphs=bool(a.graphs)) if n_flight > 1 else pipe
     elapsed, (bpp, x_out) = run(sched, a.steps, a.warmup, collective=True)
     elapsed = max_over_ranks(torch, dist, elapsed, dev, world, a.backend)
     value = N * H * Wd * world * a.steps / elapsed / 1e6
@@ -404,7 +427,7 @@ def main():
                 continue
             ps = Pipeline(dev, a.ae_config, share, seed=rank).set_input(n2, h2, w2)
             dt1, _ = run(ps, 30, 5)
-            sch = InFlight(torch, ps, dev, n_flight, a.ae_config, rank) if n_flight > 1 else ps
+            sch = InFlight(torch, ps, dev, n_flight, a.ae_config, rank, graphs=bool(a.graphs)) if n_flight > 1 else ps
             dt, _ = run(sch, 30, 5) if n_flight > 1 else (dt1, None)
             flop = n2 * h2 * w2 * (FLOP_PER_PX_ENC * 16.0 / 36.0 + FLOP_PER_PX_DEC * 16.0 / 36.0)
             shapes.append({'batch': n2, 'height': h2, 'width': w2, 'value': round(n2 * h2 * w2 * 30 / dt / 1e6, 3), 'unit': 'Mpix/s',
