@@ -59,10 +59,11 @@ __global__ void pack_conv_mfma_kernel(const float* __restrict__ w, float* __rest
 
 struct GPhase { const float* wp; int oy0, ox0, py, px; };
 
-template <int NTY, int NTX, int PS, int WK, int TR, int TC>
+// CPC: 8-channel groups staged per chunk (one barrier per chunk: more groups = more MFMAs between barriers)
+template <int NTY, int NTX, int PS, int WK, int TR, int TC, int CPC = 1>
 struct GGeo {
     static constexpr int ROWS = (TR - 1) * PS + NTY, COLS = (TC - 1) * PS + NTX;
-    static constexpr int S = COLS, CS = ROWS * COLS, CHUNK = GKC * WK * CS;
+    static constexpr int S = COLS, CS = ROWS * COLS, CHUNK = GKC * WK * CS * CPC;
     static constexpr int NST = (CHUNK + 255) / 256;
     static constexpr int LDSF = 2 * NST * 256;
     static_assert(NST <= 32, "in-bounds mask is 32 bits");
@@ -81,14 +82,16 @@ struct GGeo {
 // operand is already in the register, the weight comes as one 16-byte load per tap from that channel's row of the packed
 // fragments.  Sum order of that channel: per (K-slice, k parity) ascending chains, then parity 0 + parity 1, then the K-slices
 // in order -- fixed and position independent like the tiles' own.
-template <int NTY, int NTX, int PS, int CIN, int WM, int WN, int WK, int PT, int TR, int TC, int RD, bool KEEP = false, bool X1 = false>
+template <int NTY, int NTX, int PS, int CIN, int WM, int WN, int WK, int PT, int TR, int TC, int RD, bool KEEP = false, bool X1 = false, int CPC = 1>
 __device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph, float* __restrict__ lds, f32x16* keep = nullptr) {
 #ifdef CM_PROF
     const unsigned long long cm_t0 = __builtin_amdgcn_s_memtime();
 #endif
-    using G = GGeo<NTY, NTX, PS, WK, TR, TC>;
+    using G = GGeo<NTY, NTX, PS, WK, TR, TC, CPC>;
     constexpr int NT = NTY * NTX;
-    constexpr int NCH = CIN / (GKC * WK);
+    constexpr int NCH = CIN / (GKC * WK * CPC);
+    static_assert(CPC == 1 || WK == 1, "several channel groups per chunk: whole-K waves only");
+    static_assert(CIN % (GKC * WK * CPC) == 0, "Cin multiple of the chunk");
     constexpr int S = G::S, CS = G::CS, CHUNK = G::CHUNK, NST = G::NST;
     static_assert(WM * WN * WK == 4, "4 waves per work-group");
     static_assert(TR * TC == 32 * PT * WN, "tile = PT accumulator tiles per wave x WN pixel groups");
@@ -194,13 +197,16 @@ __device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph,
         const bool more = c + 1 < NCH;
         float st[NST];
         if (more) {
-            const float* xc = xin + (size_t)(c + 1) * GKC * WK * IHW;
+            const float* xc = xin + (size_t)(c + 1) * GKC * WK * CPC * IHW;
 #pragma unroll
             for (int i = 0; i < NST; ++i) st[i] = xc[goff[i]];
         }
         const float* __restrict__ L = lds + (c & 1) * (NST * 256);
-        const int c8 = c * WK + wk_u, c8n = more ? (c + 1) * WK + wk_u : c8;     // past the end: re-read (never used)
-        // B operands of tap t + 1 are read while the MFMAs of tap t run (left alone the compiler reads each one right
+        // the chunk's 8-channel groups one after the other as ONE sequence of CPC * NT taps (u = group * NT + tap): filter ring
+        // and B-operand double buffer run across the group boundaries
+        const int c8 = c * WK * CPC + wk_u, c8n = more ? (c + 1) * WK * CPC + wk_u : c8;   // past the end: re-read (never used)
+        constexpr int NU = CPC * NT;
+        // B operands of tap u + 1 are read while the MFMAs of tap u run (left alone the compiler reads each one right
         // before its use: load, wait, multiply); the first tap of a chunk reads its own after the barrier
         float bq[2][4][PT];
 #pragma unroll
@@ -208,33 +214,34 @@ __device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph,
 #pragma unroll
             for (int p = 0; p < PT; ++p) bq[0][ks][p] = L[boff[p] + 2 * ks * CS];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            // ring: request tap g + RD - 2 into the slot whose last reader was tap g - 2
+        for (int u = 0; u < NU; ++u) {
+            // ring: request tap u + RD - 2 into the slot whose last reader was tap u - 2
             {
-                const int tn = t + RD - 2;
-                if (tn < NT) ring[tn % RD] = wload(c8, tn);
-                else ring[tn % RD] = wload(c8n, tn - NT);
+                const int un = u + RD - 2;
+                if (un < NU) ring[un % RD] = wload(c8 + un / NT, un % NT);
+                else ring[un % RD] = wload(c8n + (un - NU) / NT, (un - NU) % NT);
                 if constexpr (X1) {
-                    if (tn < NT) xring[tn % RD] = xload(c8, tn);
-                    else xring[tn % RD] = xload(c8n, tn - NT);
+                    if (un < NU) xring[un % RD] = xload(c8 + un / NT, un % NT);
+                    else xring[un % RD] = xload(c8n + (un - NU) / NT, (un - NU) % NT);
                 }
             }
-            if (t + 1 < NT) {
-                const int tapoff = ((t + 1) / NTX) * S + ((t + 1) % NTX);
+            if (u + 1 < NU) {
+                const int tn = (u + 1) % NT, gn = (u + 1) / NT;
+                const int tapoff = (tn / NTX) * S + (tn % NTX) + 8 * gn * CS;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                    for (int p = 0; p < PT; ++p) bq[(t + 1) & 1][ks][p] = L[boff[p] + 2 * ks * CS + tapoff];
+                    for (int p = 0; p < PT; ++p) bq[(u + 1) & 1][ks][p] = L[boff[p] + 2 * ks * CS + tapoff];
             }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const float av = ring[t % RD][ks];
+                const float av = ring[u % RD][ks];
 #pragma unroll
                 for (int p = 0; p < PT; ++p)
-                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[t & 1][ks][p], acc[p], 0, 0, 0);
+                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[u & 1][ks][p], acc[p], 0, 0, 0);
                 // volatile asm: left to the compiler, the whole fma chain sinks behind the K loop and drags every B operand
                 // of the chunk along in registers (256 VGPR + 112 AGPR, one wave per SIMD)
-                if constexpr (X1) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(accx) : "v"(xring[t % RD][ks]), "v"(bq[t & 1][ks][0]));
+                if constexpr (X1) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(accx) : "v"(xring[u % RD][ks]), "v"(bq[u & 1][ks][0]));
             }
 #pragma unroll
             for (int i = 0; i < 4 * PT; ++i) {
@@ -242,7 +249,7 @@ __device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph,
                 if (i == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // the tap's filter request
                 if (X1 && i == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // ... and the extra channel's
                 if (X1) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);         // the extra channel's fma of this k-step
-                if (t + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // 1 LDS read of the next tap
+                if (u + 1 < NU) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // 1 LDS read of the next tap
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -343,10 +350,10 @@ __device__ __forceinline__ void conv_mfma_body(const GArgs& a, const GPhase& ph,
 #endif
 }
 
-template <int NTY, int NTX, int PS, int CIN, int WM, int WN, int WK, int PT, int TR, int TC, int RD>
+template <int NTY, int NTX, int PS, int CIN, int WM, int WN, int WK, int PT, int TR, int TC, int RD, int CPC = 1>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const GArgs a, const GPhase ph) {
-    __shared__ float lds[GGeo<NTY, NTX, PS, WK, TR, TC>::LDSF];
-    conv_mfma_body<NTY, NTX, PS, CIN, WM, WN, WK, PT, TR, TC, RD>(a, ph, lds);
+    __shared__ float lds[GGeo<NTY, NTX, PS, WK, TR, TC, CPC>::LDSF];
+    conv_mfma_body<NTY, NTX, PS, CIN, WM, WN, WK, PT, TR, TC, RD, false, false, CPC>(a, ph, lds);
 }
 
 template <int NTY, int NTX, int PS, int CIN, int WM, int WN, int WK, int PT, int TR, int TC, int RD>
@@ -375,17 +382,17 @@ __global__ __launch_bounds__(256) void deconv5_mfma_kernel(const GArgs a, const 
 // above) every store instruction writes every other float of its lines and the two halves of a line come from different
 // work-groups at different times: rocprofv3 counted 46.7 MB written for a 25.2 MB output (profiles/r03_counters.txt).
 typedef float f32x2g __attribute__((ext_vector_type(2)));
-template <int CIN, int WM, int WN, int PT, int TR, int TC>
+template <int CIN, int WM, int WN, int PT, int TR, int TC, int CPC>
 __global__ __launch_bounds__(256) void deconv5_pair_kernel(const GArgs a, const GPhases4 ph) {
-    __shared__ float lds[GGeo<3, 3, 1, 1, TR, TC>::LDSF];
+    __shared__ float lds[GGeo<3, 3, 1, 1, TR, TC, CPC>::LDSF];
     f32x16 v0[PT], v1[PT];
     const int py = blockIdx.z;
     if (py == 0) {               // taps 2x2 then 2x3
-        conv_mfma_body<2, 2, 1, CIN, WM, WN, 1, PT, TR, TC, 4, true>(a, ph.p[0], lds, v0);
-        conv_mfma_body<2, 3, 1, CIN, WM, WN, 1, PT, TR, TC, 3, true>(a, ph.p[1], lds, v1);
+        conv_mfma_body<2, 2, 1, CIN, WM, WN, 1, PT, TR, TC, 4, true, false, CPC>(a, ph.p[0], lds, v0);
+        conv_mfma_body<2, 3, 1, CIN, WM, WN, 1, PT, TR, TC, 3, true, false, CPC>(a, ph.p[1], lds, v1);
     } else {                     // taps 3x2 then 3x3
-        conv_mfma_body<3, 2, 1, CIN, WM, WN, 1, PT, TR, TC, 3, true>(a, ph.p[2], lds, v0);
-        conv_mfma_body<3, 3, 1, CIN, WM, WN, 1, PT, TR, TC, 3, true>(a, ph.p[3], lds, v1);
+        conv_mfma_body<3, 2, 1, CIN, WM, WN, 1, PT, TR, TC, 3, true, false, CPC>(a, ph.p[2], lds, v0);
+        conv_mfma_body<3, 3, 1, CIN, WM, WN, 1, PT, TR, TC, 3, true, false, CPC>(a, ph.p[3], lds, v1);
     }
     // same decomposition as the body's: tile, channel tile, pixel of this lane
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -497,7 +504,10 @@ extern "C" int ic_conv2d_mfma_bn_act_f32(const float* x, const float* w_packed, 
                                dim3(a.tiles_x * a.tiles_y * N, ic_cdiv(Cout, 32)), dim3(256), 0, st, a, ph);   // live channel tiles only
         } else if (Cin == 64) {     // h2: 4 channel tiles x 32 pixels per work-group
             a.tiles_x = ic_cdiv(a.GW, 16); a.tiles_y = ic_cdiv(a.GH, 2);
-            hipLaunchKernelGGL((conv_mfma_kernel<5, 5, 2, 64, 4, 1, 1, 1, 2, 16, 5>),
+#ifndef CM_CPC_H2
+#define CM_CPC_H2 2         // 8-channel groups per staged chunk (tuning builds: 1 = the round-2 form)
+#endif
+            hipLaunchKernelGGL((conv_mfma_kernel<5, 5, 2, 64, 4, 1, 1, 1, 2, 16, 5, CM_CPC_H2>),
                                dim3(a.tiles_x * a.tiles_y * N, ncot / 4), dim3(256), 0, st, a, ph);
         } else {                    // to_bn: 1 channel tile x 32 pixels x 4 K-slices per work-group
             a.tiles_x = ic_cdiv(a.GW, 16); a.tiles_y = ic_cdiv(a.GH, 2);
@@ -527,7 +537,10 @@ extern "C" int ic_conv2d_mfma_bn_act_f32(const float* x, const float* w_packed, 
         hipLaunchKernelGGL((deconv5_mfma_kernel<128, 2, 2, 1, 4, 16>),
                            dim3(a.tiles_x * a.tiles_y * N, ncot / 2, 4), dim3(256), 0, st, a, ph);
 #else
-        hipLaunchKernelGGL((deconv5_pair_kernel<128, 2, 2, 1, 4, 16>),
+#ifndef CM_CPC_H12
+#define CM_CPC_H12 2
+#endif
+        hipLaunchKernelGGL((deconv5_pair_kernel<128, 2, 2, 1, 4, 16, CM_CPC_H12>),
                            dim3(a.tiles_x * a.tiles_y * N, ncot / 2, 2), dim3(256), 0, st, a, ph);
 #endif
     }
