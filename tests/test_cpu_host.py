@@ -238,7 +238,7 @@ local = [(i, (items[i], i * i)) for i in mine]
 allr = sharding.gather_in_order(local, len(items))
 assert allr == [(items[i], i * i) for i in range(7)], allr
 assert sharding.shard(items) == [items[i] for i in mine]
-dist.barrier()
+sharding.barrier()                      # (val.py --reset: every rank passes it, whatever rank 0 did before)
 dist.destroy_process_group()
 print('rank', rank, 'ok', mine)
 '''
@@ -324,6 +324,7 @@ def test_train_host_logic(tmp_path):
 
 def test_sharding_single_process():
     from imgcomp_cvpr_amd import sharding
+    sharding.barrier()                  # no process group: a no-op
     assert sharding.shard_indices(5, 1, 2) == [1, 3]
     assert sorted(sharding.shard_indices(9, 0, 4) + sharding.shard_indices(9, 1, 4) +
                   sharding.shard_indices(9, 2, 4) + sharding.shard_indices(9, 3, 4)) == list(range(9))
