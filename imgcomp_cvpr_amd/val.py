@@ -327,6 +327,8 @@ def main(argv=None):
     p.add_argument('--restore_itr', type=int, default=-1, help='Restore the newest checkpoint with iteration <= this '
                                                                '(val.py:215-217); -1 = newest.')
     p.add_argument('--device', default=None)
+    p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                   help='process group of a multi-rank run (nccl = RCCL, one GPU per rank; gloo lets ranks share a GPU in tests)')
     p.add_argument('--in_flight', type=int, default=4, help='images processed concurrently per GPU, one stream each (1 = one at a time)')
     flags, unknown = p.parse_known_args(argv)
     if unknown:
@@ -335,8 +337,11 @@ def main(argv=None):
     if 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) > 1:
         import torch.distributed as dist
         local = int(os.environ.get('LOCAL_RANK', '0'))
-        torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if flags.backend == 'nccl':
+            torch.cuda.set_device(local)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group('gloo')
     device = flags.device or 'cuda:{}'.format(torch.cuda.current_device())
 
     image_paths, dataset_name = get_image_paths(flags.images)

@@ -1,5 +1,6 @@
 """-m gpu: the whole hot path through the plugin surface (autoencoder / probclass / bits) against the
 oracle, with the val.py wiring (reference code/val.py:81-94)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -450,3 +451,31 @@ def test_images_in_flight_plan_hint(cuda, nets, configs, syn_weights):
     torch.cuda.synchronize()
     for (s0, z0, o0), (s1, z1, o1) in zip(ref, outs):
         assert torch.equal(s0, s1) and torch.equal(z0, z1) and torch.equal(o0, o1)
+
+
+def test_val_two_ranks_share_the_images(cuda, tmp_path):
+    """multi-GPU inference as val.py does it (image-sharded, no data-path collective, one gather of the per-image
+    scalars): two ranks under torch.distributed.run -- on this box's one GPU, so gloo and --device cuda:0 -- write the same
+    measures.csv as one rank."""
+    import subprocess
+    import sys
+    from PIL import Image
+    from imgcomp_cvpr_amd import val, weights as W
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    imgs = tmp_path / 'set5'
+    imgs.mkdir()
+    for i, (h, w) in enumerate(((64, 96), (120, 72), (88, 88), (64, 96), (56, 200))):
+        im = W.synthetic_image((1, 3, h, w), 'natural', seed=40 + i)[0].transpose(1, 2, 0)
+        Image.fromarray(im).save(str(imgs / 'img{:02d}.png'.format(i)))
+    root = tmp_path / 'logs'
+    (root / '0515_1103 ae_configs@cvpr@low pc_configs@cvpr@res_shallow').mkdir(parents=True)
+    val.main([str(root), '0515_1103', str(imgs), '--weights', 'synthetic', '--reset'])
+    out = root / '0515_1103 set5' / 'measures.csv'
+    one = out.read_text()
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29581', '-m', 'imgcomp_cvpr_amd.val', str(root), '0515_1103', str(imgs), '--weights', 'synthetic',
+           '--reset', '--backend', 'gloo', '--device', 'cuda:0', '--in_flight', '2']
+    p = subprocess.run(cmd, cwd=root_dir, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, universal_newlines=True)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert out.read_text() == one and len(one.strip().split('\n')) == 6
