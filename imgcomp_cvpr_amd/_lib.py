@@ -22,6 +22,7 @@ class HipLibraryError(RuntimeError):
 CONV3_FORM_MASK = 0x0f
 CONV3_AUTO, CONV3_DIRECT, CONV3_WINO, CONV3_WINO_WHOLEK, CONV3_WINO_WHOLEK_PW = 0, 1, 2, 3, 4
 CONV3_WINO_KSPLIT, CONV3_WINO_T16, CONV3_WINO_SEG1, CONV3_WINO_SEG2, CONV3_WINO_SEG3 = 5, 6, 7, 8, 9
+CONV3_WINO_PAIR = 10
 CONV3_LEAVE_IDLE_CUS = 0x10
 CONV3_NO_XCD_RUNS = 0x20
 CONV3_PACKED_TRANSFORM = 0x40

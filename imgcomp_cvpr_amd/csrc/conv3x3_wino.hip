@@ -893,6 +893,9 @@ static WinoPlan wino_plan(long long groups, bool even_w, int flags) {
         case IC_CONV3_WINO_SEG1: case IC_CONV3_WINO_SEG2: case IC_CONV3_WINO_SEG3:
             if (even_w) { p.seg = groups; p.seg_nb = form - IC_CONV3_WINO_SEG1 + 1; } else p.whole = groups;
             return p;
+        case IC_CONV3_WINO_PAIR:
+            if (even_w) { p.seg = groups; p.seg_nb = -1; } else p.whole = groups;      // seg_nb -1: tile-pair jobs (conv3x3_wino_tp.hip)
+            return p;
         default: break;
     }
     // automatic: the full rounds of 256 tile groups run whole-K; the remainder r takes the cheapest of {whole-K, K-split,
@@ -926,7 +929,8 @@ extern "C" long long ic_wino3x3_c128_workgroups(int N, int H, int W, int flags) 
     if (N <= 0 || H <= 0 || W <= 0) return 0;
     const WinoPlan p = wino_plan((long long)N * ic_cdiv(H, 4) * ic_cdiv(W, 32), (W & 1) == 0, flags);
     long long cus = p.whole + 4 * p.ksplit;                          // one 512-register work-group per CU
-    if (p.seg > 0) {
+    if (p.seg > 0 && p.seg_nb < 0) cus += 2 * p.seg;                 // tile-pair jobs: 4 work-groups per group, two per CU
+    else if (p.seg > 0) {
         const long long wgs = 2 * ((2 * p.seg + p.seg_nb - 1) / p.seg_nb);
         cus += p.seg_nb > 1 ? wgs : (wgs + 1) / 2;                   // NB = 1: two work-groups share a CU
     }
@@ -972,7 +976,7 @@ extern "C" int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed,
     }
     if (p.seg > 0) {
         a.g0 = (int)g0; a.ngroups = (int)p.seg;
-        const int rc = icx_wino_tn_launch(a, p.seg_nb, (flags & IC_CONV3_PACKED_TRANSFORM) ? 0 : 1, st);
+        const int rc = p.seg_nb < 0 ? icx_wino_tp_launch(a, st) : icx_wino_tn_launch(a, p.seg_nb, (flags & IC_CONV3_PACKED_TRANSFORM) ? 0 : 1, st);
         if (rc) return rc;
         g0 += p.seg;
     }

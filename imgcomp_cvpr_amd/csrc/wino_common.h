@@ -64,6 +64,8 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
 
 // conv3x3_wino_tn.hip: launches the NB-segment kernel over tile groups [a.g0, a.g0 + a.ngroups); nb in {1, 2, 3}
 int icx_wino_tn_launch(const WnArgs& a, int nb, int scalar_transform, hipStream_t st);
+// conv3x3_wino_tp.hip: tile-pair / position-split jobs over tile groups [a.g0, a.g0 + a.ngroups), two work-groups per CU
+int icx_wino_tp_launch(const WnArgs& a, hipStream_t st);
 // conv3x3_wino_stack.hip: does the shape fit one resident round of nb-segment jobs / launch the persistent stack kernel
 // (fills the geometry reciprocals, zeroes the flags on the stream first)
 bool icx_wino_stack_fits(int N, int H, int W, int nb, int nlayers);

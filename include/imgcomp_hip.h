@@ -55,6 +55,8 @@ typedef void* ic_stream_t;
 #define IC_CONV3_WINO_SEG1        0x07   /* 16 channels x NB segments of 16 tiles per wave, NB = 1 / 2 / 3 (even widths) */
 #define IC_CONV3_WINO_SEG2        0x08
 #define IC_CONV3_WINO_SEG3        0x09
+#define IC_CONV3_WINO_PAIR        0x0a   /* tile group x 32 channels per work-group, waves split the 16 positions, two work-groups per CU
+                                            (even widths; conv3x3_wino_tp.hip).  ic_wino3x3_c128_plan reports it as segment jobs with nb = -1 */
 /* partly filled rounds stay one-work-group-per-CU and the CUs beyond the tile groups stay free: a caller's independent
  * branch runs there on a CU-range stream (ic_stream_create_cu_range; imgcomp_cvpr_amd/streams.py) */
 #define IC_CONV3_LEAVE_IDLE_CUS   0x10

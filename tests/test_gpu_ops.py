@@ -166,7 +166,7 @@ def test_conv3x3_c128_mfma(cuda, variant, N, H, W):
         assert_close(y, ref, 'conv3x3 mfma variant {} relu {} nres {}'.format(variant, relu, len(res)))
 
 
-@pytest.mark.parametrize('shape', ['auto', 'wholek', 'wholek_pw', 'ksplit', 't16', 'seg1', 'seg2', 'seg3', 'seg3_pk'])
+@pytest.mark.parametrize('shape', ['auto', 'wholek', 'wholek_pw', 'ksplit', 't16', 'seg1', 'seg2', 'seg3', 'seg3_pk', 'pair'])
 @pytest.mark.parametrize('N,H,W', [(1, 16, 64), (2, 13, 21), (1, 7, 5), (1, 40, 72), (3, 10, 34)])
 def test_conv3x3_c128_winograd(cuda, shape, N, H, W):
     """the Winograd F(2x2,3x3) form of the same layer: interior and border groups, odd sizes, ReLU / residuals,
@@ -186,7 +186,7 @@ def test_conv3x3_c128_winograd(cuda, shape, N, H, W):
     # forms fall back to whole-K there, which the library does by itself)
     flags = {'auto': 0, 'wholek': L.CONV3_WINO_WHOLEK, 'wholek_pw': L.CONV3_WINO_WHOLEK_PW, 'ksplit': L.CONV3_WINO_KSPLIT,
              't16': L.CONV3_WINO_T16, 'seg1': L.CONV3_WINO_SEG1, 'seg2': L.CONV3_WINO_SEG2, 'seg3': L.CONV3_WINO_SEG3,
-             'seg3_pk': L.CONV3_WINO_SEG3 | L.CONV3_PACKED_TRANSFORM}[shape]
+             'seg3_pk': L.CONV3_WINO_SEG3 | L.CONV3_PACKED_TRANSFORM, 'pair': L.CONV3_WINO_PAIR}[shape]
     for relu, res in ((1, ()), (0, (r1d,)), (0, (r1d, r2d))):
         y = torch.full((N, 128, H, W), float('nan'), device=cuda)
         L.check(L.lib.ic_wino3x3_c128_bn_act_f32(
@@ -415,7 +415,7 @@ def test_conv3x3_c128_forms_agree_on_random_shapes(cuda):
              [(int(rs.randint(1, 4)), int(rs.randint(1, 70)), int(rs.randint(1, 100))) for _ in range(17)]
     forms = (L.CONV3_DIRECT, L.CONV3_WINO_WHOLEK, L.CONV3_WINO_KSPLIT, L.CONV3_WINO_WHOLEK_PW, L.CONV3_WINO_T16,
              L.CONV3_WINO_SEG1, L.CONV3_WINO_SEG2, L.CONV3_WINO_SEG3, L.CONV3_WINO_SEG3 | L.CONV3_PACKED_TRANSFORM,
-             L.CONV3_WINO_SEG3 | L.CONV3_NO_XCD_RUNS, L.CONV3_AUTO)
+             L.CONV3_WINO_SEG3 | L.CONV3_NO_XCD_RUNS, L.CONV3_WINO_PAIR, L.CONV3_WINO_PAIR | L.CONV3_NO_XCD_RUNS, L.CONV3_AUTO)
     for N, H, W in shapes:
         x = torch.randn((N, 128, H, W), device=cuda)
         r = torch.randn((N, 128, H, W), device=cuda)

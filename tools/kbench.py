@@ -21,7 +21,7 @@ lib = _lib.lib
 SHAPES = {'kodak': (1, 128, 192), 'kodak_p': (1, 192, 128), '256': (1, 64, 64), '256b2': (2, 64, 64), '256b4': (4, 64, 64),
           '256b8': (8, 64, 64), 'train': (32, 32, 32), '4k': (1, 540, 960), '544': (1, 136, 240), 'kodakb2': (2, 128, 192)}
 FORMS = [('auto', 0), ('leave_idle', _lib.CONV3_LEAVE_IDLE_CUS), ('wholek', _lib.CONV3_WINO_WHOLEK), ('ksplit', _lib.CONV3_WINO_KSPLIT),
-         ('t16', _lib.CONV3_WINO_T16), ('seg1', _lib.CONV3_WINO_SEG1), ('seg2', _lib.CONV3_WINO_SEG2), ('seg3', _lib.CONV3_WINO_SEG3),
+         ('t16', _lib.CONV3_WINO_T16), ('seg1', _lib.CONV3_WINO_SEG1), ('seg2', _lib.CONV3_WINO_SEG2), ('seg3', _lib.CONV3_WINO_SEG3), ('pair', _lib.CONV3_WINO_PAIR),
          ('seg3_pk', _lib.CONV3_WINO_SEG3 | _lib.CONV3_PACKED_TRANSFORM), ('seg2_pk', _lib.CONV3_WINO_SEG2 | _lib.CONV3_PACKED_TRANSFORM),
          ('seg3_noxcd', _lib.CONV3_WINO_SEG3 | _lib.CONV3_NO_XCD_RUNS), ('direct', _lib.CONV3_DIRECT)]
 
