@@ -285,6 +285,34 @@ class TrainGraph(object):
         return dx
 
     WINOGRAD_WGRAD = True     # 3x3 128 -> 128 filter gradients in the Winograd domain (ic_conv3x3_c128_wgrad_f32)
+    WGRAD_SIDE_STREAM = False  # filter gradients on a second stream beside the data-gradient chain: measured SLOWER (see _wgrad_beside)
+
+    def _wgrad_beside(self, l, x_in, g):
+        """The filter gradient of a layer depends on the layer's input (tape) and on the gradient of its raw output, and nothing
+        in the backward chain depends on IT: it runs on a side stream while the main stream goes on with the data gradient and
+        the next layer's BatchNorm backward.  Both are full-chip launches, so what the overlap buys is the bubbles -- the kernel
+        boundaries of the chain and the BatchNorm reductions' 128 work-groups (one per channel: half the CUs idle).  Same
+        kernels, same operands, same order per gradient buffer: the gradients are bit-identical to the serial order (tests pass
+        with it on).  MEASURED on the MI355X (cfg3 step): 19.7 ms against 16.9 ms serial -- both kernels want every CU whole (512
+        registers per SIMD lane each), so their work-groups interleave on the CUs and the data-gradient chain, which is the
+        critical path, waits behind filter-gradient work-groups.  Off by default."""
+        if not self.WGRAD_SIDE_STREAM:
+            return self._wgrad(l, x_in, g)
+        main = torch.cuda.current_stream(self.dev)
+        if getattr(self, '_wgrad_stream', None) is None:
+            self._wgrad_stream = torch.cuda.Stream(device=self.dev)
+        side = self._wgrad_stream
+        side.wait_stream(main)                       # g is complete
+        with torch.cuda.stream(side):
+            self._wgrad(l, x_in, g)
+        g.record_stream(side)                        # the caching allocator must not hand these blocks out again before
+        x_in.record_stream(side)                     # the side stream is done with them
+        self._wgrad_pending = True
+
+    def _join_wgrad(self):
+        if getattr(self, '_wgrad_pending', False):
+            torch.cuda.current_stream(self.dev).wait_stream(self._wgrad_stream)
+            self._wgrad_pending = False
 
     def _wgrad(self, l, x_in, g):
         N = x_in.shape[0]
@@ -387,7 +415,7 @@ class TrainGraph(object):
             check(lib.ic_bn_backward_apply_f32(ptr(dy), ptr(raw), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(gamma),
                                                ptr(sums), N * H * W * world, ptr(draw), N, Cc, H * W, int(relu), self._st()),
                   'bn backward apply')
-        self._wgrad(l, x, draw)
+        self._wgrad_beside(l, x, draw)
         return self._raw_backward_data(l, draw, add1, add2) if need_dx else None
 
     # ---- residual stack (autoencoder.py:224-234 / :252-262) ----
@@ -711,6 +739,7 @@ class TrainGraph(object):
 
     # ---- data-parallel gradient exchange: three flat buckets, each reduced as soon as it is complete ----
     def _bucket_ready(self, group):
+        self._join_wgrad()                           # the group's filter gradients are complete before anybody reads the bucket
         self.buckets.ready(group)
 
     def _wait_buckets(self):
