@@ -107,6 +107,7 @@ PROTOTYPES = {
     'ic_peer_region_close': (c_int, [c_void_p]),
     'ic_peer_region_destroy': (c_int, [c_void_p]),
     'ic_peer_allreduce_f64': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_uint32, c_void_p, c_void_p]),
+    'ic_peer_allreduce_f64_bounded': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_uint32, c_uint32, c_void_p, c_void_p]),
     'ic_bn_workspace_bytes': (c_size_t, [c_int]),
     'ic_bn_stats_f32': (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p, c_void_p]),
     'ic_bn_train_stats_f32': (c_int, [c_void_p] * 5 + [c_float] * 2 + [c_void_p] * 4 + [c_int] * 3 + [c_void_p, c_void_p]),

@@ -21,6 +21,7 @@
 #define PX_SLOTS 4
 #define PX_MAXN 1024                              // doubles per contribution
 #define PX_FLAG_STRIDE 16                         // one flag per 64-byte line
+#define PX_DEFAULT_SPINS (1u << 22)               // polls of one flag before giving up: a few seconds
 #define PX_DATA_BYTES ((size_t)PX_SLOTS * PX_MAX_WORLD * PX_MAXN * sizeof(double))
 #define PX_FLAG_BYTES ((size_t)PX_SLOTS * PX_MAX_WORLD * PX_FLAG_STRIDE * sizeof(unsigned))
 
@@ -102,13 +103,21 @@ extern "C" int ic_peer_region_destroy(void* region) { return region ? (int)hipFr
 
 // vals (device, n <= ic_peer_max_values() doubles): in place -> sum over the ranks.  regions_host: `world` pointers, every
 // rank's region as mapped in this process (regions_host[rank] = the own one).  seq: 1, 2, 3, ... the same on every rank.
-// status: device int, set to 1 on a time-out (the values are then left as they were).
-extern "C" int ic_peer_allreduce_f64(double* vals, int n, void* const* regions_host, int rank, int world, unsigned seq,
-                                     int* status, ic_stream_t stream) {
-    IC_CHECK_ARG(vals && regions_host && status && n > 0 && world > 0 && rank >= 0 && rank < world && seq != 0u);
+// spin_limit: polls of a peer's flag before the exchange gives up (0 = the default, about a second).
+// status: device int (required), set to 1 on a time-out (the values are then left as they were).
+extern "C" int ic_peer_allreduce_f64_bounded(double* vals, int n, void* const* regions_host, int rank, int world, unsigned seq,
+                                             unsigned spin_limit, int* status, ic_stream_t stream) {
+    IC_CHECK_ARG(vals && regions_host && n > 0 && world > 0 && rank >= 0 && rank < world && seq != 0u);
+    IC_CHECK_ARG(status != nullptr);                  // the time-out path stores through it
     if (n > PX_MAXN || world > PX_MAX_WORLD) return IC_ERR_UNSUPPORTED;
     PxArgs a{};
-    a.vals = vals; a.rank = rank; a.world = world; a.n = n; a.seq = seq; a.spin_limit = 1u << 20;          // ~ a second of polling a.status = status;
+    a.vals = vals;
+    a.rank = rank;
+    a.world = world;
+    a.n = n;
+    a.seq = seq;
+    a.spin_limit = spin_limit ? spin_limit : PX_DEFAULT_SPINS;
+    a.status = status;
     for (int r = 0; r < world; ++r) {
         IC_CHECK_ARG(regions_host[r] != nullptr);
         a.region[r] = (char*)regions_host[r];
@@ -116,4 +125,8 @@ extern "C" int ic_peer_allreduce_f64(double* vals, int n, void* const* regions_h
     hipLaunchKernelGGL(peer_allreduce_f64_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     IC_LAUNCH_CHECK();
     return IC_OK;
+}
+extern "C" int ic_peer_allreduce_f64(double* vals, int n, void* const* regions_host, int rank, int world, unsigned seq,
+                                     int* status, ic_stream_t stream) {
+    return ic_peer_allreduce_f64_bounded(vals, n, regions_host, rank, world, seq, 0u, status, stream);
 }

@@ -17,8 +17,11 @@ from ._lib import lib, check, ptr
 
 
 class PeerExchange(object):
-    def __init__(self, device, process_group=None):
+    def __init__(self, device, process_group=None, spin_limit=0):
+        """spin_limit: polls of one peer flag before an exchange gives up and raises the status word (0 = the library's default,
+        a few seconds -- longer than any rank-0-only pause train.py does not bracket with a barrier)"""
         import torch.distributed as dist
+        self.spin_limit = int(spin_limit)
         if not (dist.is_available() and dist.is_initialized()):
             raise _lib.HipLibraryError('PeerExchange needs an initialised process group (the handles travel through it)')
         self.pg = process_group
@@ -54,8 +57,9 @@ class PeerExchange(object):
         """t: contiguous float64 device tensor of <= max_values elements; summed over the ranks in place (rank order)."""
         assert t.dtype == torch.float64 and t.is_contiguous() and t.numel() <= self.max_values
         self.seq += 1
-        check(lib.ic_peer_allreduce_f64(ptr(t), t.numel(), self._regions, self.rank, self.world, self.seq & 0xffffffff or 1,
-                                        ptr(self._status), _lib.current_stream(self.dev)), 'ic_peer_allreduce_f64')
+        check(lib.ic_peer_allreduce_f64_bounded(ptr(t), t.numel(), self._regions, self.rank, self.world, self.seq & 0xffffffff or 1,
+                                                self.spin_limit, ptr(self._status), _lib.current_stream(self.dev)),
+              'ic_peer_allreduce_f64')
         return t
 
     def check_status(self):

@@ -244,6 +244,12 @@ def train(ae_config_path, pc_config_path, log_dir_root, loader_fn, max_itr, log_
             hist[-1] = dict(out, **{'test_' + k: v for k, v in res.items()})
             if verbose:
                 print('{: 7d} | test | {}'.format(itr, ' '.join('{}: {:.4f}'.format(k, v) for k, v in res.items())), flush=True)
+        if world > 1 and ((log_dir_root and (itr % save_interval == 0 or itr == last)) or
+                          (log_interval_test > 0 and (itr % log_interval_test == 0 or itr == last))):
+            # rank 0 alone has just saved / evaluated: the others wait here instead of inside the next step's first BatchNorm
+            # exchange, whose bounded spin (sync_bn='p2p', csrc/peer_exchange.hip) would time out behind a long pause
+            import torch.distributed as dist
+            dist.barrier()
         if itr % log_interval == 0:             # reset after all of the above for accurate timings (train.py:268-269)
             t_last, n_last = time.time(), itr
     return tr, hist, log_dir

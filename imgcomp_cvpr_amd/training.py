@@ -649,8 +649,18 @@ class TrainGraph(object):
         return out
 
     # ---- distortion and its gradient as one replayed HIP graph ----
-    GRAPH_LOSS = True        # False: eager torch ops (what the plugin call sites run when the caller composes the loss itself)
-    OVERLAP_LOSS = True      # forward_backward: the graphed distortion on a side stream beside the context model's branch
+    # GRAPH_LOSS: replay the distortion from a captured HIP graph instead of dispatching its ~300 torch kernels eagerly.
+    # OFF since round 4: inside the training loop the replayed graph starts reading STALE intermediates (the previous replay's)
+    # after 5-10 steps -- ms_ssim 1.157 > 1 in profiles/r03_train_line.json was that.  Pinned down with tools/train_hazard.py
+    # and tools/train_hazard_trace.py: the graph's inputs are right (device-side copies taken behind every replay), its outputs
+    # are wrong from step 5 (side stream) / step 10 (main stream) on, deterministically; replayed in isolation afterwards, fully
+    # synchronised, it is still wrong for new inputs and right when the same inputs are replayed twice, i.e. some node consumes a
+    # buffer of the replay before; a device-wide synchronize behind every replay hides it; the same capture replayed 40 times
+    # outside the training loop (tools/distortion_graph_probe.py, host far ahead, consumers on the same / another stream / the
+    # autograd thread / a library kernel) never shows it.  A fault of graph replay in this ROCm build that the loop's launch
+    # pattern triggers, not of the kernels: eager evaluation of the same inputs is right every time.
+    GRAPH_LOSS = False
+    OVERLAP_LOSS = True      # (with GRAPH_LOSS) the graphed distortion on a side stream beside the context model's branch
 
     def _graphed_distortion(self, x):
         key = (tuple(x.shape), self.ae_config.distortion_to_minimize)
@@ -858,6 +868,9 @@ class _GraphedDistortion(object):
         self.x.copy_(x)
         self.xo.copy_(x_out)
         self.graph.replay()
+        if _TRACE is not None:
+            _TRACE.append({'x': self.x.clone(), 'xo': self.xo.clone(), 'src_xo': x_out.clone(),
+                           'outs': {k: v.clone() for k, v in self.outs.items() if v is not None}})
         self.replays = getattr(self, 'replays', 0) + 1
         o = self.outs
         d = _DistortionValues()
@@ -871,6 +884,9 @@ class _GraphedDistortion(object):
         d.mse, d.psnr = o['mse'].clone(), o['psnr'].clone()
         d.ms_ssim = o['ms_ssim'].clone() if o['ms_ssim'] is not None else None
         return d
+
+
+_TRACE = None      # tools/train_hazard_trace.py: a list collects device-side copies of every replay's inputs and outputs
 
 
 class _DistortionValues(object):

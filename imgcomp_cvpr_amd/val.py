@@ -189,8 +189,8 @@ class Fetcher(object):
         with torch.cuda.stream(main):
             sc = pending['scalars']
             otp = {'bpp': float(sc['bpp'])}                                       # .item(): waits for this stream only
-            otp['ms-ssim'] = sc['ms-ssim'] if isinstance(sc['ms-ssim'], float) else metrics.msssim_from_scale_values(sc['ms-ssim'].tolist())
-            otp['psnr'] = sc['psnr'] if isinstance(sc['psnr'], float) else metrics.psnr_from_mse(float(sc['psnr']))
+            otp['ms-ssim'] = metrics.msssim_from_scale_values(sc['ms-ssim'].tolist()) if torch.is_tensor(sc['ms-ssim']) else float(sc['ms-ssim'])
+            otp['psnr'] = metrics.psnr_from_mse(float(sc['psnr'])) if torch.is_tensor(sc['psnr']) else float(sc['psnr'])
             for k, v in pending['arrays'].items():
                 otp[k] = v.cpu().numpy()
         torch.cuda.current_stream(self.device).wait_stream(main)
@@ -214,7 +214,9 @@ class Fetcher(object):
         arrays = {}
         if self.host_metrics:
             x_out_uint8 = x_out_uint8_dev.cpu().numpy()
-            ms, ps = metrics.msssim_nchw_uint8(x_uint8.numpy(), x_out_uint8), metrics.psnr_uint8(x_uint8.numpy(), x_out_uint8)
+            # python floats: collect() tells a finished host value from a device tensor by type (np.float32 is not a float)
+            ms = float(metrics.msssim_nchw_uint8(x_uint8.numpy(), x_out_uint8))
+            ps = float(metrics.psnr_uint8(x_uint8.numpy(), x_out_uint8))
         else:
             # the same float64 computation on the device: 0.5 s of numpy per Kodak image would dwarf the 2.4 ms GPU path
             # (device tensors, nothing waited for here: collect() finishes them on the host)

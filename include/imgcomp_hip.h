@@ -429,6 +429,10 @@ int ic_peer_region_destroy(void* region);
  * status: device int, set to 1 if a peer's flag did not arrive within the spin bound (vals are left unchanged then). */
 int ic_peer_allreduce_f64(double* vals, int n, void* const* regions_host, int rank, int world, unsigned seq, int* status,
                           ic_stream_t stream);
+/* the same with an explicit bound on the polls of one peer flag (0 = the default, a few seconds): tests force the time-out
+ * path with a small bound.  status must not be NULL (IC_ERR_ARG): the time-out path stores through it. */
+int ic_peer_allreduce_f64_bounded(double* vals, int n, void* const* regions_host, int rank, int world, unsigned seq,
+                                  unsigned spin_limit, int* status, ic_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -202,3 +202,40 @@ def train_loss(x_uint8, weights, ae_cfg, pc_cfg, dtype=torch.float64):
     comps = {'d_loss_scaled': d_loss, 'pc_loss': pc_loss, 'reg': reg, 'H_real': H_real, 'H_mask': H_mask,
              'x_out': x_out, 'symbols': symbols, 'bc': bc, 'heatmap': hm, 'z': z, 'qbar': qbar}
     return total, comps, p
+
+
+def train_steps(x_uint8, weights, ae_cfg, pc_cfg, steps, dtype=torch.float64):
+    """`steps` iterations of the reference's training loop on one fixed batch, float64 throughout:
+      code/train.py:339-349      get_train_op: two tf.train.AdamOptimizer (AE variables with the AE config's lr, context model
+                                 with its own), one train_op
+      code/training_helpers.py:38-48   Adam with TF's defaults (beta1 0.9, beta2 0.999, epsilon 1e-8)
+    tf.train.AdamOptimizer: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t); m, v moving averages; var -= lr_t * m / (sqrt(v) + eps).
+    The learning rates are the configs' lr_initial (the staircase decay does not move inside a handful of steps).
+    -> (list of per-step dicts of floats, dict name -> final float64 numpy array).  The moving averages of BatchNorm play no
+    part in a training-mode forward (batch statistics), so they are carried through unchanged."""
+    b1, b2, eps = 0.9, 0.999, 1e-8
+    cur = {k: np.asarray(v, dtype=np.float64).copy() for k, v in weights.items()}
+    m = {k: np.zeros_like(v) for k, v in cur.items()}
+    v_ = {k: np.zeros_like(v) for k, v in cur.items()}
+    hist = []
+    for t in range(1, steps + 1):
+        total, comps, p = train_loss(x_uint8, cur, ae_cfg, pc_cfg, dtype)
+        total.backward()
+        K = float(ae_cfg['K_ms_ssim'])
+        comps = {k_: (v.detach() if torch.is_tensor(v) else v) for k_, v in comps.items()}
+        hist.append({'d_loss_scaled': float(comps['d_loss_scaled']), 'ms_ssim': 1.0 - float(comps['d_loss_scaled']) / K,
+                     'pc_loss': float(comps['pc_loss']), 'H_real': float(comps['H_real']), 'H_mask': float(comps['H_mask']),
+                     'bpp': float(comps['bc'].sum()) / (comps['x_out'].shape[0] * comps['x_out'].shape[2] * comps['x_out'].shape[3])})
+        for k, t_ in p.items():
+            if t_.grad is None:
+                continue
+            is_pc = k.startswith('probclass3d/')
+            if (is_pc and not ae_cfg.get('train_probclass', True)) or (not is_pc and not ae_cfg.get('train_autoencoder', True)):
+                continue
+            lr = float(pc_cfg['lr_initial'] if is_pc else ae_cfg['lr_initial'])
+            g = t_.grad.detach().numpy().astype(np.float64)
+            m[k] = b1 * m[k] + (1 - b1) * g
+            v_[k] = b2 * v_[k] + (1 - b2) * g * g
+            lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+            cur[k] = cur[k] - lr_t * m[k] / (np.sqrt(v_[k]) + eps)
+    return hist, cur

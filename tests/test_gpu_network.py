@@ -286,6 +286,17 @@ def test_val_entry_point(cuda, tmp_path, configs, syn_weights):
         val.main([str(root), '0515_1103', str(imgs), '--weights', 'synthetic', '--reset', '--in_flight', str(n)])
         rows_by_mode[n] = (out / 'measures.csv').read_text()
     assert rows_by_mode[1] == rows_by_mode[3] and len(rows_by_mode[1].strip().split('\n')) == 8
+    # --host_metrics: MS-SSIM / PSNR in numpy on the host as the reference computes them (val.py:96-108); same rows as the
+    # device metrics to the printed precision of a float32-valued metric
+    val.main([str(root), '0515_1103', str(imgs), '--weights', 'synthetic', '--reset', '--host_metrics'])
+    host_rows = (out / 'measures.csv').read_text().strip().split('\n')
+    dev_rows = rows_by_mode[1].strip().split('\n')
+    assert len(host_rows) == len(dev_rows) == 8
+    for hr, dr in zip(host_rows[1:], dev_rows[1:]):
+        hn, hb, hm, hp = hr.split(',')
+        dn, db, dm, dp = dr.split(',')
+        assert hn == dn and hb == db
+        assert abs(float(hm) - float(dm)) < 1e-5 and abs(float(hp) - float(dp)) < 1e-3
     # --real_bpp leg on a small image: arithmetic-coded size vs theoretical vs loss (val.py:163-174)
     ae_cfg, pc_cfg = configs
     f = val.Fetcher(ae_cfg, pc_cfg, syn_weights, cuda)

@@ -286,6 +286,85 @@ def test_two_steps_reduce_loss(cuda):
     assert all(np.isfinite(losses))
 
 
+def _param_digest(tr):
+    import hashlib
+    h = hashlib.sha1()
+    for g in ('pc', 'dec', 'enc'):
+        h.update(tr.graph.flat_params[g].detach().cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize('sync_between_steps', [False, True])
+def test_twenty_ms_ssim_steps_range_identity_determinism(cuda, sync_between_steps):
+    """the multi-step gate of the training loop (train.py:216-266 runs thousands of steps): 20 optimiser steps of cfg3 (cvpr/med,
+    32 crops of 128 x 128, MS-SSIM distortion) on one fixed batch, as `bench.py --mode train` issues them (nothing between the
+    steps) and with a device-wide synchronize between them.  Every step: 0 < MS-SSIM <= 1 (Cauchy-Schwarz; round 3 printed 1.157),
+    d_loss_scaled == K (1 - MS-SSIM) (train.py:379-390), the loss goes down, and the trajectory -- every step's scalars and the
+    variables after the last step, bit for bit -- repeats in a second fresh run and does not depend on the synchronisation."""
+    from imgcomp_cvpr_amd import training, config_parser as cp, weights as W
+    ae, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'med'))
+    pc, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
+    assert ae.distortion_to_minimize == 'ms_ssim'
+    x = dev(W.synthetic_image((32, 3, 128, 128), 'natural', 0), cuda)
+    K = float(ae.K_ms_ssim)
+
+    def run(sync):
+        tr = training.Trainer(ae, pc, W.synthetic_weights(ae, pc), cuda, num_itr_per_epoch=1000)
+        rows = []
+        for _ in range(20):
+            rows.append(tr.step(x))
+            if sync:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return rows, _param_digest(tr)
+    rows, digest = run(sync_between_steps)
+    for i, r in enumerate(rows):
+        assert 0.0 < r['ms_ssim'] <= 1.0, 'step {}: MS-SSIM {} outside (0, 1]'.format(i, r['ms_ssim'])
+        assert abs(r['d_loss_scaled'] - K * (1.0 - r['ms_ssim'])) <= 2e-3 + 1e-6 * K, (i, r)
+        assert all(np.isfinite(v) for v in r.values()), (i, r)
+    ms = [r['ms_ssim'] for r in rows]
+    assert ms[-1] > ms[0] + 0.3, 'twenty Adam steps on one batch must raise MS-SSIM: {}'.format(ms)
+    rows2, digest2 = run(sync_between_steps)
+    assert rows == rows2 and digest == digest2, 'the trajectory does not repeat'
+    rows3, digest3 = run(not sync_between_steps)
+    assert rows == rows3 and digest == digest3, 'the trajectory depends on host / device synchronisation'
+
+
+def test_three_ms_ssim_steps_follow_the_float64_oracle(cuda):
+    """steps 1-3 of the loop against oracle/train_oracle.train_steps (float64 autograd + float64 TF-Adam): per-step MS-SSIM, rate
+    terms and bpp, and the direction every large tensor has moved in.  Adam's first steps move each coordinate by ~lr whatever
+    the gradient's size, so coordinates whose gradient is at the fp32 noise floor may differ by a whole step between fp32 and
+    fp64: the variables are compared through the cosine between the two displacement vectors, the scalars directly."""
+    from imgcomp_cvpr_amd import training, config_parser as cp, weights as W
+    from oracle import train_oracle as T
+    ae, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'med'))
+    pc, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
+    ae.H_target = 0.5                                     # keep the rate term active on synthetic weights
+    wts = W.synthetic_weights(ae, pc)
+    x = W.synthetic_image((8, 3, 64, 64), 'natural', 3)
+    torch.set_num_threads(16)
+    hist, final = T.train_steps(x, wts, ae.as_dict(), pc.as_dict(), 3)
+    tr = training.Trainer(ae, pc, wts, cuda, num_itr_per_epoch=1000)
+    xd = dev(x, cuda)
+    rows = [tr.step(xd) for _ in range(3)]
+    torch.cuda.synchronize()
+    from tests import util
+    for i, (r, h) in enumerate(zip(rows, hist)):
+        for k, tol in (('ms_ssim', 2e-4), ('H_real', 2e-3), ('H_mask', 2e-3), ('bpp', 2e-3)):
+            e = abs(r[k] - h[k]) / max(1.0, abs(h[k]))
+            util.REPORT.append(('train step {} {}'.format(i + 1, k), abs(r[k] - h[k]), e, tol))
+            assert e <= tol, 'step {} {}: {} vs oracle {}'.format(i + 1, k, r[k], h[k])
+        assert abs(r['d_loss_scaled'] - h['d_loss_scaled']) <= 2e-3 * abs(h['d_loss_scaled']) + 1e-2
+    for n in ('autoencoder/encoder/h2/weights', 'autoencoder/encoder/res_block_enc_2/enc_2_2/conv1/weights',
+              'autoencoder/decoder/res_block_dec_0/dec_0_1/conv1/weights', 'autoencoder/decoder/h12/weights',
+              'probclass3d/logits/res1/conv3d_conv1_mask/weights'):
+        d_dev = tr.graph.params[n].detach().double().cpu().numpy().ravel() - np.asarray(wts[n], np.float64).ravel()
+        d_ref = final[n].ravel() - np.asarray(wts[n], np.float64).ravel()
+        cos = float(d_dev @ d_ref / (np.linalg.norm(d_dev) * np.linalg.norm(d_ref)))
+        util.REPORT.append(('train 3 steps displacement cosine ' + n.replace('autoencoder/', 'ae/'), 1.0 - cos, 1.0 - cos, 2e-2))
+        assert cos > 0.98, '{}: cosine {} between the fp32 and the float64 displacement after 3 steps'.format(n, cos)
+
+
 def test_train_entry_point(cuda, tmp_path):
     """python -m imgcomp_cvpr_amd.train on synthetic crops: runs, logs, writes TF-1 bundle checkpoints + var_names.pkl
     in the reference's ckpts/ layout; val.py restores the newest / a given iteration; --restore continues from them."""
@@ -691,6 +770,90 @@ def test_peer_exchange_two_processes_one_gpu(cuda):
     """csrc/peer_exchange.hip between two PROCESSES (inter-process memory handles, flags, slot rotation, 200 exchanges of varying
     length): both ranks on this box's one GPU -- the protocol and the mapping are the ones used between GPUs, the fabric is not."""
     _run_peer(2, 'gloo', [0, 0], 29551)
+
+
+def test_peer_exchange_timeout_sets_status_not_a_fault(cuda):
+    """the time-out path of csrc/peer_exchange.hip (round 3 shipped it as a null store): rank 0 of a world of two exchanges
+    while rank 1 never calls -- the bounded spin must end, raise the status word, leave the values as they were, and the device
+    must stay usable; the late rank's call with the same sequence number then completes with the right sums.  Both regions live
+    in this process (a region pointer is a region pointer to the kernel).  NULL status is refused by the ABI."""
+    import ctypes
+    from imgcomp_cvpr_amd import _lib as L
+    lib = L.lib
+    regs = (ctypes.c_void_p * 2)()
+    handles = []
+    for r in range(2):
+        own, h = ctypes.c_void_p(), (ctypes.c_ubyte * 64)()
+        L.check(lib.ic_peer_region_create(ctypes.byref(own), h))
+        regs[r] = own
+        handles.append(own)
+    st = L.current_stream(cuda)
+    status = torch.zeros(1, dtype=torch.int32, device=cuda)
+    v0 = torch.arange(5, dtype=torch.float64, device=cuda) + 1.0
+    keep = v0.clone()
+    assert lib.ic_peer_allreduce_f64_bounded(L.ptr(v0), 5, regs, 0, 2, 1, 2000, None, st) != 0, 'NULL status must be refused'
+    assert lib.ic_peer_allreduce_f64(L.ptr(v0), 5, regs, 0, 2, 1, None, st) != 0
+    L.check(lib.ic_peer_allreduce_f64_bounded(L.ptr(v0), 5, regs, 0, 2, 1, 2000, L.ptr(status), st))
+    torch.cuda.synchronize()                                  # a memory fault would surface here
+    assert int(status.item()) == 1, 'the time-out did not raise the status word'
+    assert torch.equal(v0, keep), 'a timed-out exchange must leave the local values unchanged'
+    # the late rank: rank 0's contribution and flag for sequence 1 are in its region already
+    status.zero_()
+    v1 = torch.arange(5, dtype=torch.float64, device=cuda) * 10.0
+    L.check(lib.ic_peer_allreduce_f64_bounded(L.ptr(v1), 5, regs, 1, 2, 1, 2000, L.ptr(status), st))
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    assert torch.equal(v1, keep + torch.arange(5, dtype=torch.float64, device=cuda) * 10.0)
+    for h in handles:
+        lib.ic_peer_region_destroy(h)
+
+
+def _peer_timeout_worker(rank, world, port, device_index, out_q):
+    import torch.distributed as dist
+    from imgcomp_cvpr_amd import peer, _lib as L
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(device_index)
+    dev_ = torch.device('cuda', device_index)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        px = peer.PeerExchange(dev_, spin_limit=5000)
+        t = torch.ones(8, dtype=torch.float64, device=dev_) * (rank + 1)
+        px.allreduce_f64(t)                                   # exchange 1: both ranks
+        px.check_status()
+        raised = None
+        if rank == 0:
+            u = torch.ones(8, dtype=torch.float64, device=dev_)
+            px.allreduce_f64(u)                               # exchange 2: rank 1 never arrives
+            try:
+                px.check_status()
+                raised = False
+            except L.HipLibraryError:
+                raised = True
+            ok = raised and bool(torch.equal(u, torch.ones(8, dtype=torch.float64, device=dev_)))
+        else:
+            ok = True
+        out_q.put((rank, ok and bool(torch.equal(t.cpu(), torch.full((8,), 3.0, dtype=torch.float64)))))
+        dist.barrier()
+        px.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_exchange_missing_rank_raises_in_check_status(cuda):
+    """PeerExchange between two processes on this GPU: one rank skips an exchange -> the other's check_status() raises
+    HipLibraryError (peer.py:61-64), no GPU fault, and the process group is still usable for the closing barrier."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_peer_timeout_worker, args=(r, 2, 29557, 0, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p_ in procs:
+        p_.join(timeout=120)
+        assert p_.exitcode == 0
+    assert res == {0: True, 1: True}, res
 
 
 def test_peer_exchange_between_gpus(cuda):

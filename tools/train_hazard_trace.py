@@ -1,0 +1,36 @@
+"""overlap-mode trajectory without syncs; device-side copies of the distortion graph's inputs and outputs per step, checked afterwards"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch
+from imgcomp_cvpr_amd import config_parser as cp, weights as W, training
+
+dev = torch.device('cuda', 0)
+ae_cfg, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'med'))
+pc_cfg, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
+wts = W.synthetic_weights(ae_cfg, pc_cfg)
+tr = training.Trainer(ae_cfg, pc_cfg, wts, dev, num_itr_per_epoch=1000)
+tr.graph.GRAPH_LOSS = True          # the arrangement under investigation (off by default since round 4)
+x = torch.as_tensor(W.synthetic_image((32, 3, 128, 128), 'natural', seed=0)).float().to(dev)
+training._TRACE = []
+outs = [tr.step(x) for _ in range(12)]
+torch.cuda.synchronize()
+tr_ = training._TRACE
+training._TRACE = None
+for i, (t, o) in enumerate(zip(tr_, outs)):
+    d = training.Distortions(ae_cfg, t['x'], t['xo'].detach().requires_grad_(True), is_training=True)
+    xo2 = t['xo'].detach().requires_grad_(True)
+    d2 = training.Distortions(ae_cfg, t['x'], xo2, is_training=True)
+    g2, = torch.autograd.grad(d2.d_loss_scaled, xo2)
+    print('step {:2d} reported {:.6f} | graph-out {:.6f} eager-on-graph-inputs {:.6f} | x ok {} xo==src {} xo range [{:.1f},{:.1f}] | grad equal {} maxdiff {:.3e}'.format(
+        i, o['ms_ssim'], float(t['outs']['ms_ssim']), float(d2.ms_ssim), bool(torch.equal(t['x'], x)), bool(torch.equal(t['xo'], t['src_xo'])),
+        float(t['xo'].min()), float(t['xo'].max()), bool(torch.equal(g2, t['outs']['grad'])), float((g2 - t['outs']['grad']).abs().max())), flush=True)
+# is the graph persistently broken?  replay it in isolation, fully synchronised, on step 0's inputs
+gd = tr.graph._graphed_distortion(x)
+torch.cuda.synchronize()
+d = gd.launch(tr_[0]['x'], tr_[0]['xo'])
+torch.cuda.synchronize()
+print('isolated replay on step-0 inputs: ms_ssim {:.6f} (step 0 had {:.6f}); grad equal {}'.format(
+    float(d.ms_ssim), float(tr_[0]['outs']['ms_ssim']), bool(torch.equal(d.grad, tr_[0]['outs']['grad']))))
+d = gd.launch(tr_[0]['x'], tr_[0]['xo'])
+torch.cuda.synchronize()
+print('again: ms_ssim {:.6f}'.format(float(d.ms_ssim)))
