@@ -180,6 +180,10 @@ def main():
                    help='--mode train: weak = 32 crops per GPU; strong = cfg3\'s batch of 32 split over the ranks (train.py:150-153)')
     a = p.parse_args()
 
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` by itself: become the launcher -- the line INTEGRATION.md section 3 prints, one rank per GPU
+        return self_launch(a.gpus)
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', '0'))
@@ -382,6 +386,27 @@ def main():
             traffic_src = 'dropped: {} describes shape {} / 3x3 kernel {}, this run is {} / {}'.format(
                 counters.get('file'), counters.get('input_shape'), counters.get('plan_3x3'), [N, 3, H, Wd], k3)
         wino = lib.ic_conv3x3_c128_pick_algo(N, h4, w4, step_flags) == 1
+        from_profiles = None
+        if counters and k3 in counters.get('kernels', {}) and counters.get('input_shape') == [N, 3, H, Wd]:
+            # the same fractions recomputed from the TRACKED rocprofv3 files alone (no number of this run in them): the launch's
+            # duration with nothing beside it, and in the shipped schedule (duration under the tracer / the concurrency it saw)
+            ke = counters['kernels'][k3]
+            ex_f = enc_l['executed_flop_per_launch']
+
+            def frac_of(us):
+                return round(ex_f / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if us else None
+            from_profiles = {'file': counters.get('file'), 'kernel': k3, 'executed_flop_per_launch': ex_f,
+                             'alone_us': ke.get('avg_us_rocprof'), 'alone_frac': frac_of(ke.get('avg_us_rocprof')),
+                             'work_groups': ke.get('work_groups'),
+                             'alone_frac_of_occupied_cus': (round(frac_of(ke.get('avg_us_rocprof')) * 256.0 / ke['work_groups'], 4)
+                                                            if ke.get('work_groups') and ke['work_groups'] < 256 and ke.get('avg_us_rocprof') else None),
+                             'in_flight_us_under_tracer': ke.get('avg_us_in_flight'), 'concurrency': counters.get('concurrency'),
+                             'in_flight_us_over_concurrency': ke.get('avg_us_over_concurrency'),
+                             'in_flight_frac': frac_of(ke.get('avg_us_over_concurrency')),
+                             'mfma_busy_share': ke.get('mfma_busy_share'),
+                             'note': 'frac = executed FLOPs per launch / duration / 157.3 TFLOP/s with durations from the rocprofv3 kernel '
+                                     'traces under profiles/ (alone: one image at a time; in flight: the shipped schedule under the tracer, '
+                                     'which overlaps streams less than the untraced run `frac` is measured on)'}
         roofline = {'kernel': enc_l['plan']['kernel'] + ' (ic_conv3x3_c128_auto_f32, encoder residual stack, in-step)',
                     'algorithm': 'winograd F(2x2,3x3)' if wino else 'direct', 'bound': 'mfma',
                     'achieved': enc_l['achieved'], 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': enc_l['frac'],
@@ -391,7 +416,7 @@ def main():
                     'note': 'achieved = FLOPs the matrix pipe executes (Winograd: 16/36 of the direct form) / the time in which the chip '
                             'completes one launch of the stack: HIP events around {} stacks in flight, one per stream, as in the step; '
                             '`encoder.alone` = the same launch with nothing beside it (its duration in a kernel trace, on plan.cus of 256 CUs)'.format(n_flight),
-                    'encoder': enc_l, 'decoder': dec_l}
+                    'from_profiles': from_profiles, 'encoder': enc_l, 'decoder': dec_l}
         sym = N * int(ae_cfg.num_chan_bn) * (H // 8) * (Wd // 8)
         roofline_pc = {'kernel': 'context model, 4 masked conv3d layers + cross-entropy (ic_pc_bitcost_f32), standalone',
                        'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': PEAK_F32_MFMA_TFLOPS,
@@ -439,6 +464,11 @@ def main():
         extra['shapes'] = shapes
         if a.pipelined:
             extra['in_flight_sweep'] = pipelined_section(torch, dev, a, N, H, Wd, pipe)
+        if world == 1:
+            try:
+                extra['train'] = train_object(torch, dist, dev)
+            except Exception as ex:                                    # informational in this line; --mode train is the contract form
+                extra['train'] = {'error': str(ex)[:300]}
 
     # ---- CPU baseline: the oracle on the host cores (rank 0, N == 1 only) ----
     cpu = None
@@ -494,6 +524,24 @@ def main():
     if world > 1:
         dist.barrier()                 # rank 0 is still timing the stage split / dominant kernel: leave together
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """re-run this command line under torch.distributed.run: one process per GPU on this node, rendezvous on 127.0.0.1 (the
+    container's host name may not resolve), a free port.  The ranks' output is this process's output; returns their exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf inter-process handles (RCCL, peer-mapped BatchNorm exchange)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc:
+        sys.exit(rc)
+    return rc
 
 
 def edge_layer_table(torch, lib, _lib, W, ae, ae_cfg, x, qhard, stack_out_enc, stack_out_dec, timed, st, N, H, Wd):
@@ -634,31 +682,13 @@ def train_main(a, dev, rank, world):
     batch of 32 split over the ranks, what train.py does with --batch_size 32 (reference train.py:150-153 feeds one batch)."""
     import torch
     import torch.distributed as dist
-    from imgcomp_cvpr_amd import config_parser as cp, weights as W, training
-    ae_cfg, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'med'))
-    pc_cfg, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
-    wts = W.synthetic_weights(ae_cfg, pc_cfg)
     GLOBAL, H, Wd = 32, 128, 128
     if a.scaling == 'strong':
         assert GLOBAL % world == 0, 'strong scaling splits a batch of 32: --gpus must divide it'
         N = GLOBAL // world
     else:
         N = GLOBAL
-    tr = training.Trainer(ae_cfg, pc_cfg, wts, dev, num_itr_per_epoch=1000)
-    x = torch.as_tensor(W.synthetic_image((N, 3, H, Wd), 'natural', seed=rank)).float().to(dev)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-    for _ in range(a.warmup):
-        tr.step(x)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = tr.step(x)
-    barrier()
-    elapsed = max_over_ranks(torch, dist, time.perf_counter() - t0, dev, world, a.backend)
+    elapsed, out, tr = train_steps_timed(torch, dist, dev, rank, world, N, H, Wd, a.steps, a.warmup, a.backend)
     if rank == 0:
         print(json.dumps({
             'metric': 'training images/s (cfg3: cvpr/med + res_shallow, 128x128 crops, {})'.format(
@@ -675,6 +705,47 @@ def train_main(a, dev, rank, world):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def train_steps_timed(torch, dist, dev, rank, world, N, H, Wd, steps, warmup, backend='nccl'):
+    """`warmup` + `steps` cfg3 training steps on one fixed synthetic batch of N crops per rank, timed like the contract's region
+    (barrier + synchronize on both sides, max over the ranks) -> (seconds for `steps`, the last step's scalars, the Trainer)"""
+    from imgcomp_cvpr_amd import config_parser as cp, weights as W, training
+    ae_cfg, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'med'))
+    pc_cfg, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
+    tr = training.Trainer(ae_cfg, pc_cfg, W.synthetic_weights(ae_cfg, pc_cfg), dev, num_itr_per_epoch=1000)
+    x = torch.as_tensor(W.synthetic_image((N, 3, H, Wd), 'natural', seed=rank)).float().to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+    out = None
+    for _ in range(warmup):
+        out = tr.step(x)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = tr.step(x)
+    barrier()
+    return max_over_ranks(torch, dist, time.perf_counter() - t0, dev, world, backend), out, tr
+
+
+def train_object(torch, dist, dev, steps=12, warmup=4):
+    """the N = 1 inference line's `train` object: BASELINE configs[2] (cfg3) on this GPU -- images/s, ms per step and the last
+    step's loss terms (MS-SSIM must lie in (0, 1]; d_loss_scaled = K (1 - MS-SSIM)), so that the driver's BENCH file carries a
+    training number too.  `python bench.py --mode train` prints the same measurement as a full contract line."""
+    elapsed, out, tr = train_steps_timed(torch, dist, dev, 0, 1, 32, 128, 128, steps, warmup)
+    K = float(tr.graph.ae_config.K_ms_ssim)
+    ent = {'workload': 'BASELINE configs[2]: one training step, ae_configs/cvpr/med + pc_configs/cvpr/res_shallow, 32x3x128x128 crops, '
+                       'MS-SSIM loss, two Adam optimisers; one fixed synthetic batch',
+           'value': round(32 * steps / elapsed, 2), 'unit': 'img/s', 'ms_per_step': round(elapsed / steps * 1e3, 3),
+           'steps': steps, 'warmup': warmup, 'last_step': {k: round(float(v), 5) for k, v in out.items()},
+           'checks': {'ms_ssim_in_unit_interval': bool(0.0 < out['ms_ssim'] <= 1.0),
+                      'd_loss_is_K_times_one_minus_ms_ssim': bool(abs(out['d_loss_scaled'] - K * (1.0 - out['ms_ssim'])) < 2e-3 + 1e-6 * K)}}
+    del tr
+    torch.cuda.empty_cache()
+    return ent
 
 
 if __name__ == '__main__':

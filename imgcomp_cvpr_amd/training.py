@@ -936,6 +936,7 @@ class TFAdam(object):
     """tf.train.AdamOptimizer (train.py:339-349 via training_helpers.py:38-48): beta1 0.9, beta2 0.999, eps 1e-8,
     lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t); var -= lr_t * m / (sqrt(v) + eps)  (epsilon outside the bias
     correction, unlike torch.optim.Adam)."""
+    kind = 'ADAM'
 
     def __init__(self, params, grads, lr, beta1=0.9, beta2=0.999, eps=1e-8, flat=None):
         """flat: [(flat_params, flat_grads), ...] -- buffers that params / grads are views of, in one common layout (TrainGraph's
@@ -960,6 +961,9 @@ class TFAdam(object):
             self.v = [torch.zeros_like(p) for p in self.params]
         self.t = 0
 
+    def slot_tensors(self, params):
+        return [self.m, self.v]
+
     def step(self, lr=None):
         self.t += 1
         lr = self.lr if lr is None else lr
@@ -976,6 +980,70 @@ class TFAdam(object):
         denom = torch._foreach_sqrt(self.v)
         torch._foreach_add_(denom, self.eps)
         torch._foreach_addcdiv_(self.params, self.m, denom, value=-lr_t)
+
+
+class TFGradientDescent(object):
+    """tf.train.GradientDescentOptimizer (training_helpers.py:42-48, optimizer = SGD): var -= lr * grad.  No slots."""
+    kind = 'SGD'
+
+    def __init__(self, params, grads, lr, flat=None):
+        self.lr = lr
+        self.pairs = [(fp, fg) for fp, fg in flat] if flat else list(zip(params, grads))
+        self.t = 0
+
+    def step(self, lr=None):
+        self.t += 1
+        lr = self.lr if lr is None else lr
+        for p_, g_ in self.pairs:
+            p_.add_(g_, alpha=-float(lr))
+
+    def slot_tensors(self, params):
+        return []
+
+
+class TFMomentum(object):
+    """tf.train.MomentumOptimizer(momentum=config.optimizer_momentum, use_nesterov=True) (training_helpers.py:46-47):
+    accum = momentum * accum + grad;  var -= lr * grad + lr * momentum * accum   (TF's Nesterov form of ApplyMomentum)."""
+    kind = 'MOMENTUM'
+
+    def __init__(self, params, grads, lr, momentum=0.9, flat=None):
+        self.lr, self.momentum = lr, float(momentum)
+        self.params = list(params)
+        self.pairs = [(fp, fg) for fp, fg in flat] if flat else list(zip(params, grads))
+        self.acc = [torch.zeros_like(p_) for p_, _ in self.pairs]
+        self.t = 0
+
+    def step(self, lr=None):
+        self.t += 1
+        lr = float(self.lr if lr is None else lr)
+        for (p_, g_), a_ in zip(self.pairs, self.acc):
+            a_.mul_(self.momentum).add_(g_)
+            p_.add_(g_, alpha=-lr).add_(a_, alpha=-lr * self.momentum)
+
+    def _view(self, p_):
+        for (fp, _), a_ in zip(self.pairs, self.acc):
+            off = (p_.data_ptr() - fp.data_ptr()) // 4
+            if p_.data_ptr() >= fp.data_ptr() and 0 <= off < fp.numel():
+                return a_.view(-1)[off:off + p_.numel()].view(p_.shape)
+        raise ValueError('a parameter is not a view of the optimiser\'s buffers')
+
+    def slot_tensors(self, params):
+        """[(checkpoint suffix index, tensors)]: the one slot `momentum` -> `<var>/<optimizer name>`"""
+        return [[self._view(p_) for p_ in params]]
+
+
+def create_optimizer(config, params, grads, flat):
+    """training_helpers.create_optimizer / optimizer_cls (:38-48): config.optimizer in ADAM | SGD | MOMENTUM (Nesterov, momentum =
+    config.optimizer_momentum).  The learning rate arrives per step (create_learning_rate_tensor -> learning_rate())."""
+    kind = str(getattr(config, 'optimizer', 'ADAM'))
+    lr = float(config.lr_initial)
+    if kind == 'ADAM':
+        return TFAdam(params, grads, lr, flat=flat)
+    if kind == 'SGD':
+        return TFGradientDescent(params, grads, lr, flat=flat)
+    if kind == 'MOMENTUM':
+        return TFMomentum(params, grads, lr, momentum=float(config.optimizer_momentum), flat=flat)
+    raise ValueError('Invalid optimizer {} (ADAM, SGD, MOMENTUM)'.format(kind))
 
 
 def get_num_itr_per_epoch(num_images, batch_size, num_crops_per_img):
@@ -1006,10 +1074,12 @@ class Trainer(object):
         ae_names = g.group_names['enc'] + g.group_names['dec']
         pc_names = g.group_names['pc']
         self._ae_names, self._pc_names = ae_names, pc_names
-        self.opt_ae = TFAdam([g.trainable[n] for n in ae_names], [g.grads[n] for n in ae_names], float(ae_config.lr_initial),
-                             flat=[(g.flat_params[k], g.flat_grads[k]) for k in ('enc', 'dec')])
-        self.opt_pc = TFAdam([g.trainable[n] for n in pc_names], [g.grads[n] for n in pc_names], float(pc_config.lr_initial),
-                             flat=[(g.flat_params['pc'], g.flat_grads['pc'])])
+        # get_train_op (train.py:339-349): create_optimizer(ae_config, lr_ae, 'Adam_AE') for the autoencoder's variables,
+        # create_optimizer(pc_config, lr_pc, 'Adam_PC') for the context model's -- each config picks its own optimiser class
+        self.opt_ae = create_optimizer(ae_config, [g.trainable[n] for n in ae_names], [g.grads[n] for n in ae_names],
+                                       flat=[(g.flat_params[k], g.flat_grads[k]) for k in ('enc', 'dec')])
+        self.opt_pc = create_optimizer(pc_config, [g.trainable[n] for n in pc_names], [g.grads[n] for n in pc_names],
+                                       flat=[(g.flat_params['pc'], g.flat_grads['pc'])])
         self.num_itr_per_epoch = num_itr_per_epoch
         self.global_step = 0
 
@@ -1038,15 +1108,36 @@ class Trainer(object):
         if training_state:
             out['global_step'] = np.array(self.global_step, np.int64)
             for opt, tag, names in ((self.opt_ae, 'Adam_AE', self._ae_names), (self.opt_pc, 'Adam_PC', self._pc_names)):
-                for n, m, v in zip(names, opt.m, opt.v):
-                    out['{}/{}'.format(n, tag)] = m.detach().cpu().numpy()
-                    out['{}/{}_1'.format(n, tag)] = v.detach().cpu().numpy()
-                # TF-1.x: `beta1_power` / `beta2_power` at the graph root, uniquified per optimiser in creation order
-                # (get_train_op creates Adam_AE first, train.py:339-349)
-                b1n, b2n = BETA_POWER_NAMES[tag]
-                out[b1n] = np.array(opt.b1 ** opt.t, np.float32)
-                out[b2n] = np.array(opt.b2 ** opt.t, np.float32)
+                # slot variables are named after the optimiser's NAME (`Adam_AE` whatever its class, train.py:341,344), uniquified
+                # `_1` for the second slot: Adam m, v -> `<var>/Adam_AE`, `<var>/Adam_AE_1`; Momentum's one slot -> `<var>/Adam_AE`
+                params = [self.graph.trainable[n] for n in names]
+                for si, tensors in enumerate(opt.slot_tensors(params)):
+                    for n, t_ in zip(names, tensors):
+                        out['{}/{}{}'.format(n, tag, '_1' if si else '')] = t_.detach().cpu().numpy()
+                if opt.kind == 'ADAM':
+                    # TF-1.x: `beta1_power` / `beta2_power` at the graph root, uniquified per optimiser in creation order
+                    # (get_train_op creates Adam_AE first, train.py:339-349).  TF initialises beta1_power to beta1 and multiplies it
+                    # once per update (_finish), so after t updates the checkpoint holds beta ** (t + 1)
+                    b1n, b2n = BETA_POWER_NAMES[tag]
+                    out[b1n] = np.array(opt.b1 ** (opt.t + 1), np.float32)
+                    out[b2n] = np.array(opt.b2 ** (opt.t + 1), np.float32)
         return out
+
+    def _adam_steps_from_checkpoint(self, ckpt, tag, opt):
+        """updates already applied, from the beta powers TF keeps: the checkpoint holds beta ** (t + 1).  beta2_power is preferred
+        (0.999 ** t is a normal float32 until t ~ 87,000; 0.9 ** t goes denormal near t = 830 and reaches zero near 980); beyond
+        what either can resolve the global step counts the updates."""
+        def read(name, legacy):
+            v = ckpt.get(name, ckpt.get(legacy))
+            return float(np.asarray(v).reshape(-1)[0]) if v is not None else None
+        b1n, b2n = BETA_POWER_NAMES[tag]
+        for val, base in ((read(b2n, tag + '/beta2_power'), opt.b2), (read(b1n, tag + '/beta1_power'), opt.b1)):
+            # a NORMAL float32 carries beta ** (t + 1) to 6e-8 relative, i.e. t to 6e-8 / |log beta| << 1: exact
+            if val is not None and 1e-30 < val < 1.0:
+                t = int(round(math.log(val) / math.log(base))) - 1
+                if t >= 0:
+                    return t
+        return self.global_step
 
     def restore_training_state(self, ckpt):
         """global_step, Adam moments and step counts from a checkpoint dict (whatever of it is present): the DECAY schedule
@@ -1056,15 +1147,15 @@ class Trainer(object):
         dev = self.graph.dev
         for opt, tag, names in ((self.opt_ae, 'Adam_AE', self._ae_names), (self.opt_pc, 'Adam_PC', self._pc_names)):
             found = 0
+            slots = opt.slot_tensors([self.graph.trainable[n] for n in names])
             for i, n in enumerate(names):
-                km, kv = '{}/{}'.format(n, tag), '{}/{}_1'.format(n, tag)
-                if km in ckpt and kv in ckpt:
-                    opt.m[i].copy_(torch.as_tensor(np.asarray(ckpt[km]), dtype=torch.float32).to(dev).view_as(opt.m[i]))
-                    opt.v[i].copy_(torch.as_tensor(np.asarray(ckpt[kv]), dtype=torch.float32).to(dev).view_as(opt.v[i]))
+                keys = ['{}/{}{}'.format(n, tag, '_1' if si else '') for si in range(len(slots))]
+                if keys and all(k_ in ckpt for k_ in keys):
+                    for k_, tensors in zip(keys, slots):
+                        tensors[i].copy_(torch.as_tensor(np.asarray(ckpt[k_]), dtype=torch.float32).to(dev).view_as(tensors[i]))
                     found += 1
-            if found:
-                # t from beta1_power = beta1 ** t when present, else the step counter
-                bp = ckpt.get(BETA_POWER_NAMES[tag][0], ckpt.get(tag + '/beta1_power'))     # second form: files written by round-2 builds
-                opt.t = int(round(math.log(float(np.asarray(bp).reshape(-1)[0])) / math.log(opt.b1))) if bp is not None and float(np.asarray(bp).reshape(-1)[0]) > 0 \
-                    else self.global_step
+            if found and opt.kind == 'ADAM':
+                opt.t = self._adam_steps_from_checkpoint(ckpt, tag, opt)
+            elif found:
+                opt.t = self.global_step
         return self.global_step

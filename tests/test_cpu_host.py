@@ -560,3 +560,60 @@ def test_checkpoint_name_filters():
               'Adam_PC/beta2_power', 'beta1_power', 'beta2_power', 'beta1_power_1', 'beta2_power_1'):
         assert T.is_training_state(n), n
     assert not T.is_training_state(w)
+
+
+def test_optimizer_classes_follow_the_config(configs):
+    """training_helpers.optimizer_cls (:42-48): ADAM | SGD | MOMENTUM (use_nesterov=True, momentum = optimizer_momentum).  The update
+    rules on plain tensors against TF's documented ones; an unknown name raises (round 3 trained with Adam whatever the config said)."""
+    import torch
+    from imgcomp_cvpr_amd import training
+    ae_cfg, pc_cfg = configs
+    assert ae_cfg.optimizer == 'ADAM' and pc_cfg.optimizer == 'ADAM' and float(ae_cfg.optimizer_momentum) == 0.9
+
+    class Cfg(object):
+        lr_initial = 0.1
+        optimizer_momentum = 0.9
+    p0, g = torch.tensor([1.0, -2.0, 3.0]), torch.tensor([0.5, -1.0, 0.25])
+    c = Cfg()
+    c.optimizer = 'SGD'
+    p = p0.clone()
+    opt = training.create_optimizer(c, [p], [g], flat=None)
+    assert isinstance(opt, training.TFGradientDescent) and opt.slot_tensors([p]) == []
+    opt.step()
+    assert torch.allclose(p, p0 - 0.1 * g)
+    opt.step(0.01)
+    assert torch.allclose(p, p0 - 0.11 * g)
+    c.optimizer = 'MOMENTUM'
+    p = p0.clone()
+    opt = training.create_optimizer(c, [p], [g], flat=[(p, g)])
+    assert isinstance(opt, training.TFMomentum)
+    acc, ref = torch.zeros(3), p0.clone()
+    for _ in range(3):
+        opt.step()
+        acc = 0.9 * acc + g                                  # ApplyMomentum, use_nesterov
+        ref = ref - 0.1 * g - 0.1 * 0.9 * acc
+    assert torch.allclose(p, ref, atol=1e-6)
+    (slot,), = [opt.slot_tensors([p])]
+    assert torch.allclose(slot[0], acc, atol=1e-6)
+    c.optimizer = 'ADAM'
+    assert isinstance(training.create_optimizer(c, [p0.clone()], [g], flat=None), training.TFAdam)
+    c.optimizer = 'RMSPROP'
+    with pytest.raises(ValueError):
+        training.create_optimizer(c, [p0.clone()], [g], flat=None)
+
+
+def test_adam_step_count_from_tf_beta_powers():
+    """TF-1 Adam keeps beta ** (t + 1) after t updates (beta1_power starts at beta1, _finish multiplies once per update); a
+    step-0 TF checkpoint must restore t = 0, and beta2_power still resolves t where float32 beta1_power has gone to zero."""
+    import math
+    from imgcomp_cvpr_amd import training
+
+    class Opt(object):
+        b1, b2 = 0.9, 0.999
+    tr = training.Trainer.__new__(training.Trainer)
+    tr.global_step = 777
+    for t in (0, 1, 5, 829, 2000, 20000):
+        ck = {'beta1_power': np.array(0.9 ** (t + 1), np.float32), 'beta2_power': np.array(0.999 ** (t + 1), np.float32)}
+        assert tr._adam_steps_from_checkpoint(ck, 'Adam_AE', Opt) == t, t
+    assert tr._adam_steps_from_checkpoint({'beta1_power_1': np.array(0.9 ** 4, np.float32)}, 'Adam_PC', Opt) == 3
+    assert tr._adam_steps_from_checkpoint({}, 'Adam_AE', Opt) == 777                      # no beta powers: the global step

@@ -6,6 +6,7 @@
 mode=$1; tag=$2; shift 2
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
+rm -rf $out            # a pass directory only ever holds its own pass (a round-1 leftover was committed as round 3 once)
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 cd $root

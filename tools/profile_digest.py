@@ -57,15 +57,36 @@ def per_kernel(path):
     return {k: {c: v / len(calls[k]) for c, v in acc[k].items()} for k in acc}, {k: len(v) for k, v in calls.items()}
 
 
-def find(d, suffix, prefix=''):
+def find(d, suffix, prefix=None):
+    """the file `<pass tag>_<suffix>` of pass directory gpurun_out/<d> (tools/profile.sh names every output after its pass:
+    `-o <tag>`).  EXACT name -- round 3 took the first file that ended in the suffix and committed a round-1 leftover
+    (`b_kernel_stats.csv`) under a round-3 name; if several copies exist (rocprofv3 nests per-host directories) the newest wins."""
     dd = os.path.join(G, d)
     if not os.path.isdir(dd):
         return None
-    for root, _, files in os.walk(dd):
-        for fn in sorted(files):
-            if fn.endswith(suffix) and fn.startswith(prefix):
-                return os.path.join(root, fn)
-    return None
+    want = (prefix if prefix is not None else d.replace('prof_', '', 1)) + '_' + suffix
+    hits = [os.path.join(root, fn) for root, _, files in os.walk(dd) for fn in files if fn == want]
+    return max(hits, key=os.path.getmtime) if hits else None
+
+
+def library_symbols():
+    """every kernel base name the shipped library holds (its code objects carry the mangled names as plain bytes)"""
+    so = os.path.join(ROOT, 'imgcomp_cvpr_amd', 'libimgcomp_hip.so')
+    return open(so, 'rb').read() if os.path.exists(so) else None
+
+
+def check_stats_describe_head(path, blob):
+    """refuse a stats table whose dominant kernels are not symbols of the library as built now (a stale profile)"""
+    if blob is None:
+        return
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: -float(r.get('TotalDurationNs') or r.get('Percentage') or 0))
+    ours = [r for r in rows if not re.search(r'at::|rocblas|Cijk_|hipblas|copyBuffer|fillBuffer|elementwise|reduce_kernel|vectorized', r['Name'])]
+    for r in ours[:4]:
+        base = re.split(r'[<(]', r['Name'].replace('void ', ''))[0].strip().split('::')[-1]
+        if base.encode() not in blob:
+            sys.exit('STALE PROFILE: {} lists kernel `{}` (top of the table) which is not in imgcomp_cvpr_amd/libimgcomp_hip.so as built now; '
+                     're-run tools/profile_round.sh'.format(os.path.relpath(path, ROOT), base))
 
 
 def bench_line(d):
@@ -76,9 +97,11 @@ def bench_line(d):
     return json.loads(m[-1]) if m else None
 
 
+BLOB = library_symbols()
 for t in ('bench', 'alone', 'bench1', 'pc', 'train'):
     src = find('prof_' + t, 'kernel_stats.csv')
     if src:
+        check_stats_describe_head(src, BLOB)
         shutil.copy(src, os.path.join(P, '{}_{}_kernel_stats.csv'.format(tag, t)))
     line = bench_line('prof_' + t)
     if line:
