@@ -603,20 +603,24 @@ class TrainGraph(object):
         enc = self.plugin_encode(x)
         x_out = self.plugin_decode(enc.qbar)
         pad_value = self._pad_value() if self.pc_config.use_centers_for_padding else 0.0
-        if self.GRAPH_LOSS and self.OVERLAP_LOSS:
-            # The graph-replayed distortion is ~300 tiny kernels: 2 ms of wall time at 15 % GPU occupancy.  Nothing in the
-            # rate branch depends on it, so it runs on a side stream while the context model's forward, the rate loss and the
-            # context model's backward fill the chip from the main stream; the decoder's backward waits for its gradient.
-            # Same Functions, same kernels, same sums as the single-backward form below -- only the order of enqueueing.
-            gd = self._graphed_distortion(x)
+        hd = self._hip_distortion(x) if (self.HIP_LOSS and cfg.distortion_to_minimize == 'ms_ssim') else None
+        if hd is not None or (self.GRAPH_LOSS and self.OVERLAP_LOSS):
+            # The distortion and its gradient with respect to x_out come from ONE call -- csrc/msssim.hip (16 launches, ~0.1 ms)
+            # or, with GRAPH_LOSS, the replayed torch graph on a side stream -- so the backward is staged by hand: the rate
+            # branch first (its bucket's all-reduce goes out first), then clip / de-normalise + decoder + encoder with the
+            # distortion's gradient fed in.  Same Functions, same kernels, same sums as the single-backward form below.
             main = torch.cuda.current_stream(self.dev)
-            if getattr(self, '_loss_stream', None) is None:
-                # its own hardware queue: streams of equal priority may share one, and a shared queue runs its streams in turn
-                self._loss_stream = torch.cuda.Stream(device=self.dev, priority=-1)
-            side = self._loss_stream
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                d = gd.launch(x, x_out.detach())
+            if hd is not None:
+                d = hd.launch(x, x_out.detach())
+            else:
+                gd = self._graphed_distortion(x)
+                if getattr(self, '_loss_stream', None) is None:
+                    # its own hardware queue: streams of equal priority may share one, and a shared queue runs its streams in turn
+                    self._loss_stream = torch.cuda.Stream(device=self.dev, priority=-1)
+                side = self._loss_stream
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    d = gd.launch(x, x_out.detach())
             bc = self.plugin_bitcost(enc.qbar.detach(), enc.symbols, pad_value)
             zero = torch.zeros((), device=self.dev)
             _, H_real, pc_comps, _ = get_loss(cfg, None, None, zero, bc, enc.heatmap)
@@ -626,7 +630,8 @@ class TrainGraph(object):
             d_bc = grads[0] if grads[0] is not None else torch.zeros_like(bc)
             d_hm = grads[1] if len(grads) > 1 else None
             torch.autograd.backward([bc], [d_bc])                       # context-model backward (its bucket goes out first)
-            main.wait_stream(side)
+            if hd is None:
+                main.wait_stream(side)
             g_qbar, = torch.autograd.grad(x_out, [enc.qbar], d.grad)    # clip / de-normalise + decoder backward
             if d_hm is not None:
                 torch.autograd.backward([enc.qbar, enc.heatmap], [g_qbar, d_hm])
@@ -661,6 +666,20 @@ class TrainGraph(object):
     # pattern triggers, not of the kernels: eager evaluation of the same inputs is right every time.
     GRAPH_LOSS = False
     OVERLAP_LOSS = True      # (with GRAPH_LOSS) the graphed distortion on a side stream beside the context model's branch
+    # HIP_LOSS: the MS-SSIM distortion and its gradient from csrc/msssim.hip (one launch per scale and direction) instead of the
+    # ~300 torch kernels of ms_ssim.py -- no graph, no static buffers, any shape with five scales.  False: torch, eagerly.
+    HIP_LOSS = True
+
+    def _hip_distortion(self, x):
+        """the HIP distortion of this input shape, or None when MS-SSIM is undefined for it (fewer than five scales)"""
+        key = tuple(x.shape)
+        cache = self.__dict__.setdefault('_hip_distortions', {})
+        if key not in cache:
+            try:
+                cache[key] = _HipMsSsimDistortion(self.ae_config, x.shape, self.dev)
+            except NotImplementedError:
+                cache[key] = None
+        return cache[key]
 
     def _graphed_distortion(self, x):
         key = (tuple(x.shape), self.ae_config.distortion_to_minimize)
@@ -674,6 +693,10 @@ class TrainGraph(object):
         dispatched they take the host 5-8 ms during which the GPU idles (rocprofv3 trace of the step: 15 % busy in that section).
         Shapes are static in training, so forward and backward of the distortion are captured ONCE per input shape into a HIP
         graph and replayed: same kernels, same order, same results, no host time."""
+        if self.HIP_LOSS and self.ae_config.distortion_to_minimize == 'ms_ssim':
+            hd = self._hip_distortion(x)
+            if hd is not None:
+                return hd(x, x_out)
         if not self.GRAPH_LOSS:
             return Distortions(self.ae_config, x, x_out, is_training=True)
         return self._graphed_distortion(x)(x, x_out)
@@ -884,6 +907,61 @@ class _GraphedDistortion(object):
         d.mse, d.psnr = o['mse'].clone(), o['psnr'].clone()
         d.ms_ssim = o['ms_ssim'].clone() if o['ms_ssim'] is not None else None
         return d
+
+
+class _HipMsSsimDistortion(object):
+    """Distortions(config, x, x_out, is_training=True) for distortion_to_minimize = ms_ssim (train.py:352-394) and
+    d(d_loss_scaled) / d(x_out), from csrc/msssim.hip: the blur matrices of the shape are made once on the host
+    (ic_msssim_plan_fill) and uploaded; a call is ~16 launches on the current stream, no host synchronisation."""
+
+    def __init__(self, config, shape, device):
+        N, C, H, W = (int(v) for v in shape)
+        nb = int(lib.ic_msssim_plan_bytes(H, W))
+        if nb == 0:
+            raise NotImplementedError('MS-SSIM needs five scales: {} x {} is too small'.format(H, W))
+        host = torch.empty(nb, dtype=torch.uint8)
+        check(lib.ic_msssim_plan_fill(H, W, host.data_ptr(), nb), 'ic_msssim_plan_fill')
+        self.plan = host.to(device)
+        self.ws_bytes = int(lib.ic_msssim_workspace_bytes(N, C, H, W))
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        self.shape, self.K, self.config, self.dev = (N, C, H, W), float(config.K_ms_ssim), config, torch.device(device)
+
+    def launch(self, x, x_out, want_grad=True):
+        """-> values with .ms_ssim, .d_loss_scaled (0-d device tensors) and .grad = d(d_loss_scaled)/d(x_out)"""
+        N, C, H, W = self.shape
+        assert tuple(x.shape) == self.shape and tuple(x_out.shape) == self.shape
+        x, x_out = x.contiguous(), x_out.contiguous()
+        grad = torch.empty_like(x_out) if want_grad else None
+        scal = torch.empty(16, dtype=torch.float32, device=self.dev)
+        check(lib.ic_msssim_loss_grad_f32(ptr(x), ptr(x_out), N, C, H, W, self.K, ptr(self.plan), ptr(grad), ptr(scal), ptr(self.ws),
+                                          self.ws_bytes, _lib.current_stream(self.dev)), 'ic_msssim_loss_grad_f32')
+        d = _DistortionValues()
+        d.ms_ssim, d.d_loss_scaled, d.grad, d.scalars = scal[0], scal[1], grad, scal
+        d.mse = d.psnr = None
+        return d
+
+    def __call__(self, x, x_out):
+        """the autograd form (the plugin call sites compose the loss themselves): d_loss_scaled carries the gradient to x_out"""
+        d = _DistortionValues()
+        d.d_loss_scaled, d.ms_ssim = _HipDistortionFn.apply(self, x, x_out)
+        with torch.no_grad():                      # logged only (train.py:361-366: integer-cast values when not minimised)
+            d.mse = Distortions.get_mse_per_img(x, x_out, True).mean()
+            d.psnr = Distortions.get_psnr_per_image(x, x_out, True).mean()
+        return d
+
+
+class _HipDistortionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hd, x, x_out):
+        v = hd.launch(x, x_out, want_grad=True)
+        ctx.save_for_backward(v.grad)
+        ctx.mark_non_differentiable(v.ms_ssim)
+        return v.d_loss_scaled.clone(), v.ms_ssim.clone()
+
+    @staticmethod
+    def backward(ctx, go, _unused):
+        grad, = ctx.saved_tensors
+        return None, None, grad * go
 
 
 _TRACE = None      # tools/train_hazard_trace.py: a list collects device-side copies of every replay's inputs and outputs

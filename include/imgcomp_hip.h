@@ -434,6 +434,22 @@ int ic_peer_allreduce_f64(double* vals, int n, void* const* regions_host, int ra
 int ic_peer_allreduce_f64_bounded(double* vals, int n, void* const* regions_host, int rank, int world, unsigned seq,
                                   unsigned spin_limit, int* status, ic_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * MS-SSIM training distortion and its gradient (csrc/msssim.hip).  Reference: code/ms_ssim.py:3-186 (5 scales, separable
+ * Gaussian 'VALID' blur with REFLECT pads on small scales, 2x2 box between scales), train.py:352-394
+ * (d_loss_scaled = K_ms_ssim * (1 - MS-SSIM(x, x_out)); TensorFlow derives d / d x_out, here it is written out).
+ * The blur matrices of a shape are computed once on the HOST (ic_msssim_plan_fill -> a plain buffer the caller uploads) and
+ * passed as a device pointer with every call.  IC_ERR_UNSUPPORTED / 0 bytes: an image too small for five scales.
+ * --------------------------------------------------------------------------------------------- */
+size_t ic_msssim_plan_bytes(int H, int W);
+int ic_msssim_plan_fill(int H, int W, void* host_buf, size_t bytes);          /* CPU arithmetic only */
+size_t ic_msssim_workspace_bytes(int N, int C, int H, int W);
+/* x, x_out: (N,C,H,W) float32 in 0..255.  grad_out (N,C,H,W) = d (K (1 - MS-SSIM)) / d x_out (NULL: value only).
+ * scalars_out: 16 device floats: [0] MS-SSIM, [1] K (1 - MS-SSIM), [2..5] cs of scales 0..3, [6] ssim of scale 4,
+ * [8..12] dL/dS_l / positions_l.  Means are reduced in float64 in a fixed order (bit-reproducible). */
+int ic_msssim_loss_grad_f32(const float* x, const float* x_out, int N, int C, int H, int W, float K, const void* plan_dev,
+                            float* grad_out, float* scalars_out, void* workspace, size_t workspace_bytes, ic_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

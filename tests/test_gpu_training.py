@@ -256,6 +256,44 @@ def test_ms_ssim_loss_module(cuda):
     assert rel_err(gb.grad, tb.grad) < 1e-3
 
 
+@pytest.mark.parametrize('shape', [(2, 3, 128, 128), (3, 3, 64, 64), (1, 3, 160, 160), (2, 3, 72, 136), (1, 3, 33, 47), (1, 2, 17, 19)])
+def test_hip_ms_ssim_distortion_value_and_gradient(cuda, shape):
+    """csrc/msssim.hip (ic_msssim_loss_grad_f32) against the oracle's float64 restatement of code/ms_ssim.py under autograd:
+    K (1 - MS-SSIM) and its gradient with respect to the reconstruction, on the training shapes (128 and the config's 160 crops),
+    the small-scale REFLECT pads (64: two scales narrower than the window), non-square, odd sizes (the (0,1) REFLECT pad of
+    the 2x2 box) and the smallest image with five scales.  Two calls are bit-identical (fixed-order float64 means)."""
+    from imgcomp_cvpr_amd import training, config_parser as cp, weights as W
+    from oracle import train_oracle as T
+    ae, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'med'))
+    rs = np.random.RandomState(shape[2])
+    a = (W.synthetic_image((shape[0], 3, shape[2], shape[3]), 'natural', 1)[:, :shape[1]]).astype(np.float64)
+    b = np.clip(a + rs.normal(0, 9, a.shape), 0, 255)
+    tb = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    K = float(ae.K_ms_ssim)
+    ref = K * (1.0 - T.ms_ssim(torch.as_tensor(a).double(), tb))
+    ref.backward()
+    hd = training._HipMsSsimDistortion(ae, shape, cuda)
+    d = hd.launch(dev(a, cuda), dev(b, cuda))
+    d2 = hd.launch(dev(a, cuda), dev(b, cuda))
+    torch.cuda.synchronize()
+    assert torch.equal(d.grad, d2.grad) and torch.equal(d.scalars[:13], d2.scalars[:13])
+    assert 0.0 < float(d.ms_ssim) <= 1.0
+    assert abs(float(d.ms_ssim) - (1.0 - float(ref) / K)) < 1e-5, (float(d.ms_ssim), 1.0 - float(ref) / K)
+    assert abs(float(d.d_loss_scaled) - float(ref)) < 1e-5 * K
+    assert_close(d.grad, tb.grad, 'MS-SSIM distortion gradient {}x{}'.format(shape[2], shape[3]), 1e-3)
+    # the autograd form the plugin call sites use
+    xo = dev(b, cuda).requires_grad_(True)
+    dd = hd(dev(a, cuda), xo)
+    (dd.d_loss_scaled * 2.0).backward()
+    assert torch.equal(xo.grad, d.grad * 2.0) and float(dd.ms_ssim) == float(d.ms_ssim)
+    assert lib_unsupported_below_five_scales()
+
+
+def lib_unsupported_below_five_scales():
+    from imgcomp_cvpr_amd import _lib as L
+    return L.lib.ic_msssim_plan_bytes(16, 16) == 0 and L.lib.ic_msssim_workspace_bytes(1, 3, 16, 64) == 0 and L.lib.ic_msssim_plan_bytes(17, 17) > 0
+
+
 def test_optimizer_and_schedule(cuda):
     from imgcomp_cvpr_amd import training, config_parser as cp
     ae, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'low'))

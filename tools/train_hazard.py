@@ -30,6 +30,7 @@ def trajectory(mode, steps, batch, dev, size=128, sync=True):
     pc_cfg, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
     wts = W.synthetic_weights(ae_cfg, pc_cfg)
     tr = training.Trainer(ae_cfg, pc_cfg, wts, dev, num_itr_per_epoch=1000)
+    tr.graph.HIP_LOSS = mode == 'hip'              # csrc/msssim.hip (the default since round 4)
     tr.graph.GRAPH_LOSS = mode in ('overlap', 'graph')
     tr.graph.OVERLAP_LOSS = mode == 'overlap'
     x = torch.as_tensor(W.synthetic_image((batch, 3, size, size), 'natural', seed=0)).float().to(dev)
@@ -50,7 +51,7 @@ def main():
     p = argparse.ArgumentParser()
     p.add_argument('--steps', type=int, default=15)
     p.add_argument('--batch', type=int, default=32)
-    p.add_argument('--modes', default='overlap,graph,eager')
+    p.add_argument('--modes', default='hip,overlap,graph,eager')
     p.add_argument('--nosync', action='store_true', help='no synchronize / read-back between the steps (bench.py --mode train)')
     a = p.parse_args()
     dev = torch.device('cuda', 0)

@@ -9,6 +9,7 @@ ae_cfg, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'med'))
 pc_cfg, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
 wts = W.synthetic_weights(ae_cfg, pc_cfg)
 tr = training.Trainer(ae_cfg, pc_cfg, wts, dev, num_itr_per_epoch=1000)
+tr.graph.HIP_LOSS = False
 tr.graph.GRAPH_LOSS = True          # the arrangement under investigation (off by default since round 4)
 x = torch.as_tensor(W.synthetic_image((32, 3, 128, 128), 'natural', seed=0)).float().to(dev)
 training._TRACE = []
