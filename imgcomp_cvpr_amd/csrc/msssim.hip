@@ -263,6 +263,7 @@ __global__ __launch_bounds__(256) void msssim_finish_kernel(const MsFinArgs g) {
         for (int l = 0; l < MS_LEVELS; ++l) ms *= pow(S[l], g.weight[l]);        // a negative mean gives NaN, as tf.pow / torch do
         g.scalars[0] = (float)ms;
         g.scalars[1] = (float)((double)g.K * (1.0 - ms));
+        g.scalars[7] = 0.f; g.scalars[13] = 0.f; g.scalars[14] = 0.f; g.scalars[15] = 0.f;
         for (int l = 0; l < MS_LEVELS; ++l) {
             g.scalars[2 + l] = (float)S[l];
             g.scalars[8 + l] = (float)(-(double)g.K * g.weight[l] * ms / S[l] / g.count[l]);
