@@ -510,6 +510,10 @@ def main():
             'value': round(value, 3), 'unit': 'Mpix/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(elapsed / a.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            # rounds 1-2 quoted `value` one image at a time; since round 3 it is the throughput of the evaluation loop with
+            # several independent images in flight (still one image per step) -- the latency-style figure is `one_image_at_a_time`
+            'value_definition': ('throughput, {} independent batch-1 images in flight on one GPU; NOT comparable with BENCH_r01/r02 '
+                                 '(one image at a time: see one_image_at_a_time)'.format(n_flight) if n_flight > 1 else 'one image at a time'),
             'config': {'workload': 'BASELINE configs[1]: Kodak-shaped image {}x3x{}x{} per GPU per step, '
                                    'ae_configs/cvpr/{} + pc_configs/cvpr/res_shallow, encode + parallel '
                                    'context-model bitcost + decode(qhard); random-init weights'.format(
