@@ -107,6 +107,7 @@ PROTOTYPES = {
     'ic_peer_region_close': (c_int, [c_void_p]),
     'ic_peer_region_destroy': (c_int, [c_void_p]),
     'ic_peer_allreduce_f64': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_uint32, c_void_p, c_void_p]),
+    'ic_build_has_tuning_forms': (c_int, []),
     'ic_msssim_plan_bytes': (c_size_t, [c_int, c_int]),
     'ic_msssim_plan_fill': (c_int, [c_int, c_int, c_void_p, c_size_t]),
     'ic_msssim_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -588,6 +588,7 @@ __global__ __launch_bounds__(256) void wino3x3_c128_ksplit_kernel(const WnArgs a
     wino_body<VEC, 4>(a, t / a.grows, t % a.grows, gx, cot);
 }
 
+#ifdef IC_TUNING        // forms that lost every measurement and that the automatic plan never picks: tuning builds only (make TUNING=1)
 // ---- 16 tiles x 16 channels per wave on v_mfma_f32_16x16x4_f32 -------------------------------------------------------------
 // The 32 x 32 form above makes (tile groups x 4) wave-jobs of 1024 MFMAs; a Kodak map is 768 of them for 1024 SIMDs and a
 // quarter of the chip idles.  Here a wave-job is 16 tiles (ONE tile row of 16 = 2 x 32 output pixels) x 16 output channels:
@@ -793,6 +794,8 @@ __global__ __launch_bounds__(256) void wino3x3_c128_t16_kernel(const WnArgs a) {
 #endif
 }
 
+#endif  // IC_TUNING
+
 // all the 3x3 filters of a network in one launch (training re-packs every filter every step; 128 five-microsecond
 // launches per step otherwise): layer l reads w_tab[l], writes out + l * WN_PACKED_FLOATS
 __global__ __launch_bounds__(256) void wino_pack_batch_kernel(const float* const* __restrict__ w_tab, float* __restrict__ out,
@@ -889,13 +892,17 @@ static WinoPlan wino_plan(long long groups, bool even_w, int flags) {
     switch (form) {
         case IC_CONV3_WINO_WHOLEK: case IC_CONV3_WINO_WHOLEK_PW: p.whole = groups; return p;
         case IC_CONV3_WINO_KSPLIT: p.ksplit = groups; return p;
+#ifdef IC_TUNING
         case IC_CONV3_WINO_T16: if (even_w) p.t16 = groups; else p.whole = groups; return p;
+#endif
         case IC_CONV3_WINO_SEG1: case IC_CONV3_WINO_SEG2: case IC_CONV3_WINO_SEG3:
             if (even_w) { p.seg = groups; p.seg_nb = form - IC_CONV3_WINO_SEG1 + 1; } else p.whole = groups;
             return p;
+#ifdef IC_TUNING
         case IC_CONV3_WINO_PAIR:
             if (even_w) { p.seg = groups; p.seg_nb = -1; } else p.whole = groups;      // seg_nb -1: tile-pair jobs (conv3x3_wino_tp.hip)
             return p;
+#endif
         default: break;
     }
     // automatic: the full rounds of 256 tile groups run whole-K; the remainder r takes the cheapest of {whole-K, K-split,
@@ -938,6 +945,15 @@ extern "C" long long ic_wino3x3_c128_workgroups(int N, int H, int W, int flags) 
     return cus;
 }
 
+// 1: this build carries the forms that the plan never picks by itself (16 x 16 jobs, tile pairs, the persistent stack kernel)
+extern "C" int ic_build_has_tuning_forms(void) {
+#ifdef IC_TUNING
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 // the plan itself: tile groups per form {whole-K, NB-segment, segments per job NB, 16 x 16 (two-slot), K-split}
 extern "C" int ic_wino3x3_c128_plan(int N, int H, int W, int flags, long long plan_out[5]) {
     IC_CHECK_ARG(plan_out && N > 0 && H > 0 && W > 0);
@@ -952,6 +968,12 @@ extern "C" int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed,
     IC_CHECK_ARG(x && w_packed && scale && shift && y);
     IC_CHECK_ARG(N > 0 && H > 0 && W > 0);
     if ((long long)WN_C * H * W * 4 >= (1ll << 31)) return IC_ERR_UNSUPPORTED;    // per-image byte offsets are 31-bit
+#ifndef IC_TUNING
+    {   // the 16 x 16-job and tile-pair forms are compiled into tuning builds only (ic_build_has_tuning_forms)
+        const int form = flags & IC_CONV3_FORM_MASK;
+        if (form == IC_CONV3_WINO_T16 || form == IC_CONV3_WINO_PAIR) return IC_ERR_UNSUPPORTED;
+    }
+#endif
     WnArgs a{};
     a.x = x; a.wp = w_packed; a.scale = scale; a.shift = shift; a.res1 = res1; a.res2 = res2; a.y = y;
     a.N = N; a.H = H; a.W = W; a.relu = relu;
@@ -976,15 +998,21 @@ extern "C" int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed,
     }
     if (p.seg > 0) {
         a.g0 = (int)g0; a.ngroups = (int)p.seg;
+#ifdef IC_TUNING
         const int rc = p.seg_nb < 0 ? icx_wino_tp_launch(a, st) : icx_wino_tn_launch(a, p.seg_nb, (flags & IC_CONV3_PACKED_TRANSFORM) ? 0 : 1, st);
+#else
+        const int rc = icx_wino_tn_launch(a, p.seg_nb, (flags & IC_CONV3_PACKED_TRANSFORM) ? 0 : 1, st);
+#endif
         if (rc) return rc;
         g0 += p.seg;
     }
+#ifdef IC_TUNING
     if (p.t16 > 0) {
         a.g0 = (int)g0; a.ngroups = (int)p.t16;
         hipLaunchKernelGGL(wino3x3_c128_t16_kernel, dim3((unsigned)(4 * p.t16)), dim3(256), 0, st, a);
         g0 += p.t16;
     }
+#endif
     if (p.ksplit > 0) {
         const dim3 grid((unsigned)(p.ksplit * 4));
         a.g0 = (int)g0; a.ngroups = (int)p.ksplit;

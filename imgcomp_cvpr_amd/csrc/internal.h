@@ -33,9 +33,3 @@ int icx_conv5s2_cin3_mfma(const ConvArgs& a, hipStream_t st);
 size_t icx_pc_bwd_data_mfma_workspace(int N, int CinF, int CoutF, int OD, int OH, int OW);
 int icx_pc_bwd_data_mfma(const float* g, const float* w, float* dx_raw, int N, int CinF, int CoutF, int OD, int OH, int OW,
                          const float* zero_bias, void* workspace, size_t workspace_bytes, hipStream_t st);
-
-// probclass_cl.hip: the context model's inference pass with channels-last feature volumes (k = 24)
-bool icx_pc_cl_supported(int k, int L, int C, int h, int w);
-int icx_pc_forward_cl(const float* q, const int64_t* symbols, const float* const* wt, const float* pk1, const float* pk2,
-                      const float* pk16, int L, float pad_value, float* logits, float* bits, int N, int C, int h, int w,
-                      float* b0, float* b1, float* b2, hipStream_t st);

@@ -68,7 +68,13 @@ static int res_stack_walk(StackWalk& w, const void* const* tab, int B, float* co
 // CUs (a concurrent branch on a CU-range stream could keep work-groups of a persistent launch from becoming resident together)
 // -- and must have asked for it (IC_CONV3_STACK_KERNEL): measured, the hand-off costs what the kernel boundary costs.
 static int stack_kernel_nb(int N, int H, int W, int nlayers, int flags) {
+#ifndef IC_TUNING
+    return 0;                                            // the persistent stack kernel is compiled into tuning builds only
+#else
     if (!(flags & IC_CONV3_STACK_KERNEL) || (flags & (IC_CONV3_LEAVE_IDLE_CUS | IC_CONV3_PACKED_TRANSFORM))) return 0;
+    // several calls in flight: a persistent launch needs ALL its work-groups resident at once, which concurrent launches of other
+    // images cannot guarantee -- hand-offs would run into their spin bound
+    if (((flags >> 19) & 0xf) >= 2) return 0;
     const int form = flags & IC_CONV3_FORM_MASK;
     if (form != IC_CONV3_AUTO && form != IC_CONV3_WINO && !(form >= IC_CONV3_WINO_SEG1 && form <= IC_CONV3_WINO_SEG3)) return 0;
     if (ic_conv3x3_c128_pick_algo(N, H, W, flags) != 1) return 0;
@@ -76,6 +82,7 @@ static int stack_kernel_nb(int N, int H, int W, int nlayers, int flags) {
     if (ic_wino3x3_c128_plan(N, H, W, flags & IC_CONV3_FORM_MASK, pl) != IC_OK) return 0;
     if (pl[0] || pl[3] || pl[4] || !pl[1]) return 0;
     return icx_wino_stack_fits(N, H, W, (int)pl[2], nlayers) ? (int)pl[2] : 0;
+#endif
 }
 
 // sync: WN_STACK_SYNC_BYTES of the caller's workspace for the persistent form (nullptr: per-layer launches only)
@@ -83,6 +90,7 @@ static int res_stack(const void* const* tab, int B, float* const bufs[5], int N,
                      hipStream_t st, int* out_idx, unsigned* sync) {
     const int nlayers = 6 * B + 2;
     const int nb = sync ? stack_kernel_nb(N, H, W, nlayers, flags) : 0;
+#ifdef IC_TUNING
     if (nb) {
         WnStackArgs sa{};
         StackWalk w{true, &sa, flags, N, H, W, st, 0};
@@ -92,6 +100,8 @@ static int res_stack(const void* const* tab, int B, float* const bufs[5], int N,
         sa.nlayers = nlayers; sa.xcd_runs = (flags & IC_CONV3_NO_XCD_RUNS) ? 0 : 1;
         return icx_wino_stack_launch(sa, nb, st);
     }
+#endif
+    (void)nb;
     StackWalk w{false, nullptr, flags, N, H, W, st, 0};
     return res_stack_walk(w, tab, B, bufs, out_idx);
 }

@@ -16,8 +16,6 @@
 // identical for every position (no split reductions, no atomics) so that an incremental decoder can
 // reproduce the same logits bit-for-bit later ("hard parts").
 #include "common.h"
-#include "internal.h"
-#include <stdlib.h>
 
 struct PcLayerArgs {
     const float* in;      // layer 0: q (N,C,h,w); else (N,Cin,D,H,W) planar
@@ -711,12 +709,6 @@ extern "C" int ic_pc_pack_filters_f32(const float* const* wtab_host, int k, int 
     return pc_pack_filters(wtab_host, k, L, packed, (hipStream_t)stream);
 }
 
-// IC_PC_PLANAR=1 in the environment forces the planar kernels for inference too (A/B runs and the bit-identity tests)
-static int pc_debug_flags() {
-    const char* e = getenv("IC_PC_PLANAR");
-    return (e && e[0] == '1') ? 1 : 0;
-}
-
 // prepacked: the three MFMA filter packings already sit at the end of the workspace (the sequential decoder packs once
 // per call).  wt[8], when not NULL, is a caller-owned packing made once at load time (ic_pc_pack_filters_f32): inference
 // then runs without the per-call packing launch.
@@ -732,15 +724,6 @@ static int pc_forward(const float* q, int prepadded, const int64_t* symbols, con
     float* b1 = b0 + (size_t)N * k * (C + 3) * (h + 6) * (w + 6);
     float* b2 = b1 + (size_t)N * k * (C + 2) * (h + 4) * (w + 4);
     int rc;
-    // Inference with a caller-made packing (wt[8], ic_pc_pack_filters_f32 at load time) and k = 24: the channels-last pass
-    // (probclass_cl.hip) -- bit-identical logits and bits, the three feature volumes of the workspace in (N, D, H, W, 24) order.
-    // Training leaves wt[8] NULL: its backward reads the planar volumes written below.
-    if (wt[8] && !prepadded && !prepacked && icx_pc_cl_supported(k, L, C, h, w) && !(pc_debug_flags() & 1)) {
-        const float* pk1c = wt[8];
-        const float* pk2c = pk1c + pc_packed_floats(k, k);
-        const float* pk16c = pk2c + pc_packed_floats(k, k) + pc_packed_floats(k, 32);
-        return icx_pc_forward_cl(q, symbols, wt, pk1c, pk2c, pk16c, L, pad_value, logits, bits, N, C, h, w, b0, b1, b2, st);
-    }
     PcLayerArgs a{};
     a.N = N; a.pad_value = pad_value; a.prepadded = prepadded;
     // conv0: 1 -> k, first mask, ReLU

@@ -51,12 +51,17 @@ typedef void* ic_stream_t;
 #define IC_CONV3_WINO_WHOLEK      0x03   /* 32x32 jobs, 4 channel tiles per work-group, input transform shared through LDS */
 #define IC_CONV3_WINO_WHOLEK_PW   0x04   /* the same with a per-wave input transform (the whole-K form of odd widths) */
 #define IC_CONV3_WINO_KSPLIT      0x05   /* one channel tile per work-group, 4 K-quarters summed through LDS */
-#define IC_CONV3_WINO_T16         0x06   /* 16x16 jobs, two-slot ring (round-1 kernel; even widths) */
+#define IC_CONV3_WINO_T16         0x06   /* 16x16 jobs, two-slot ring (round-1 kernel; even widths).  TUNING builds only, see below */
 #define IC_CONV3_WINO_SEG1        0x07   /* 16 channels x NB segments of 16 tiles per wave, NB = 1 / 2 / 3 (even widths) */
 #define IC_CONV3_WINO_SEG2        0x08
 #define IC_CONV3_WINO_SEG3        0x09
 #define IC_CONV3_WINO_PAIR        0x0a   /* tile group x 32 channels per work-group, waves split the 16 positions, two work-groups per CU
-                                            (even widths; conv3x3_wino_tp.hip).  ic_wino3x3_c128_plan reports it as segment jobs with nb = -1 */
+                                            (even widths; conv3x3_wino_tp.hip).  ic_wino3x3_c128_plan reports it as segment jobs with nb = -1.
+                                            TUNING builds only */
+/* IC_CONV3_WINO_T16, IC_CONV3_WINO_PAIR and IC_CONV3_STACK_KERNEL name forms that were built, tested bit-identical and measured
+ * slower than or level with what the plan picks.  The shipped library does not carry them (`make TUNING=1` does):
+ * ic_build_has_tuning_forms() tells, forcing T16 / PAIR without them returns IC_ERR_UNSUPPORTED, IC_CONV3_STACK_KERNEL is ignored. */
+int ic_build_has_tuning_forms(void);
 /* partly filled rounds stay one-work-group-per-CU and the CUs beyond the tile groups stay free: a caller's independent
  * branch runs there on a CU-range stream (ic_stream_create_cu_range; imgcomp_cvpr_amd/streams.py) */
 #define IC_CONV3_LEAVE_IDLE_CUS   0x10
@@ -68,13 +73,13 @@ typedef void* ic_stream_t;
                                             round, run its 6B+2 layers as ONE persistent launch (conv3x3_wino_stack.hip) instead of one
                                             launch per layer.  Bit-identical; measured level with per-layer launches, so
                                             it is an option, not the default */
-#define IC_CONV3_PACKED_TRANSFORM 0x40
+#define IC_CONV3_PACKED_TRANSFORM 0x40   /* NB-segment kernels: input transform on v_pk_add_f32 instead of single adds (A/B) */
 /* the caller keeps n (2..15) INDEPENDENT calls of this shape in flight on different streams (the images of an evaluation set,
  * val.py:157-158): a launch no longer has to fill the chip by itself, so the plan takes the form that costs the least CU-time --
  * 32 x 32 whole-K jobs, whose 192 work-groups for a Kodak map leave a quarter of the chip to the neighbouring stream's launch
  * instead of idle -- for launches of at least 128 tile groups (smaller maps keep the one-launch plan: their work-groups are short
  * and the overlap alone fills the chip).  n = 0 / 1: plan for one launch at a time. */
-#define IC_CONV3_IN_FLIGHT(n)     (((n) & 0xf) << 19)   /* NB-segment kernels: input transform on v_pk_add_f32 instead of single adds (A/B) */
+#define IC_CONV3_IN_FLIGHT(n)     (((n) & 0xf) << 19)
 #define IC_CONV3_DIRECT_VARIANT(v) ((((v) + 1) & 0xf) << 8)   /* direct form: force tile variant v (0..9); tests */
 /* h13 (ic_deconv2d_bn_act_f32, 5x5/2 transposed, 64 -> <= 4): tiles per work-group, 0 = automatic; tests */
 #define IC_EDGE_TILES_PER_WG(n)   ((n) & 0xff)

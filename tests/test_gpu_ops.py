@@ -172,6 +172,16 @@ def test_conv3x3_c128_winograd(cuda, shape, N, H, W):
     """the Winograd F(2x2,3x3) form of the same layer: interior and border groups, odd sizes, ReLU / residuals,
     and the adjoint packing (data gradient) against the adjoint of the oracle's conv."""
     L = _lib()
+    if shape in ('t16', 'pair') and not L.lib.ic_build_has_tuning_forms():
+        # the forms the plan never picks are compiled into tuning builds only (make -C imgcomp_cvpr_amd/csrc TUNING=1): the shipped
+        # library must refuse them instead of silently running something else
+        x1 = torch.zeros((1, 128, 8, 32), device=cuda)
+        wp1 = torch.zeros(L.lib.ic_wino3x3_c128_packed_floats(), device=cuda)
+        one = torch.ones(128, device=cuda)
+        rc = L.lib.ic_wino3x3_c128_bn_act_f32(L.ptr(x1), L.ptr(wp1), L.ptr(one), L.ptr(one), None, None, L.ptr(torch.empty_like(x1)), 1, 8, 32,
+                                              0, L.CONV3_WINO_T16 if shape == 't16' else L.CONV3_WINO_PAIR, L.current_stream())
+        assert rc != 0
+        pytest.skip('tuning-build form (make TUNING=1)')
     rs = np.random.RandomState(300 + H)
     x = rs.normal(0, 1, (N, 128, H, W)).astype(np.float32)
     w = rs.normal(0, 0.05, (3, 3, 128, 128)).astype(np.float32)
