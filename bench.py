@@ -172,7 +172,7 @@ def main():
     p.add_argument('--calib_copy', action='store_true',
                    help='after the timed steps: a 256 MiB device-to-device copy (rocprofv3 --pmc passes calibrate FETCH_SIZE / WRITE_SIZE on it)')
     p.add_argument('--plan_flags', type=lambda v: int(v, 0), default=0,
-                   help='IC_CONV3_* bits OR-ed into every encode / decode call (0x80 = IC_CONV3_STACK_KERNEL: each residual stack as one persistent launch)')
+                   help='IC_CONV3_* bits OR-ed into every encode / decode call (include/imgcomp_hip.h; 0x80 = IC_CONV3_STACK_KERNEL needs a `make TUNING=1` library)')
     p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                    help='process-group backend for N > 1 (nccl = RCCL; gloo lets two ranks share one GPU in the tests)')
     p.add_argument('--device', type=int, default=None, help='HIP device index of this rank (default: LOCAL_RANK)')

@@ -240,21 +240,26 @@ __global__ __launch_bounds__(256) void wino3x3_c128_wgrad_kernel(const WwArgs a)
 // sums are added as (g0 + g1) + (g2 + g3) -- a fixed order, and four times the loads in flight of a sequential loop
 __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ partial, int S, const float* __restrict__ w,
                                                                 float wd, float* __restrict__ dw) {
-    __shared__ f32x4 red[4][64];
+    __shared__ double red[4][64][4];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int e4 = blockIdx.x * 64 + lane;                 // float4 index: 9 * 128 * 128 / 4 = 576 * 64
     const int per = (S + 3) >> 2, k0 = grp * per, k1 = k0 + per < S ? k0 + per : S;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int k = k0; k < k1; ++k) s += reinterpret_cast<const f32x4*>(partial + (size_t)k * 9 * WN_C * WN_C)[e4];
-    red[grp][lane] = s;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};                    // the K-slices' fp32 sums are added up in float64, fixed order
+    for (int k = k0; k < k1; ++k) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(partial + (size_t)k * 9 * WN_C * WN_C)[e4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] += (double)v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[grp][lane][j] = s[j];
     __syncthreads();
     if (grp == 0) {
-        f32x4 t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-        if (w) {
-            const f32x4 wv = reinterpret_cast<const f32x4*>(w)[e4];
+        f32x4 t;
+        f32x4 wv = {0.f, 0.f, 0.f, 0.f};
+        if (w) wv = reinterpret_cast<const f32x4*>(w)[e4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) t[j] = fmaf(wd, wv[j], t[j]);
-        }
+        for (int j = 0; j < 4; ++j)
+            t[j] = (float)(((red[0][lane][j] + red[1][lane][j]) + (red[2][lane][j] + red[3][lane][j])) + (double)wd * (double)wv[j]);
         reinterpret_cast<f32x4*>(dw)[e4] = t;
     }
 }

@@ -172,10 +172,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            const float* __restrict__ w, float wd, float* __restrict__ dw) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= count) return;
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += partial[(size_t)k * count + e];
-    if (w) s = fmaf(wd, w[e], s);
-    dw[e] = s;
+    double s = 0.0;                                              // the slices' fp32 sums are added up in float64 (fixed order)
+    for (int k = 0; k < S; ++k) s += (double)partial[(size_t)k * count + e];
+    if (w) s += (double)wd * (double)w[e];
+    dw[e] = (float)s;
 }
 
 static void wg_plan(int A, int B, long long P, int KH, int KW, int* TA, int* WA, int* TB, int* WB, int* S, int* PS) {
@@ -263,9 +263,9 @@ __global__ __launch_bounds__(256) void wgrad3d_reduce_kernel(const float* __rest
     const int t3 = (int)(e / AB), r = (int)(e % AB);
     int lt = -1;
     for (int k = 0; k < NT; ++k) if (a.taps[k] == t3) lt = k;
-    float s = 0.f;
-    if (lt >= 0) for (int k = 0; k < S; ++k) s += partial[((size_t)k * NT + lt) * AB + r];
-    dw[e] = s;
+    double s = 0.0;
+    if (lt >= 0) for (int k = 0; k < S; ++k) s += (double)partial[((size_t)k * NT + lt) * AB + r];
+    dw[e] = (float)s;
 }
 
 extern "C" size_t ic_pc_wgrad_workspace_bytes(int N, int A, int B, int VD, int VH, int VW) {
