@@ -48,6 +48,10 @@ def pytest_terminal_summary(terminalreporter):
         # in it whatever their rank
         rows = sorted(worst.items(), key=lambda kv: -kv[1][1] / kv[1][2])
         terminalreporter.write_line('parity report: {} comparisons against the float64 oracle, worst per label (closest to its bound first)'.format(len(util.REPORT)))
+        terminalreporter.write_line('  how the north_star\'s "within 1e-4 fp32" is read: rel = max|HIP - oracle64| / max(1, max|oracle64|) per tensor, i.e. relative '
+                                    'to the TENSOR SCALE, not per element; abs = the same maximum in the tensor\'s own units (x_out: 0..255 grey levels,')
+        terminalreporter.write_line('  so abs 2.5e-4 there is rel 9.6e-7).  Bounds: single op 2e-5, whole network 5e-5, heatmap and end-to-end 1e-4; symbols and '
+                                    'qhard bit-exact given the same z.  Both columns are printed for every label:')
         for k, (ae, re_, bound) in rows:
             terminalreporter.write_line('  {:72s} abs {:9.3e}  rel {:9.3e}  bound {:7.1e}'.format(k, ae, re_, bound))
     if util.FLIPS:

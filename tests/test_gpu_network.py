@@ -133,7 +133,7 @@ def test_full_size_properties(cuda, configs, syn_weights, nets, algo):
         assert torch.equal(z1, e3.z), 'result depends on the MFMA tile variant'
     elif algo == 'winograd3x3':
         # every Winograd decomposition performs the same operations per output: bit-identical
-        forms = [_lib.CONV3_WINO_WHOLEK, _lib.CONV3_WINO_KSPLIT, _lib.CONV3_WINO_SEG1, _lib.CONV3_WINO_SEG2, _lib.CONV3_WINO_SEG3,
+        forms = [_lib.CONV3_WINO_WHOLEK, _lib.CONV3_WINO_SEG1, _lib.CONV3_WINO_SEG2, _lib.CONV3_WINO_SEG3,
                  _lib.CONV3_WINO_SEG3 | _lib.CONV3_PACKED_TRANSFORM]
         if _lib.lib.ic_build_has_tuning_forms():                      # make TUNING=1: the forms the plan never picks
             forms += [_lib.CONV3_WINO_T16, _lib.CONV3_WINO_PAIR]
