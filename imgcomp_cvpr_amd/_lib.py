@@ -108,6 +108,11 @@ PROTOTYPES = {
     'ic_peer_region_destroy': (c_int, [c_void_p]),
     'ic_peer_allreduce_f64': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_uint32, c_void_p, c_void_p]),
     'ic_build_has_tuning_forms': (c_int, []),
+    'ic_wino4_3x3_c128_packed_floats': (c_size_t, []),
+    'ic_pack_wino4_3x3_c128_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    'ic_wino4_3x3_c128_supported': (c_int, [c_int, c_int, c_int]),
+    'ic_wino4_3x3_c128_workgroups': (c_longlong, [c_int, c_int, c_int]),
+    'ic_wino4_3x3_c128_bn_act_f32': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
     'ic_msssim_plan_bytes': (c_size_t, [c_int, c_int]),
     'ic_msssim_plan_fill': (c_int, [c_int, c_int, c_void_p, c_size_t]),
     'ic_msssim_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),

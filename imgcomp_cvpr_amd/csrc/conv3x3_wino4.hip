@@ -1,0 +1,454 @@
+// 3x3, stride 1, 128 -> 128 channel convolution of the residual stacks (autoencoder.py:224-234, :252-262, :274-287) in Winograd
+// F(4x4, 3x3) form on the fp32 matrix cores: 36 multiplies per 16 outputs -- 36 / 144 of the direct form's, 0.5625 of F(2x2,3x3)'s.
+//
+//   Y = At [ (G g Gt) (.) (Bt d B) ] A        g: 3x3 filter, d: 6x6 input patch, Y: 4x4 outputs ("tile"); points 0, +-1, +-2, inf
+//
+// Numerics first (tools/wino_f4_numerics.py, round 4): the whole encoder / decoder evaluated in float32 with this form has the SAME
+// error against the float64 oracle as with the direct form or F(2x2) -- z 1.1-1.6e-5, x_out 3e-7 of the tensor scale, no symbol
+// flips: the network's error is set by its other parts, the larger transform constants do not show.  (Round 2 had rejected the
+// form by scaling the device's whole-network error with a per-layer factor; the per-layer factor does not carry through
+// BatchNorm + skips.)
+//
+// Layout on a gfx950 wave, v_mfma_f32_16x16x4_f32 (D[16 x 16] += A[16 x 4] B[4 x 16]):
+//   * M axis = 16 output channels, N axis = 16 tiles (a SEGMENT: 16 horizontally adjacent tiles = 4 x 64 output pixels),
+//     K = 4 input channels.  Lane l = (tile n = l & 15, k = l >> 4): ONE 6x6 patch transform per lane yields its B operands of
+//     all 36 positions of a k-step; a wave owns 16 channels x 16 tiles x 36 positions = 36 accumulators of 4 registers = 144 AGPRs
+//     (a 32 x 32 tile would need 576), so TWO work-groups fit a CU and each SIMD always has a second wave to issue from.
+//   * the output transform At M A is lane-local (same lane, same register index across the 36 accumulators): 4 channels x 4 x 4
+//     pixels per lane, stored as 16-byte runs (a tile row is 4 neighbouring pixels; 16 lanes = 256 contiguous bytes).
+//   * work-group = 4 waves = 4 channel tiles (one HALF of the output channels) of one segment.  Wave w loads and transforms the
+//     input of k-steps 4 j + w only; the B operands reach the other waves through a two-half LDS ring (72 KB), one barrier per
+//     4 k-steps.  Patch columns: every lane loads its own aligned 4 pixels per patch row, the two outer columns are the neighbour
+//     lanes' values (DPP row shifts; the two ends of the 16-lane tile row load one extra dword).
+//   * A operands (transformed filters, 36 x 128 x 128 floats = 2.36 MB per layer) are pre-packed in fragment order: 9 16-byte
+//     loads per k-step and lane, each 1 KB contiguous across the wave, L2 resident, streamed through a register ring.
+//   * zero padding is done by the memory system (raw buffer loads, out-of-range lane offsets), as in the F(2x2) kernels.
+// Shapes: W % 4 == 0 (aligned 16-byte rows); anything else keeps the F(2x2) forms (ic_conv3x3_c128_auto_f32).
+#include "wino_common.h"
+#include "internal.h"
+
+#define W4_QUADS 9                                  // 36 positions in quads of 4
+#define W4_PACKED_FLOATS (36 * WN_C * WN_C)
+#define W4_ACC_A 32                                 // accumulators (of 36) kept in AGPRs
+#ifndef W4_WAVES
+#define W4_WAVES 8                                  // waves per work-group: 8 = all 128 output channels of a segment
+#endif
+#ifndef W4_RB
+#define W4_RB 3                                     // B-operand ring, in quads (36 % W4_RB == 0)
+#endif
+#ifndef W4_SLEEP
+#define W4_SLEEP 40
+#endif
+#ifndef W4_DBG
+#define W4_DBG 0
+#endif
+#ifndef W4_ABL
+#define W4_ABL 0                                    // tuning builds: 1 no transform turns in the loop, 2 no filter requests, 4 no B reads
+#endif
+#ifndef W4_GAP
+#define W4_GAP 0                                    // quads between a turn's patch request and its transform
+#endif
+#ifndef W4_STAGGER
+#define W4_STAGGER 1
+#endif
+#ifndef W4_TURN
+#define W4_TURN 6
+#endif
+//                                                 // quad of an iteration at which a wave transforms its k-step of the next one
+#define W4_RA 4                                     // filter-fragment ring, in quads (36 % W4_RA == 0)
+
+// ---- filter transform + packing: U = G g Gt in float64, rounded once -------------------------------------------------------
+// packed float index: (((cot * 32 + ks) * 9 + p / 4) * 64 + lane) * 4 + p % 4, cot = co / 16, ks = ci / 4, lane = (ci & 3) * 16 + (co & 15),
+// p = 6 xi + nu.  backward = 1 packs the adjoint (data-gradient) filter: g'[a][b][in = co][out = ci] = g[2 - a][2 - b][ci][co].
+__global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict__ w_tf, float* __restrict__ out, int backward) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= WN_C * WN_C) return;
+    const int cin = idx / WN_C, cout = idx % WN_C;
+    double g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            g[a][b] = backward ? (double)w_tf[(((2 - a) * 3 + (2 - b)) * WN_C + cout) * WN_C + cin]
+                               : (double)w_tf[((a * 3 + b) * WN_C + cin) * WN_C + cout];
+    const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    double t[6][3];
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) t[x][b] = G[x][0] * g[0][b] + G[x][1] * g[1][b] + G[x][2] * g[2][b];
+    float* o = out + ((size_t)((cout >> 4) * 32 + (cin >> 2)) * W4_QUADS * 64 + ((cin & 3) * 16 + (cout & 15))) * 4;
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+        for (int v = 0; v < 6; ++v) {
+            const int p = 6 * x + v;
+            o[(p >> 2) * 256 + (p & 3)] = (float)(t[x][0] * G[v][0] + t[x][1] * G[v][1] + t[x][2] * G[v][2]);
+        }
+}
+
+extern "C" size_t ic_wino4_3x3_c128_packed_floats(void) { return W4_PACKED_FLOATS; }
+
+extern "C" int ic_pack_wino4_3x3_c128_f32(const float* w_tf, float* w_packed, int backward, ic_stream_t stream) {
+    IC_CHECK_ARG(w_tf && w_packed);
+    hipLaunchKernelGGL(wino4_pack_kernel, dim3(WN_C * WN_C / 256), dim3(256), 0, (hipStream_t)stream, w_tf, w_packed, backward);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
+// Bt x of 6 values (points 0, +-1, +-2, inf):
+//   t0 = 4 d0 - 5 d2 + d4      t1 = -4 d1 - 4 d2 + d3 + d4      t2 = 4 d1 - 4 d2 - d3 + d4
+//   t3 = -2 d1 - d2 + 2 d3 + d4      t4 = 2 d1 - d2 - 2 d3 + d4      t5 = 4 d1 - 5 d3 + d5
+// (inputs by value: the outputs may be the same variables)
+__device__ __forceinline__ void w4_bt(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5,
+                                      float& t0, float& t1, float& t2, float& t3, float& t4, float& t5) {
+    const float p = fmaf(-4.f, d2, d4), q = fmaf(-4.f, d1, d3);       // d4 - 4 d2, d3 - 4 d1
+    const float r = d4 - d2, s = 2.f * (d3 - d1);
+    const float a0 = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+    const float a5 = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+    t0 = a0;
+    t1 = p + q;
+    t2 = p - q;
+    t3 = r + s;
+    t4 = r - s;
+    t5 = a5;
+}
+// At x of 6 values: y0 = m0 + m1 + m2 + m3 + m4, y1 = (m1 - m2) + 2 (m3 - m4), y2 = (m1 + m2) + 4 (m3 + m4), y3 = (m1 - m2) + 8 (m3 - m4) + m5
+__device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, float m4, float m5,
+                                      float& y0, float& y1, float& y2, float& y3) {
+    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+    y0 = (m0 + s1) + s2;
+    y1 = fmaf(2.f, d2, d1);
+    y2 = fmaf(4.f, s2, s1);
+    y3 = fmaf(8.f, d2, d1) + m5;
+}
+
+// WAVES = 4: a work-group is one HALF of the output channels of a segment, two work-groups per CU.
+// WAVES = 8: a work-group is ALL 128 output channels of a segment (one per CU): the input transform is made once per segment
+//            instead of once per half -- waves 0..3 produce the k-steps of the even iterations, waves 4..7 those of the odd ones.
+template <bool WT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void wino4_3x3_c128_kernel(const WnArgs a) {
+#if W4_DBG & 4
+    __shared__ f32x4 ring[2 * 4 * W4_QUADS * 64 + 1024];          // > 80 KB: one work-group per CU (debug)
+#else
+    __shared__ f32x4 ring[2 * 4 * W4_QUADS * 64];                 // [half][k-step of the iteration][position quad][lane]: 72 KB
+#endif
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, n16 = lane & 15, kq = lane >> 4;
+    const int b = a.xcd_runs ? ic_xcd_run(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int half_co = WAVES == 4 ? (b & 1) : 0;
+    const int seg = (WAVES == 4 ? (b >> 1) : b) + a.g0;
+    const int sx = seg % a.gcols, t_ = seg / a.gcols;
+    const int ty = t_ % a.grows, n = t_ / a.grows;
+    const int cot = half_co * 4 + wave;                           // 16-channel tile of this wave
+    const int pw = wave & 3;                                      // k-step of an iteration this wave produces
+    const int pgrp = wave >> 2;                                   // WAVES = 8: parity of the iterations it produces for
+    const int tx = 16 * sx + n16;
+    const int H = a.H, W = a.W, HW = H * W;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)n * WN_C * HW), 0, WN_C * HW * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, W4_PACKED_FLOATS * 4, 0x00020000);
+    // patch rows 4 ty - 1 .. 4 ty + 4: own aligned 4 pixels (columns 4 tx .. 4 tx + 3); the end lanes of the tile row also fetch
+    // the column outside (lane 0: 4 tx - 1, lane 15: 4 tx + 4), every other lane gets an out-of-range offset there
+    // Row validity is wave-uniform (one tile row per work-group), column validity per lane: ONE lane offset for the patch's first
+    // row (out of range when the tile lies beyond the map) and one for the end column; a row outside the image swaps in the
+    // out-of-range offset by a scalar condition.
+    const bool col_ok = 4 * tx < W;
+    const int ecol = n16 == 0 ? 4 * tx - 1 : (n16 == 15 ? 4 * tx + 4 : -1);
+    const bool e_ok = col_ok && ecol >= 0 && ecol < W;
+    const int r_first = 4 * ty - 1;
+    // (offsets are formed in int: r_first may be -1; the rows actually used are >= 0)
+    const int obase = (kq * HW + r_first * W + 4 * tx) * 4;
+    const int ebase = (kq * HW + r_first * W + ecol) * 4;
+    const unsigned fo = (unsigned)lane * 16u;
+    // HW_ID.WAVE_ID bit 0: the slot of this wave on its SIMD (two resident waves: slots 0 and 1)
+    const bool early = WAVES == 8 || !W4_STAGGER || (__builtin_amdgcn_s_getreg(0x1804) & 1) == 0;
+
+    // Accumulators live in AGPRs, tied to the MFMA's destination by inline asm (the builtin lets the allocator put the result
+    // into ANOTHER tuple than the addend: the freed addend registers are then handed to the next ds_read / buffer load, and
+    // with two waves per SIMD sharing the matrix pipe that load can land before the queued MFMA has read them -- measured: a
+    // few wrong outputs per 10^7 in lanes 12..15 of each row, only under full load, never twice in the same place).
+    f32x4 acc[36];
+#pragma unroll
+    for (int p = 0; p < 36; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (at two waves per SIMD the compiler splits the 256 registers of a wave 128 : 128 between the two files: 32 of the 36
+    // accumulators sit in AGPRs, the last four in VGPRs -- the MFMA takes its addend from either file)
+#pragma unroll
+    for (int p = 0; p < 36; ++p) {
+        if (p < W4_ACC_A) asm volatile("" : "+a"(acc[p]));
+        else asm volatile("" : "+v"(acc[p]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x4 pr[6];            // own 4 pixels of the 6 patch rows
+    float pe[6];            // the column outside (lanes 0 / 15 of a tile row)
+    auto load_patch = [&](int ks) __attribute__((always_inline)) {
+        const int so = ks * 4 * HW * 4;                           // scalar: channels 4 ks ..
+        // the 12 lane offsets are re-derived from two registers at every call: hoisted out of the loop (which the compiler does
+        // on its own) they would sit in 12 registers next to 144 accumulators and spill
+        int ob = obase, eb = ebase;
+        asm volatile("" : "+v"(ob), "+v"(eb));
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const bool row_ok = r_first + i >= 0 && r_first + i < H;          // scalar
+            const unsigned o1 = (row_ok && col_ok) ? (unsigned)(ob + i * W * 4) : WN_OOB;
+            const unsigned o2 = (row_ok && e_ok) ? (unsigned)(eb + i * W * 4) : WN_OOB;
+            pr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, o1, so, 0));
+            pe[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, o2, so, 0));
+        }
+    };
+    // Bt d B of this lane's patch -> ring[half][st = wave][quad][lane].  In place on 36 registers: columns first (each 6 -> 6),
+    // then rows, a pair of rows = three position quads written as soon as it is complete; the phases are fenced so that the
+    // scheduler does not interleave them (36 accumulators + rings leave ~50 registers for all of this)
+    auto transform_put = [&](int half) __attribute__((always_inline)) {
+        float u[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            u[i][0] = dpp_from_left(pe[i], pr[i][3]);            // column 4 tx - 1 = the left neighbour's last pixel
+            u[i][5] = dpp_from_right(pe[i], pr[i][0]);           // column 4 tx + 4 = the right neighbour's first pixel
+            u[i][1] = pr[i][0]; u[i][2] = pr[i][1]; u[i][3] = pr[i][2]; u[i][4] = pr[i][3];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            w4_bt(u[0][j], u[1][j], u[2][j], u[3][j], u[4][j], u[5][j], u[0][j], u[1][j], u[2][j], u[3][j], u[4][j], u[5][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4* dst = &ring[((half * 4 + pw) * W4_QUADS) * 64 + lane];
+#pragma unroll
+        for (int x = 0; x < 6; x += 2) {
+            float v0[6], v1[6];
+            w4_bt(u[x][0], u[x][1], u[x][2], u[x][3], u[x][4], u[x][5], v0[0], v0[1], v0[2], v0[3], v0[4], v0[5]);
+            w4_bt(u[x + 1][0], u[x + 1][1], u[x + 1][2], u[x + 1][3], u[x + 1][4], u[x + 1][5], v1[0], v1[1], v1[2], v1[3], v1[4], v1[5]);
+            const int q0 = 3 * (x / 2);                           // positions 6 x .. 6 x + 11 = quads q0 .. q0 + 2
+            dst[(q0 + 0) * 64] = f32x4{v0[0], v0[1], v0[2], v0[3]};
+            dst[(q0 + 1) * 64] = f32x4{v0[4], v0[5], v1[0], v1[1]};
+            dst[(q0 + 2) * 64] = f32x4{v1[2], v1[3], v1[4], v1[5]};
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // filter fragments: quad index Q = ks * 9 + q of this wave's channel tile: 1 KB per quad
+    f32x4 fa[W4_RA];
+    auto load_filter = [&](int slot, int Q) __attribute__((always_inline)) {       // slot = Q % W4_RA, passed as a constant
+        const int Qc = Q < 32 * W4_QUADS ? Q : 32 * W4_QUADS - 1;
+        fa[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(fr, fo, (cot * 32 * W4_QUADS + Qc) * 1024, 0));
+    };
+
+    // ---- prologue: the input of iteration 0, the first filter fragments ----
+#if !(W4_DBG & 16384)
+    if (WAVES == 4 || pgrp == 0 || (W4_DBG & 4096)) load_patch(pw);
+#pragma unroll
+    for (int Q = 0; Q < W4_RA - 1; ++Q) load_filter(Q, Q);
+    if (WAVES == 4 || pgrp == 0 || (W4_DBG & 4096)) transform_put(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#endif
+
+#if W4_DBG & 16384
+    // debug: no LDS, no barrier -- every wave loads and transforms every k-step itself
+    for (int ks = 0; ks < 32; ++ks) {
+        load_patch(ks);
+        float u[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            u[i][0] = dpp_from_left(pe[i], pr[i][3]);
+            u[i][5] = dpp_from_right(pe[i], pr[i][0]);
+            u[i][1] = pr[i][0]; u[i][2] = pr[i][1]; u[i][3] = pr[i][2]; u[i][4] = pr[i][3];
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) w4_bt(u[0][j], u[1][j], u[2][j], u[3][j], u[4][j], u[5][j], u[0][j], u[1][j], u[2][j], u[3][j], u[4][j], u[5][j]);
+        float vb[36];
+#pragma unroll
+        for (int x = 0; x < 6; ++x) w4_bt(u[x][0], u[x][1], u[x][2], u[x][3], u[x][4], u[x][5], vb[6 * x], vb[6 * x + 1], vb[6 * x + 2], vb[6 * x + 3], vb[6 * x + 4], vb[6 * x + 5]);
+#pragma unroll
+        for (int q = 0; q < W4_QUADS; ++q) {
+            const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(fr, fo, (cot * 32 * W4_QUADS + ks * W4_QUADS + q) * 1024, 0));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (4 * q + i < W4_ACC_A) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[4 * q + i]) : "v"(f[i]), "v"(vb[4 * q + i]));
+                else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[4 * q + i]) : "v"(f[i]), "v"(vb[4 * q + i]));
+            }
+        }
+    }
+#else
+    // One iteration = 4 k-steps = 36 quads of 4 MFMAs.  Per quad, IN THIS ORDER: its 4 MFMAs, then the request of the filter
+    // fragments W4_RA - 1 quads ahead into the ring slot the PREVIOUS quad consumed, then the B operands two quads ahead into the
+    // slot the previous quad consumed: a register is overwritten by a load issued at least 4 MFMAs after its last reader.
+    for (int jj = 0; jj < 8; jj += 2) {
+#pragma unroll
+        for (int u2 = 0; u2 < 2; ++u2) {                          // iteration j = jj + u2 reads ring half u2
+            const int j = jj + u2;
+            f32x4 bq[W4_RB];
+            bq[0] = ring[((u2 * 4 + 0) * W4_QUADS + 0) * 64 + lane];
+            bq[1] = ring[((u2 * 4 + 0) * W4_QUADS + 1) * 64 + lane];
+#pragma unroll
+            for (int lq = 0; lq < 36; ++lq) {                     // quad of the iteration: k-step lq / 9, positions 4 (lq % 9) ..
+                const int q = lq % W4_QUADS;
+                const int Q = j * 36 + lq;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if ((W4_DBG & 8192) && 4 * q + i >= W4_ACC_A) continue;      // debug: no MFMA on the VGPR-resident accumulators
+                    if (4 * q + i < W4_ACC_A) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[4 * q + i]) : "v"(fa[lq % W4_RA][i]), "v"(bq[lq % W4_RB][i]));
+                    else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[4 * q + i]) : "v"(fa[lq % W4_RA][i]), "v"(bq[lq % W4_RB][i]));
+                }
+                if (!(W4_ABL & 2)) load_filter((lq + W4_RA - 1) % W4_RA, Q + W4_RA - 1);      // 36 % W4_RA == 0: the slot depends on lq only
+                if (lq + 2 < 36 && !(W4_ABL & 4))
+                    bq[(lq + 2) % W4_RB] = ring[((u2 * 4 + (lq + 2) / W4_QUADS) * W4_QUADS + (lq + 2) % W4_QUADS) * 64 + lane];
+                if (!(W4_ABL & 1)) {
+                    // the wave's own k-step of the NEXT iteration: requested, transformed and written into the other half in one go
+                    // (a patch kept in registers across a dozen quads spills: 144 accumulators leave ~110 registers); the two waves a
+                    // SIMD holds (one of each resident work-group) take their turns half an iteration apart
+                    const bool mine = WAVES == 4 || (W4_DBG & 4096) || ((u2 ^ 1) == pgrp);         // iteration j + 1 has the parity of half u2 ^ 1
+                    if (lq == W4_TURN && j + 1 < 8 && early && mine) load_patch(4 * (j + 1) + pw);
+                    if (lq == W4_TURN + W4_GAP && j + 1 < 8 && early && mine) transform_put(u2 ^ 1);
+                    if (lq == W4_TURN + 18 && j + 1 < 8 && !early && mine) load_patch(4 * (j + 1) + pw);
+                    if (lq == W4_TURN + 18 + W4_GAP && j + 1 < 8 && !early && mine) transform_put(u2 ^ 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);                // quads stay in program order: the rings are sized for exactly that
+            }
+#if W4_DBG & 8
+            __syncthreads();
+#else
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                         // next half complete, this half read by everybody
+#endif
+#if W4_DBG & 16
+            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+        }
+    }
+#endif
+    // inline asm is opaque to the hazard recogniser: pad the last MFMAs' latency, then pass every accumulator through an empty
+    // volatile asm so that no read of it can be scheduled above the pad (conv3x3_wino_tn.hip found that the hard way)
+#if W4_DBG & 128
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#elif W4_DBG & 512
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#elif W4_DBG & 2048
+    {   // drain: one MFMA that depends on the last accumulator written (0 * 0 + acc): it cannot issue before that write is done
+        const float zf = 0.f;
+        asm volatile("s_nop 15\n\tv_mfma_f32_16x16x4_f32 %0, %1, %1, %0\n\ts_nop 15\n\ts_nop 15" : "+v"(acc[35]) : "v"(zf));
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %1, %0\n\ts_nop 15\n\ts_nop 15" : "+a"(acc[31]) : "v"(zf));
+    }
+#elif W4_DBG & 1024
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_sleep %0\n\ts_nop 15" :: "n"(W4_SLEEP) : "memory");
+#else
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+#pragma unroll
+    for (int p = 0; p < 36; ++p) {
+        if (p < W4_ACC_A) asm volatile("" : "+a"(acc[p]));
+        else asm volatile("" : "+v"(acc[p]));
+    }
+
+#if W4_DBG & 256
+    if (a.prof) {             // debug build: raw accumulators -> a.prof[((work-group * 4 + wave) * 36 + p) * 64 + lane] (4 floats each)
+        f32x4* dbg = (f32x4*)a.prof + ((size_t)(blockIdx.x * WAVES + wave) * 36) * 64 + lane;
+#pragma unroll
+        for (int p = 0; p < 36; ++p) dbg[p * 64] = acc[p];
+    }
+#endif
+    // ---- At M A, BN fold, activation, residuals, store: 4 channels x (4 x 4 pixels) per lane ----
+    const int img_bytes = WN_C * HW * 4;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (size_t)n * WN_C * HW), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res1 ? a.res1 + (size_t)n * WN_C * HW : a.x), 0, a.res1 ? img_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res2 ? a.res2 + (size_t)n * WN_C * HW : a.x), 0, a.res2 ? img_bytes : 0, 0x00020000);
+    // the epilogue's lane geometry is derived again from the lane id (laundered: kept alive from the prologue across the loop it
+    // would be spilled to scratch next to 144 accumulators)
+    // (mbcnt: the lane id from the hardware -- threadIdx kept alive across the loop is what the compiler spilled)
+    int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(lane_e));
+    const int kq_e = lane_e >> 4, tx_e = 16 * sx + (lane_e & 15);
+    const bool col_ok_e = 4 * tx_e < W;
+    unsigned lo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int oy = 4 * ty + i;
+        lo[i] = (col_ok_e && oy < H) ? (unsigned)((4 * kq_e * HW + oy * W + 4 * tx_e) * 4) : WN_OOB;
+    }
+    const float relu_lo = a.relu ? 0.f : -__builtin_inff();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = 16 * cot + r;                              // + 4 kq: in the lane offset (4 kq HW) and the scale pointer below
+        const float sc = a.scale[co + 4 * kq_e], sh = a.shift[co + 4 * kq_e];
+        const int so = co * HW * 4;
+        f32x4 e1[4], e2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#if W4_DBG & 1
+            e1[i] = f32x4{0.f, 0.f, 0.f, 0.f}; e2[i] = e1[i];
+            if (a.res1) e1[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1r, lo[i], so, 0));
+            if (a.res2) e2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2r, lo[i], so, 0));
+#else
+            e1[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1r, lo[i], so, 0));
+            e2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2r, lo[i], so, 0));
+#endif
+        }
+        float w_[6][4];                                           // columns transformed: w_[xi][j]
+#pragma unroll
+        for (int x = 0; x < 6; ++x)
+            w4_at(acc[6 * x][r], acc[6 * x + 1][r], acc[6 * x + 2][r], acc[6 * x + 3][r], acc[6 * x + 4][r], acc[6 * x + 5][r],
+                  w_[x][0], w_[x][1], w_[x][2], w_[x][3]);
+        float y[4][4];
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx)
+            w4_at(w_[0][jx], w_[1][jx], w_[2][jx], w_[3][jx], w_[4][jx], w_[5][jx], y[0][jx], y[1][jx], y[2][jx], y[3][jx]);
+#if W4_DBG & 32768
+        if (r == 0) asm volatile("s_sleep 24" ::: "memory");          // debug: the delay moved behind the first reads of the accumulators
+#endif
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 o;
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) o[jx] = fmaxf(fmaf(y[i][jx], sc, sh), relu_lo);
+            o += e1[i];
+            o += e2[i];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yr, lo[i], so, WT ? 16 : 0);
+#if W4_DBG & 2
+            asm volatile("s_nop 7\n s_nop 7" ::: "memory");
+#endif
+        }
+    }
+}
+
+static void* g_w4_dbg = nullptr;
+extern "C" void ic_wino4_debug_set_buffer(void* p) { g_w4_dbg = p; }
+
+extern "C" int ic_wino4_3x3_c128_supported(int N, int H, int W) {
+    return N > 0 && H > 0 && W > 0 && (W & 3) == 0 && (long long)WN_C * H * W * 4 < (1ll << 31);
+}
+
+// work-groups of a launch: (segments of 16 tiles) x 2 channel halves, two per CU
+extern "C" long long ic_wino4_3x3_c128_workgroups(int N, int H, int W) {
+    if (!ic_wino4_3x3_c128_supported(N, H, W)) return 0;
+    return (W4_WAVES == 8 ? 1ll : 2ll) * N * ic_cdiv(H, 4) * ic_cdiv(W, 64);
+}
+
+extern "C" int ic_wino4_3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
+                                            const float* res1, const float* res2, float* y, int N, int H, int W, int relu,
+                                            int flags, ic_stream_t stream) {
+    IC_CHECK_ARG(x && w_packed && scale && shift && y);
+    IC_CHECK_ARG(N > 0 && H > 0 && W > 0);
+    if (!ic_wino4_3x3_c128_supported(N, H, W)) return IC_ERR_UNSUPPORTED;
+    WnArgs a{};
+    a.x = x; a.wp = w_packed; a.scale = scale; a.shift = shift; a.res1 = res1; a.res2 = res2; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.relu = relu;
+    a.grows = ic_cdiv(H, 4); a.gcols = ic_cdiv(W, 64); a.xcd_runs = (flags & IC_CONV3_NO_XCD_RUNS) ? 0 : 1;
+    a.g0 = 0; a.ngroups = N * a.grows * a.gcols;
+    a.prof = (unsigned long long*)g_w4_dbg;
+    hipStream_t st = (hipStream_t)stream;
+#if W4_WAVES == 8
+    const long long wgs = a.ngroups;
+    if (wgs <= 256) hipLaunchKernelGGL((wino4_3x3_c128_kernel<true, 8>), dim3((unsigned)wgs), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((wino4_3x3_c128_kernel<false, 8>), dim3((unsigned)wgs), dim3(512), 0, st, a);
+#else
+    const long long wgs = 2ll * a.ngroups;
+    if (wgs <= 512) hipLaunchKernelGGL((wino4_3x3_c128_kernel<true, 4>), dim3((unsigned)wgs), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wino4_3x3_c128_kernel<false, 4>), dim3((unsigned)wgs), dim3(256), 0, st, a);
+#endif
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}

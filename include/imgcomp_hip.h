@@ -440,6 +440,20 @@ int ic_peer_allreduce_f64_bounded(double* vals, int n, void* const* regions_host
                                   unsigned spin_limit, int* status, ic_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The same 3x3 128 -> 128 layer (autoencoder.py:274-287) in Winograd F(4x4,3x3) form (csrc/conv3x3_wino4.hip): 36 / 144 of the
+ * direct form's multiplies.  W % 4 == 0 (ic_wino4_3x3_c128_supported); filters packed by ic_pack_wino4_3x3_c128_f32
+ * (36 x 128 x 128 floats; backward = 1: the adjoint filter of the data gradient).  Same epilogue contract as
+ * ic_wino3x3_c128_bn_act_f32: y = act(conv * scale + shift) + res1 + res2.
+ * --------------------------------------------------------------------------------------------- */
+size_t ic_wino4_3x3_c128_packed_floats(void);
+int ic_pack_wino4_3x3_c128_f32(const float* w_tf, float* w_packed, int backward, ic_stream_t stream);
+int ic_wino4_3x3_c128_supported(int N, int H, int W);
+long long ic_wino4_3x3_c128_workgroups(int N, int H, int W);
+int ic_wino4_3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
+                                 const float* res1, const float* res2, float* y, int N, int H, int W, int relu,
+                                 int flags, ic_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * MS-SSIM training distortion and its gradient (csrc/msssim.hip).  Reference: code/ms_ssim.py:3-186 (5 scales, separable
  * Gaussian 'VALID' blur with REFLECT pads on small scales, 2x2 box between scales), train.py:352-394
  * (d_loss_scaled = K_ms_ssim * (1 - MS-SSIM(x, x_out)); TensorFlow derives d / d x_out, here it is written out).
