@@ -347,8 +347,8 @@ def main():
             else:
                 ms = ms_alone
             flop_direct = CONV3_FLOP_PER_OUT_PX * N * h4 * w4
-            wino = lib.ic_conv3x3_c128_pick_algo(N, h4, w4, flags) == 1
-            executed = flop_direct * (16.0 / 36.0 if wino else 1.0)
+            form = lib.ic_conv3x3_c128_pick_form(N, h4, w4, flags)
+            executed = flop_direct * {0: 1.0, 1: 16.0 / 36.0, 2: 36.0 / 144.0}[form]
             plan = plan_name(lib, _lib, N, h4, w4, flags)
             ent = {'avg_launch_us': round(ms * 1e3, 2), 'layers_timed': nl, 'stacks_in_flight': n_flight,
                    'achieved': round(executed / (ms * 1e-3) / 1e12, 2),
@@ -385,7 +385,8 @@ def main():
         elif counters:
             traffic_src = 'dropped: {} describes shape {} / 3x3 kernel {}, this run is {} / {}'.format(
                 counters.get('file'), counters.get('input_shape'), counters.get('plan_3x3'), [N, 3, H, Wd], k3)
-        wino = lib.ic_conv3x3_c128_pick_algo(N, h4, w4, step_flags) == 1
+        form3 = lib.ic_conv3x3_c128_pick_form(N, h4, w4, step_flags)
+        wino = form3 != 0
         from_profiles = None
         if counters and k3 in counters.get('kernels', {}) and counters.get('input_shape') == [N, 3, H, Wd]:
             # the same fractions recomputed from the TRACKED rocprofv3 files alone (no number of this run in them): the launch's
@@ -408,12 +409,12 @@ def main():
                                      'traces under profiles/ (alone: one image at a time; in flight: the shipped schedule under the tracer, '
                                      'which overlaps streams less than the untraced run `frac` is measured on)'}
         roofline = {'kernel': enc_l['plan']['kernel'] + ' (ic_conv3x3_c128_auto_f32, encoder residual stack, in-step)',
-                    'algorithm': 'winograd F(2x2,3x3)' if wino else 'direct', 'bound': 'mfma',
+                    'algorithm': {0: 'direct', 1: 'winograd F(2x2,3x3)', 2: 'winograd F(4x4,3x3)'}[form3], 'bound': 'mfma',
                     'achieved': enc_l['achieved'], 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': enc_l['frac'],
                     'traffic': traffic, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': traffic_src,
-                    'algorithmic_bytes_per_launch': int(3 * 512 * N * h4 * w4 + (1048576 if wino else 589824)),
+                    'algorithmic_bytes_per_launch': int(3 * 512 * N * h4 * w4 + {0: 589824, 1: 1048576, 2: 2359296}[form3]),
                     'launches_per_step': 2 * (6 * int(ae_cfg.arch_param_B) + 2),
-                    'note': 'achieved = FLOPs the matrix pipe executes (Winograd: 16/36 of the direct form) / the time in which the chip '
+                    'note': 'achieved = FLOPs the matrix pipe executes (Winograd F(2x2): 16/36 of the direct form, F(4x4): 36/144) / the time in which the chip '
                             'completes one launch of the stack: HIP events around {} stacks in flight, one per stream, as in the step; '
                             '`encoder.alone` = the same launch with nothing beside it (its duration in a kernel trace, on plan.cus of 256 CUs)'.format(n_flight),
                     'from_profiles': from_profiles, 'encoder': enc_l, 'decoder': dec_l}
@@ -454,7 +455,9 @@ def main():
             dt1, _ = run(ps, 30, 5)
             sch = InFlight(torch, ps, dev, n_flight, a.ae_config, rank, graphs=bool(a.graphs)) if n_flight > 1 else ps
             dt, _ = run(sch, 30, 5) if n_flight > 1 else (dt1, None)
-            flop = n2 * h2 * w2 * (FLOP_PER_PX_ENC * 16.0 / 36.0 + FLOP_PER_PX_DEC * 16.0 / 36.0)
+            # executed FLOPs: the 64 3x3 layers (589,824 FLOP per input pixel and network half) in the form the plan runs, the 5x5 layers direct
+            f3 = {0: 1.0, 1: 16.0 / 36.0, 2: 36.0 / 144.0}[lib.ic_conv3x3_c128_pick_form(n2, h2 // 4, w2 // 4, (_lib.CONV3_IN_FLIGHT(n_flight) if n_flight > 1 else 0))]
+            flop = n2 * h2 * w2 * (2 * 589824.0 * f3 + (FLOP_PER_PX_ENC - 589824.0) + (FLOP_PER_PX_DEC - 589824.0))
             shapes.append({'batch': n2, 'height': h2, 'width': w2, 'value': round(n2 * h2 * w2 * 30 / dt / 1e6, 3), 'unit': 'Mpix/s',
                            'ms_per_step': round(dt / 30 * 1e3, 4), 'images_in_flight': n_flight,
                            'one_image_at_a_time': {'value': round(n2 * h2 * w2 * 30 / dt1 / 1e6, 3), 'ms_per_step': round(dt1 / 30 * 1e3, 4)},
@@ -624,8 +627,12 @@ def max_over_ranks(torch, dist, elapsed, dev, world, backend):
 
 def plan_name(lib, _lib, N, h4, w4, flags):
     """which kernel(s) ic_conv3x3_c128_auto_f32 launches for this shape and these flags (the library's own plan query)."""
-    if lib.ic_conv3x3_c128_pick_algo(N, h4, w4, flags) != 1:
-        return {'kernel': 'conv3x3_c128_kernel', 'cus': 256}
+    form = lib.ic_conv3x3_c128_pick_form(N, h4, w4, flags)
+    if form == 0:
+        return {'kernel': 'conv3x3_c128_kernel', 'cus': 256, 'form': 'direct'}
+    if form == 2:
+        wgs = int(lib.ic_wino4_3x3_c128_workgroups(N, h4, w4))
+        return {'kernel': 'wino4_3x3_c128_kernel', 'cus': min(256, (wgs + 1) // 2), 'form': 'winograd F(4x4,3x3)', 'work_groups': wgs}
     pl = (ctypes.c_longlong * 5)()
     _lib.check(lib.ic_wino3x3_c128_plan(N, h4, w4, flags, pl))
     names = []

@@ -23,6 +23,8 @@ CONV3_FORM_MASK = 0x0f
 CONV3_AUTO, CONV3_DIRECT, CONV3_WINO, CONV3_WINO_WHOLEK, CONV3_WINO_WHOLEK_PW = 0, 1, 2, 3, 4
 CONV3_WINO_KSPLIT, CONV3_WINO_T16, CONV3_WINO_SEG1, CONV3_WINO_SEG2, CONV3_WINO_SEG3 = 5, 6, 7, 8, 9
 CONV3_WINO_PAIR = 10
+CONV3_WINO4 = 11                    # Winograd F(4x4,3x3)
+CONV3_NO_WINO4 = 0x800000
 CONV3_LEAVE_IDLE_CUS = 0x10
 CONV3_NO_XCD_RUNS = 0x20
 CONV3_PACKED_TRANSFORM = 0x40
@@ -108,6 +110,7 @@ PROTOTYPES = {
     'ic_peer_region_destroy': (c_int, [c_void_p]),
     'ic_peer_allreduce_f64': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_uint32, c_void_p, c_void_p]),
     'ic_build_has_tuning_forms': (c_int, []),
+    'ic_conv3x3_c128_pick_form': (c_int, [c_int, c_int, c_int, c_int]),
     'ic_wino4_3x3_c128_packed_floats': (c_size_t, []),
     'ic_pack_wino4_3x3_c128_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     'ic_wino4_3x3_c128_supported': (c_int, [c_int, c_int, c_int]),

@@ -1027,13 +1027,17 @@ extern "C" int ic_wino3x3_c128_bn_act_f32(const float* x, const float* w_packed,
 // blob = [direct-form fragments (ic_conv3x3_c128_packed_floats) | Winograd fragments (2 x 16 x 128 x 128)].
 // The form is picked per launch: Winograd whenever the shape is addressable with 31-bit offsets, the direct kernel
 // otherwise or on request (flags & IC_CONV3_FORM_MASK == IC_CONV3_DIRECT).
-extern "C" size_t ic_conv3x3_c128_both_packed_floats(void) { return ic_conv3x3_c128_packed_floats() + WN_PACKED_FLOATS; }
+// blob = [direct-form fragments | F(2x2) fragments (2 x 16 x 128 x 128) | F(4x4) fragments (36 x 128 x 128)]
+extern "C" size_t ic_conv3x3_c128_both_packed_floats(void) {
+    return ic_conv3x3_c128_packed_floats() + WN_PACKED_FLOATS + ic_wino4_3x3_c128_packed_floats();
+}
 
 extern "C" int ic_pack_conv3x3_c128_both_f32(const float* w_tf, float* w_packed, int backward, ic_stream_t stream) {
     IC_CHECK_ARG(w_tf && w_packed);
     int rc = backward ? ic_pack_conv3x3_c128_bwd_f32(w_tf, w_packed, stream) : ic_pack_conv3x3_c128_f32(w_tf, w_packed, stream);
     if (rc) return rc;
-    return ic_pack_wino3x3_c128_f32(w_tf, w_packed + ic_conv3x3_c128_packed_floats(), backward, stream);
+    if ((rc = ic_pack_wino3x3_c128_f32(w_tf, w_packed + ic_conv3x3_c128_packed_floats(), backward, stream))) return rc;
+    return ic_pack_wino4_3x3_c128_f32(w_tf, w_packed + ic_conv3x3_c128_packed_floats() + WN_PACKED_FLOATS, backward, stream);
 }
 
 extern "C" int ic_conv3x3_c128_pick_algo(int N, int H, int W, int flags) {
@@ -1044,12 +1048,33 @@ extern "C" int ic_conv3x3_c128_pick_algo(int N, int H, int W, int flags) {
     return (flags & IC_CONV3_FORM_MASK) == IC_CONV3_DIRECT ? 0 : 1;
 }
 
+// The form ic_conv3x3_c128_auto_f32 runs: 0 direct, 1 Winograd F(2x2,3x3) (decomposition: ic_wino3x3_c128_plan), 2 Winograd F(4x4,3x3).
+// F(4x4) does 0.5625 of F(2x2)'s matrix work in work-groups of ~31 us: it wins wherever its work-groups (segments of 16 tiles x 2
+// channel halves, two per CU) fill the chip -- a launch of >= 512 of them (4K maps, batches), or several independent launches in
+// flight (IC_CONV3_IN_FLIGHT: the images of an evaluation set); a single Kodak-sized launch (192 work-groups) is faster in the
+// F(2x2) NB-segment form (37 against 47 us).  Measured (tools/wino4_check.py, round 4): 4K map 543 against 662 us, batch 8 of
+// Kodak maps 201 against 245 us.
+extern "C" int ic_conv3x3_c128_pick_form(int N, int H, int W, int flags) {
+    if (ic_conv3x3_c128_pick_algo(N, H, W, flags) == 0) return 0;
+    const int form = flags & IC_CONV3_FORM_MASK;
+    if (form == IC_CONV3_WINO4) return ic_wino4_3x3_c128_supported(N, H, W) ? 2 : 1;
+    if (form != IC_CONV3_AUTO && form != IC_CONV3_WINO) return 1;                  // a particular F(2x2) decomposition was asked for
+    if (!ic_wino4_3x3_c128_supported(N, H, W) || (flags & (IC_CONV3_LEAVE_IDLE_CUS | IC_CONV3_NO_WINO4))) return 1;
+    const long long wgs = ic_wino4_3x3_c128_workgroups(N, H, W);
+    const int in_flight = (flags >> 19) & 0xf;
+    return (wgs >= 512 || (in_flight >= 2 && wgs * in_flight >= 384)) ? 2 : 1;
+}
+
 extern "C" int ic_conv3x3_c128_auto_f32(const float* x, const float* w_both, const float* scale, const float* shift,
                                         const float* res1, const float* res2, float* y, int N, int H, int W, int relu,
                                         int flags, ic_stream_t stream) {
     IC_CHECK_ARG(x && w_both && scale && shift && y && N > 0 && H > 0 && W > 0);
-    if (ic_conv3x3_c128_pick_algo(N, H, W, flags) == 1)
+    const int form = ic_conv3x3_c128_pick_form(N, H, W, flags);
+    if (form == 2)
+        return ic_wino4_3x3_c128_bn_act_f32(x, w_both + ic_conv3x3_c128_packed_floats() + WN_PACKED_FLOATS, scale, shift, res1, res2, y,
+                                            N, H, W, relu, flags, stream);
+    if (form == 1)
         return ic_wino3x3_c128_bn_act_f32(x, w_both + ic_conv3x3_c128_packed_floats(), scale, shift, res1, res2, y, N, H, W,
-                                          relu, flags, stream);
+                                          relu, flags & ~IC_CONV3_WINO4_BITS, stream);
     return ic_conv3x3_c128_bn_act_f32(x, w_both, scale, shift, res1, res2, y, N, H, W, relu, flags, stream);
 }

@@ -31,7 +31,7 @@
 #define W4_PACKED_FLOATS (36 * WN_C * WN_C)
 #define W4_ACC_A 32                                 // accumulators (of 36) kept in AGPRs
 #ifndef W4_WAVES
-#define W4_WAVES 8                                  // waves per work-group: 8 = all 128 output channels of a segment
+#define W4_WAVES 4                                  // waves per work-group: 8 = all 128 output channels of a segment
 #endif
 #ifndef W4_RB
 #define W4_RB 3                                     // B-operand ring, in quads (36 % W4_RB == 0)
@@ -46,16 +46,18 @@
 #define W4_ABL 0                                    // tuning builds: 1 no transform turns in the loop, 2 no filter requests, 4 no B reads
 #endif
 #ifndef W4_GAP
-#define W4_GAP 0                                    // quads between a turn's patch request and its transform
+#define W4_GAP 3                                    // quads between a turn's patch request and its transform
 #endif
 #ifndef W4_STAGGER
-#define W4_STAGGER 1
+#define W4_STAGGER 0
 #endif
 #ifndef W4_TURN
 #define W4_TURN 6
 #endif
 //                                                 // quad of an iteration at which a wave transforms its k-step of the next one
-#define W4_RA 4                                     // filter-fragment ring, in quads (36 % W4_RA == 0)
+#ifndef W4_RA
+#define W4_RA 6                                     // filter-fragment ring, in quads (36 % W4_RA == 0)
+#endif
 
 // ---- filter transform + packing: U = G g Gt in float64, rounded once -------------------------------------------------------
 // packed float index: (((cot * 32 + ks) * 9 + p / 4) * 64 + lane) * 4 + p % 4, cot = co / 16, ks = ci / 4, lane = (ci & 3) * 16 + (co & 15),
@@ -134,6 +136,9 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
     __shared__ f32x4 ring[2 * 4 * W4_QUADS * 64 + 1024];          // > 80 KB: one work-group per CU (debug)
 #else
     __shared__ f32x4 ring[2 * 4 * W4_QUADS * 64];                 // [half][k-step of the iteration][position quad][lane]: 72 KB
+#endif
+#if W4_DBG & 65536
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, n16 = lane & 15, kq = lane >> 4;
@@ -273,6 +278,9 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
         }
     }
 #else
+#if W4_DBG & 65536
+    const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
+#endif
     // One iteration = 4 k-steps = 36 quads of 4 MFMAs.  Per quad, IN THIS ORDER: its 4 MFMAs, then the request of the filter
     // fragments W4_RA - 1 quads ahead into the ring slot the PREVIOUS quad consumed, then the B operands two quads ahead into the
     // slot the previous quad consumed: a register is overwritten by a load issued at least 4 MFMAs after its last reader.
@@ -319,6 +327,9 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
 #endif
         }
     }
+#endif
+#if W4_DBG & 65536
+    const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
 #endif
     // inline asm is opaque to the hazard recogniser: pad the last MFMAs' latency, then pass every accumulator through an empty
     // volatile asm so that no read of it can be scheduled above the pad (conv3x3_wino_tn.hip found that the hard way)
@@ -370,22 +381,29 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
         lo[i] = (col_ok_e && oy < H) ? (unsigned)((4 * kq_e * HW + oy * W + 4 * tx_e) * 4) : WN_OOB;
     }
     const float relu_lo = a.relu ? 0.f : -__builtin_inff();
+    // BN scale / shift of the lane's four channels and the first channel's residual rows are requested before anything is
+    // computed; residual 1 of channel r + 1 is requested before channel r is finished (most layers have one residual or none:
+    // conv1 of a block has none, conv2 has the block input, every third block and the stack's end add a second one, which is
+    // fetched inside its channel's turn).  An absent residual is a zero-record descriptor: the load returns 0 without a memory access.
+    float scv[4], shv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { scv[r] = a.scale[16 * cot + 4 * kq_e + r]; shv[r] = a.shift[16 * cot + 4 * kq_e + r]; }
+    f32x4 e1n[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e1n[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1r, lo[i], 16 * cot * HW * 4, 0));
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int co = 16 * cot + r;                              // + 4 kq: in the lane offset (4 kq HW) and the scale pointer below
-        const float sc = a.scale[co + 4 * kq_e], sh = a.shift[co + 4 * kq_e];
+        const int co = 16 * cot + r;                              // + 4 kq: in the lane offset (4 kq HW)
         const int so = co * HW * 4;
         f32x4 e1[4], e2[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-#if W4_DBG & 1
-            e1[i] = f32x4{0.f, 0.f, 0.f, 0.f}; e2[i] = e1[i];
-            if (a.res1) e1[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1r, lo[i], so, 0));
-            if (a.res2) e2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2r, lo[i], so, 0));
-#else
-            e1[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1r, lo[i], so, 0));
+            e1[i] = e1n[i];
             e2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2r, lo[i], so, 0));
-#endif
+        }
+        if (r + 1 < 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) e1n[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1r, lo[i], so + HW * 4, 0));
         }
         float w_[6][4];                                           // columns transformed: w_[xi][j]
 #pragma unroll
@@ -396,26 +414,30 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
 #pragma unroll
         for (int jx = 0; jx < 4; ++jx)
             w4_at(w_[0][jx], w_[1][jx], w_[2][jx], w_[3][jx], w_[4][jx], w_[5][jx], y[0][jx], y[1][jx], y[2][jx], y[3][jx]);
-#if W4_DBG & 32768
-        if (r == 0) asm volatile("s_sleep 24" ::: "memory");          // debug: the delay moved behind the first reads of the accumulators
-#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             f32x4 o;
 #pragma unroll
-            for (int jx = 0; jx < 4; ++jx) o[jx] = fmaxf(fmaf(y[i][jx], sc, sh), relu_lo);
+            for (int jx = 0; jx < 4; ++jx) o[jx] = fmaxf(fmaf(y[i][jx], scv[r], shv[r]), relu_lo);
             o += e1[i];
             o += e2[i];
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yr, lo[i], so, WT ? 16 : 0);
-#if W4_DBG & 2
-            asm volatile("s_nop 7\n s_nop 7" ::: "memory");
-#endif
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
+#if W4_DBG & 65536
+    if (a.prof && (threadIdx.x & 63) == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* d = a.prof + 4 * ((size_t)blockIdx.x * WAVES + (threadIdx.x >> 6));
+        d[0] = t_loop0 - t_entry; d[1] = t_loop1 - t_loop0; d[2] = __builtin_amdgcn_s_memtime() - t_loop1; d[3] = t_entry;
+    }
+#endif
 }
 
+#if W4_DBG & (256 | 65536)
 static void* g_w4_dbg = nullptr;
 extern "C" void ic_wino4_debug_set_buffer(void* p) { g_w4_dbg = p; }
+#endif
 
 extern "C" int ic_wino4_3x3_c128_supported(int N, int H, int W) {
     return N > 0 && H > 0 && W > 0 && (W & 3) == 0 && (long long)WN_C * H * W * 4 < (1ll << 31);
@@ -438,7 +460,9 @@ extern "C" int ic_wino4_3x3_c128_bn_act_f32(const float* x, const float* w_packe
     a.N = N; a.H = H; a.W = W; a.relu = relu;
     a.grows = ic_cdiv(H, 4); a.gcols = ic_cdiv(W, 64); a.xcd_runs = (flags & IC_CONV3_NO_XCD_RUNS) ? 0 : 1;
     a.g0 = 0; a.ngroups = N * a.grows * a.gcols;
+#if W4_DBG & (256 | 65536)
     a.prof = (unsigned long long*)g_w4_dbg;
+#endif
     hipStream_t st = (hipStream_t)stream;
 #if W4_WAVES == 8
     const long long wgs = a.ngroups;

@@ -58,6 +58,9 @@ typedef void* ic_stream_t;
 #define IC_CONV3_WINO_PAIR        0x0a   /* tile group x 32 channels per work-group, waves split the 16 positions, two work-groups per CU
                                             (even widths; conv3x3_wino_tp.hip).  ic_wino3x3_c128_plan reports it as segment jobs with nb = -1.
                                             TUNING builds only */
+#define IC_CONV3_WINO4            0x0b   /* Winograd F(4x4,3x3) (conv3x3_wino4.hip; W % 4 == 0, else the F(2x2) plan) */
+#define IC_CONV3_NO_WINO4         0x800000   /* automatic plan: F(2x2) forms only (A/B runs, bit-identity tests between F(2x2) forms) */
+#define IC_CONV3_WINO4_BITS       0          /* (no flag bits of its own besides the form) */
 /* IC_CONV3_WINO_T16, IC_CONV3_WINO_PAIR and IC_CONV3_STACK_KERNEL name forms that were built, tested bit-identical and measured
  * slower than or level with what the plan picks.  The shipped library does not carry them (`make TUNING=1` does):
  * ic_build_has_tuning_forms() tells, forcing T16 / PAIR without them returns IC_ERR_UNSUPPORTED, IC_CONV3_STACK_KERNEL is ignored. */
@@ -445,6 +448,9 @@ int ic_peer_allreduce_f64_bounded(double* vals, int n, void* const* regions_host
  * (36 x 128 x 128 floats; backward = 1: the adjoint filter of the data gradient).  Same epilogue contract as
  * ic_wino3x3_c128_bn_act_f32: y = act(conv * scale + shift) + res1 + res2.
  * --------------------------------------------------------------------------------------------- */
+/* the form ic_conv3x3_c128_auto_f32 (and with it the whole-network entry points) runs for a shape and flags:
+ * 0 direct, 1 Winograd F(2x2,3x3), 2 Winograd F(4x4,3x3) */
+int ic_conv3x3_c128_pick_form(int N, int H, int W, int flags);
 size_t ic_wino4_3x3_c128_packed_floats(void);
 int ic_pack_wino4_3x3_c128_f32(const float* w_tf, float* w_packed, int backward, ic_stream_t stream);
 int ic_wino4_3x3_c128_supported(int N, int H, int W);
