@@ -632,7 +632,7 @@ def plan_name(lib, _lib, N, h4, w4, flags):
         return {'kernel': 'conv3x3_c128_kernel', 'cus': 256, 'form': 'direct'}
     if form == 2:
         wgs = int(lib.ic_wino4_3x3_c128_workgroups(N, h4, w4))
-        return {'kernel': 'wino4_3x3_c128_kernel', 'cus': min(256, (wgs + 1) // 2), 'form': 'winograd F(4x4,3x3)', 'work_groups': wgs}
+        return {'kernel': 'wino4_3x3_c128_kernel', 'cus': min(256, wgs), 'form': 'winograd F(4x4,3x3)', 'work_groups': wgs}
     pl = (ctypes.c_longlong * 5)()
     _lib.check(lib.ic_wino3x3_c128_plan(N, h4, w4, flags, pl))
     names = []

@@ -7,13 +7,13 @@
 // error against the float64 oracle as with the direct form or F(2x2) -- z 1.1-1.6e-5, x_out 3e-7 of the tensor scale, no symbol
 // flips: the network's error is set by its other parts, the larger transform constants do not show.  (Round 2 had rejected the
 // form by scaling the device's whole-network error with a per-layer factor; the per-layer factor does not carry through
-// BatchNorm + skips.)
+// BatchNorm + skips.)  One layer alone: 4-8e-6 of the tensor scale against 3-5e-7 for F(2x2) (tests/test_gpu_ops.py, bound 2e-5).
 //
 // Layout on a gfx950 wave, v_mfma_f32_16x16x4_f32 (D[16 x 16] += A[16 x 4] B[4 x 16]):
 //   * M axis = 16 output channels, N axis = 16 tiles (a SEGMENT: 16 horizontally adjacent tiles = 4 x 64 output pixels),
 //     K = 4 input channels.  Lane l = (tile n = l & 15, k = l >> 4): ONE 6x6 patch transform per lane yields its B operands of
-//     all 36 positions of a k-step; a wave owns 16 channels x 16 tiles x 36 positions = 36 accumulators of 4 registers = 144 AGPRs
-//     (a 32 x 32 tile would need 576), so TWO work-groups fit a CU and each SIMD always has a second wave to issue from.
+//     all 36 positions of a k-step; a wave owns 16 channels x 16 tiles x 36 positions = 36 accumulators of 4 registers = 144
+//     registers (a 32 x 32 tile would need 576), so TWO work-groups fit a CU and each SIMD always has a second wave to issue from.
 //   * the output transform At M A is lane-local (same lane, same register index across the 36 accumulators): 4 channels x 4 x 4
 //     pixels per lane, stored as 16-byte runs (a tile row is 4 neighbouring pixels; 16 lanes = 256 contiguous bytes).
 //   * work-group = 4 waves = 4 channel tiles (one HALF of the output channels) of one segment.  Wave w loads and transforms the
@@ -24,39 +24,38 @@
 //     loads per k-step and lane, each 1 KB contiguous across the wave, L2 resident, streamed through a register ring.
 //   * zero padding is done by the memory system (raw buffer loads, out-of-range lane offsets), as in the F(2x2) kernels.
 // Shapes: W % 4 == 0 (aligned 16-byte rows); anything else keeps the F(2x2) forms (ic_conv3x3_c128_auto_f32).
+//
+// Where the time goes (in-kernel shader-clock stamps, make with -DW4_STAMPS, tools/w4prof.py; batch of 8 Kodak-sized maps, two
+// work-groups per CU): prologue 7.8 k clocks, loop 92 k, epilogue 20 k per wave, against 36.9 k clocks of pure MFMA issue for
+// the wave's 1152 instructions (two waves share a SIMD's matrix pipe: 73.7 k for both).  The loop is within 25 % of that; what is
+// left is the 8 transform turns (~200 VALU instructions each, ~2 k clocks) and the filter-fragment waits.
+//
+// BUILD NOTE (csrc/Makefile): this file is compiled with -fno-slp-vectorize.  With the SLP vectoriser's packed fp32 instructions
+// (v_pk_fma_f32 / v_pk_add_f32) in the input transform the kernel returned wrong values in lanes 12..15 of 16-lane rows, a few
+// per 10^7 outputs, never twice in the same place, ONLY when two waves shared a SIMD -- not with one work-group per CU, not with
+// the LDS ring enlarged, not with extra barriers or MFMA drains (tools/w4dbg.py, tools/w4conc.py: ~50 % of launches wrong with,
+// 0 of 75 without).  tests/test_gpu_ops.py::test_conv3x3_c128_winograd_f4_full_load_is_deterministic holds the full-load case.
 #include "wino_common.h"
 #include "internal.h"
 
 #define W4_QUADS 9                                  // 36 positions in quads of 4
 #define W4_PACKED_FLOATS (36 * WN_C * WN_C)
 #define W4_ACC_A 32                                 // accumulators (of 36) kept in AGPRs
+// tuning knobs (defaults = the measured best, round 4: 4 waves, rings 6 / 3, turn at quad 6, transform 3 quads after its request)
 #ifndef W4_WAVES
 #define W4_WAVES 4                                  // waves per work-group: 8 = all 128 output channels of a segment
+#endif
+#ifndef W4_RA
+#define W4_RA 6                                     // filter-fragment ring, in quads (36 % W4_RA == 0)
 #endif
 #ifndef W4_RB
 #define W4_RB 3                                     // B-operand ring, in quads (36 % W4_RB == 0)
 #endif
-#ifndef W4_SLEEP
-#define W4_SLEEP 40
-#endif
-#ifndef W4_DBG
-#define W4_DBG 0
-#endif
-#ifndef W4_ABL
-#define W4_ABL 0                                    // tuning builds: 1 no transform turns in the loop, 2 no filter requests, 4 no B reads
+#ifndef W4_TURN
+#define W4_TURN 6                                   // quad of an iteration at which a wave requests its k-step of the next one
 #endif
 #ifndef W4_GAP
-#define W4_GAP 3                                    // quads between a turn's patch request and its transform
-#endif
-#ifndef W4_STAGGER
-#define W4_STAGGER 0
-#endif
-#ifndef W4_TURN
-#define W4_TURN 6
-#endif
-//                                                 // quad of an iteration at which a wave transforms its k-step of the next one
-#ifndef W4_RA
-#define W4_RA 6                                     // filter-fragment ring, in quads (36 % W4_RA == 0)
+#define W4_GAP 3                                    // quads between that request and the transform
 #endif
 
 // ---- filter transform + packing: U = G g Gt in float64, rounded once -------------------------------------------------------
@@ -132,12 +131,8 @@ __device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, fl
 template <bool WT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void wino4_3x3_c128_kernel(const WnArgs a) {
-#if W4_DBG & 4
-    __shared__ f32x4 ring[2 * 4 * W4_QUADS * 64 + 1024];          // > 80 KB: one work-group per CU (debug)
-#else
     __shared__ f32x4 ring[2 * 4 * W4_QUADS * 64];                 // [half][k-step of the iteration][position quad][lane]: 72 KB
-#endif
-#if W4_DBG & 65536
+#ifdef W4_STAMPS
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -168,13 +163,9 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
     const int obase = (kq * HW + r_first * W + 4 * tx) * 4;
     const int ebase = (kq * HW + r_first * W + ecol) * 4;
     const unsigned fo = (unsigned)lane * 16u;
-    // HW_ID.WAVE_ID bit 0: the slot of this wave on its SIMD (two resident waves: slots 0 and 1)
-    const bool early = WAVES == 8 || !W4_STAGGER || (__builtin_amdgcn_s_getreg(0x1804) & 1) == 0;
 
-    // Accumulators live in AGPRs, tied to the MFMA's destination by inline asm (the builtin lets the allocator put the result
-    // into ANOTHER tuple than the addend: the freed addend registers are then handed to the next ds_read / buffer load, and
-    // with two waves per SIMD sharing the matrix pipe that load can land before the queued MFMA has read them -- measured: a
-    // few wrong outputs per 10^7 in lanes 12..15 of each row, only under full load, never twice in the same place).
+    // Accumulators are tied to the MFMA's destination by inline asm: the builtin lets the allocator put the result into ANOTHER
+    // tuple than the addend, which doubles the accumulator footprint for the duration and pushes the rings into scratch.
     f32x4 acc[36];
 #pragma unroll
     for (int p = 0; p < 36; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -242,43 +233,14 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
     };
 
     // ---- prologue: the input of iteration 0, the first filter fragments ----
-#if !(W4_DBG & 16384)
-    if (WAVES == 4 || pgrp == 0 || (W4_DBG & 4096)) load_patch(pw);
+    if (WAVES == 4 || pgrp == 0) load_patch(pw);
 #pragma unroll
     for (int Q = 0; Q < W4_RA - 1; ++Q) load_filter(Q, Q);
-    if (WAVES == 4 || pgrp == 0 || (W4_DBG & 4096)) transform_put(0);
+    if (WAVES == 4 || pgrp == 0) transform_put(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-#endif
 
-#if W4_DBG & 16384
-    // debug: no LDS, no barrier -- every wave loads and transforms every k-step itself
-    for (int ks = 0; ks < 32; ++ks) {
-        load_patch(ks);
-        float u[6][6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            u[i][0] = dpp_from_left(pe[i], pr[i][3]);
-            u[i][5] = dpp_from_right(pe[i], pr[i][0]);
-            u[i][1] = pr[i][0]; u[i][2] = pr[i][1]; u[i][3] = pr[i][2]; u[i][4] = pr[i][3];
-        }
-#pragma unroll
-        for (int j = 0; j < 6; ++j) w4_bt(u[0][j], u[1][j], u[2][j], u[3][j], u[4][j], u[5][j], u[0][j], u[1][j], u[2][j], u[3][j], u[4][j], u[5][j]);
-        float vb[36];
-#pragma unroll
-        for (int x = 0; x < 6; ++x) w4_bt(u[x][0], u[x][1], u[x][2], u[x][3], u[x][4], u[x][5], vb[6 * x], vb[6 * x + 1], vb[6 * x + 2], vb[6 * x + 3], vb[6 * x + 4], vb[6 * x + 5]);
-#pragma unroll
-        for (int q = 0; q < W4_QUADS; ++q) {
-            const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(fr, fo, (cot * 32 * W4_QUADS + ks * W4_QUADS + q) * 1024, 0));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (4 * q + i < W4_ACC_A) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[4 * q + i]) : "v"(f[i]), "v"(vb[4 * q + i]));
-                else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[4 * q + i]) : "v"(f[i]), "v"(vb[4 * q + i]));
-            }
-        }
-    }
-#else
-#if W4_DBG & 65536
+#ifdef W4_STAMPS
     const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
 #endif
     // One iteration = 4 k-steps = 36 quads of 4 MFMAs.  Per quad, IN THIS ORDER: its 4 MFMAs, then the request of the filter
@@ -297,71 +259,35 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
                 const int Q = j * 36 + lq;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    if ((W4_DBG & 8192) && 4 * q + i >= W4_ACC_A) continue;      // debug: no MFMA on the VGPR-resident accumulators
                     if (4 * q + i < W4_ACC_A) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[4 * q + i]) : "v"(fa[lq % W4_RA][i]), "v"(bq[lq % W4_RB][i]));
                     else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[4 * q + i]) : "v"(fa[lq % W4_RA][i]), "v"(bq[lq % W4_RB][i]));
                 }
-                if (!(W4_ABL & 2)) load_filter((lq + W4_RA - 1) % W4_RA, Q + W4_RA - 1);      // 36 % W4_RA == 0: the slot depends on lq only
-                if (lq + 2 < 36 && !(W4_ABL & 4))
+                load_filter((lq + W4_RA - 1) % W4_RA, Q + W4_RA - 1);      // 36 % W4_RA == 0: the slot depends on lq only
+                if (lq + 2 < 36)
                     bq[(lq + 2) % W4_RB] = ring[((u2 * 4 + (lq + 2) / W4_QUADS) * W4_QUADS + (lq + 2) % W4_QUADS) * 64 + lane];
-                if (!(W4_ABL & 1)) {
-                    // the wave's own k-step of the NEXT iteration: requested, transformed and written into the other half in one go
-                    // (a patch kept in registers across a dozen quads spills: 144 accumulators leave ~110 registers); the two waves a
-                    // SIMD holds (one of each resident work-group) take their turns half an iteration apart
-                    const bool mine = WAVES == 4 || (W4_DBG & 4096) || ((u2 ^ 1) == pgrp);         // iteration j + 1 has the parity of half u2 ^ 1
-                    if (lq == W4_TURN && j + 1 < 8 && early && mine) load_patch(4 * (j + 1) + pw);
-                    if (lq == W4_TURN + W4_GAP && j + 1 < 8 && early && mine) transform_put(u2 ^ 1);
-                    if (lq == W4_TURN + 18 && j + 1 < 8 && !early && mine) load_patch(4 * (j + 1) + pw);
-                    if (lq == W4_TURN + 18 + W4_GAP && j + 1 < 8 && !early && mine) transform_put(u2 ^ 1);
-                }
+                // the wave's own k-step of the NEXT iteration: requested, then W4_GAP quads later transformed and written into the
+                // other half (a patch kept in registers for longer spills: 144 accumulators + rings leave ~50 registers)
+                const bool mine = WAVES == 4 || ((u2 ^ 1) == pgrp);   // iteration j + 1 has the parity of half u2 ^ 1
+                if (lq == W4_TURN && j + 1 < 8 && mine) load_patch(4 * (j + 1) + pw);
+                if (lq == W4_TURN + W4_GAP && j + 1 < 8 && mine) transform_put(u2 ^ 1);
                 __builtin_amdgcn_sched_barrier(0);                // quads stay in program order: the rings are sized for exactly that
             }
-#if W4_DBG & 8
-            __syncthreads();
-#else
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                         // next half complete, this half read by everybody
-#endif
-#if W4_DBG & 16
-            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#endif
         }
     }
-#endif
-#if W4_DBG & 65536
+#ifdef W4_STAMPS
     const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
 #endif
     // inline asm is opaque to the hazard recogniser: pad the last MFMAs' latency, then pass every accumulator through an empty
     // volatile asm so that no read of it can be scheduled above the pad (conv3x3_wino_tn.hip found that the hard way)
-#if W4_DBG & 128
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#elif W4_DBG & 512
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#elif W4_DBG & 2048
-    {   // drain: one MFMA that depends on the last accumulator written (0 * 0 + acc): it cannot issue before that write is done
-        const float zf = 0.f;
-        asm volatile("s_nop 15\n\tv_mfma_f32_16x16x4_f32 %0, %1, %1, %0\n\ts_nop 15\n\ts_nop 15" : "+v"(acc[35]) : "v"(zf));
-        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %1, %0\n\ts_nop 15\n\ts_nop 15" : "+a"(acc[31]) : "v"(zf));
-    }
-#elif W4_DBG & 1024
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_sleep %0\n\ts_nop 15" :: "n"(W4_SLEEP) : "memory");
-#else
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#endif
 #pragma unroll
     for (int p = 0; p < 36; ++p) {
         if (p < W4_ACC_A) asm volatile("" : "+a"(acc[p]));
         else asm volatile("" : "+v"(acc[p]));
     }
 
-#if W4_DBG & 256
-    if (a.prof) {             // debug build: raw accumulators -> a.prof[((work-group * 4 + wave) * 36 + p) * 64 + lane] (4 floats each)
-        f32x4* dbg = (f32x4*)a.prof + ((size_t)(blockIdx.x * WAVES + wave) * 36) * 64 + lane;
-#pragma unroll
-        for (int p = 0; p < 36; ++p) dbg[p * 64] = acc[p];
-    }
-#endif
     // ---- At M A, BN fold, activation, residuals, store: 4 channels x (4 x 4 pixels) per lane ----
     const int img_bytes = WN_C * HW * 4;
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (size_t)n * WN_C * HW), 0, img_bytes, 0x00020000);
@@ -425,7 +351,7 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-#if W4_DBG & 65536
+#ifdef W4_STAMPS
     if (a.prof && (threadIdx.x & 63) == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned long long* d = a.prof + 4 * ((size_t)blockIdx.x * WAVES + (threadIdx.x >> 6));
@@ -434,7 +360,8 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
 #endif
 }
 
-#if W4_DBG & (256 | 65536)
+#ifdef W4_STAMPS
+// stamp builds only (never in the shipped library: tests/test_cpu_host.py checks the export list)
 static void* g_w4_dbg = nullptr;
 extern "C" void ic_wino4_debug_set_buffer(void* p) { g_w4_dbg = p; }
 #endif
@@ -460,7 +387,7 @@ extern "C" int ic_wino4_3x3_c128_bn_act_f32(const float* x, const float* w_packe
     a.N = N; a.H = H; a.W = W; a.relu = relu;
     a.grows = ic_cdiv(H, 4); a.gcols = ic_cdiv(W, 64); a.xcd_runs = (flags & IC_CONV3_NO_XCD_RUNS) ? 0 : 1;
     a.g0 = 0; a.ngroups = N * a.grows * a.gcols;
-#if W4_DBG & (256 | 65536)
+#ifdef W4_STAMPS
     a.prof = (unsigned long long*)g_w4_dbg;
 #endif
     hipStream_t st = (hipStream_t)stream;

@@ -21,14 +21,14 @@ def nets(cuda, configs, syn_weights):
     return ae, pc
 
 
-@pytest.fixture(params=['direct3x3', 'winograd3x3', 'wino_seg3', 'wino_seg2'])
+@pytest.fixture(params=['direct3x3', 'winograd3x3', 'wino_seg3', 'wino_seg2', 'wino4'])
 def algo(request, nets):
     """force one form of the 3x3 layers for the whole network (the default picks per launch from the shape): a per-object
     plan flag that every encode / decode call of THIS autoencoder passes down -- the library has no process-wide switch."""
     from imgcomp_cvpr_amd import _lib
     ae, _ = nets
     ae.plan_flags = {'direct3x3': _lib.CONV3_DIRECT, 'winograd3x3': _lib.CONV3_WINO, 'wino_seg3': _lib.CONV3_WINO_SEG3,
-                     'wino_seg2': _lib.CONV3_WINO_SEG2}[request.param]
+                     'wino_seg2': _lib.CONV3_WINO_SEG2, 'wino4': _lib.CONV3_WINO4}[request.param]
     yield request.param
     ae.plan_flags = 0
 

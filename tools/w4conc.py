@@ -1,3 +1,4 @@
+"""F(4x4) launches of one work-group per CU next to an unrelated kernel stream: does ANY co-resident wave break it? (it does not -- only a second wave of this kernel with packed fp32 ops did)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 exec(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'wino4_check.py')).read().split("torch.set_num_threads(16)")[0])

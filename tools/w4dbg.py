@@ -1,3 +1,4 @@
+"""does the F(4x4) kernel return the same values launch after launch at full load? (the check that found the packed-fp32 failure; N H W from argv as in wino4_check.py)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 exec(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'wino4_check.py')).read().split("torch.set_num_threads(16)")[0])

@@ -1,4 +1,4 @@
-"""in-kernel stamps of the F(4x4) kernel (needs a -DW4_DBG=65536 build): prologue / loop / epilogue shader clocks per wave"""
+"""in-kernel stamps of the F(4x4) kernel (needs a build with -DW4_STAMPS: make -C imgcomp_cvpr_amd/csrc clean all CXXFLAGS+=-DW4_STAMPS): prologue / loop / epilogue shader clocks per wave"""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 exec(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'wino4_check.py')).read().split("torch.set_num_threads(16)")[0])
