@@ -1049,11 +1049,15 @@ extern "C" int ic_conv3x3_c128_pick_algo(int N, int H, int W, int flags) {
 }
 
 // The form ic_conv3x3_c128_auto_f32 runs: 0 direct, 1 Winograd F(2x2,3x3) (decomposition: ic_wino3x3_c128_plan), 2 Winograd F(4x4,3x3).
-// F(4x4) does 0.5625 of F(2x2)'s matrix work in work-groups of ~31 us: it wins wherever its work-groups (segments of 16 tiles x 2
-// channel halves, two per CU) fill the chip -- a launch of >= 512 of them (4K maps, batches), or several independent launches in
-// flight (IC_CONV3_IN_FLIGHT: the images of an evaluation set); a single Kodak-sized launch (192 work-groups) is faster in the
-// F(2x2) NB-segment form (37 against 47 us).  Measured (tools/wino4_check.py, round 4): 4K map 543 against 662 us, batch 8 of
-// Kodak maps 201 against 245 us.
+// F(4x4) executes 0.5625 of F(2x2)'s multiplies; it is chosen where TWO of its work-groups per CU are resident (each SIMD then has a
+// second wave to issue from while one waits for its 2.36 MB of filter fragments -- 2.25 x F(2x2)'s, and cold in L2 at every layer
+// of a network: 64 layers x 2.36 MB):
+//   * a launch of >= 512 work-groups (N >= 3 Kodak maps, a 4K map: 426 against 622 us; 8 Kodak maps 175 against 242 us), or
+//   * several independent launches in flight (IC_CONV3_IN_FLIGHT: the images of an evaluation set) with >= 384 work-groups together;
+//   * and only where the map fills its 16-tile segments: 30 maps of 20 x 20 (the training crops: 5 of 16 tiles per segment) take
+//     42.8 against 31.5 us.
+// One Kodak map alone (192 work-groups, one per CU) is 29.4 against 32.8 us in a loop over ONE layer (tools/w4sweep.py) but loses in
+// the network, where every layer brings new filters: 2.85 against 2.47 ms per image one at a time (bench.py, round 4).
 extern "C" int ic_conv3x3_c128_pick_form(int N, int H, int W, int flags) {
     if (ic_conv3x3_c128_pick_algo(N, H, W, flags) == 0) return 0;
     const int form = flags & IC_CONV3_FORM_MASK;
@@ -1061,6 +1065,8 @@ extern "C" int ic_conv3x3_c128_pick_form(int N, int H, int W, int flags) {
     if (form != IC_CONV3_AUTO && form != IC_CONV3_WINO) return 1;                  // a particular F(2x2) decomposition was asked for
     if (!ic_wino4_3x3_c128_supported(N, H, W) || (flags & (IC_CONV3_LEAVE_IDLE_CUS | IC_CONV3_NO_WINO4))) return 1;
     const long long wgs = ic_wino4_3x3_c128_workgroups(N, H, W);
+    const long long tiles = (long long)N * ic_cdiv(H, 4) * ic_cdiv(W, 4);
+    if (tiles * 10 < wgs * 8 * 7) return 1;                                       // segments less than 70 % full (16 tiles x 2 halves per segment)
     const int in_flight = (flags >> 19) & 0xf;
     return (wgs >= 512 || (in_flight >= 2 && wgs * in_flight >= 384)) ? 2 : 1;
 }

@@ -55,8 +55,17 @@
 #define W4_TURN 6                                   // quad of an iteration at which a wave requests its k-step of the next one
 #endif
 #ifndef W4_GAP
-#define W4_GAP 3                                    // quads between that request and the transform
+#define W4_GAP 5                                    // quads between that request and the transform
 #endif
+#ifndef W4_PRE_N
+#define W4_PRE_N 2                                  // channels whose residual 1 is requested that early (the other of the first two: at the epilogue's start)
+#endif
+#ifndef W4_PRE
+#define W4_PRE 31                                   // quad of the LAST iteration at which the epilogue's first operands are requested (-1: in the epilogue)
+#endif
+#ifndef W4_SPREAD
+#define W4_SPREAD 1                                 // 1: the transform of a turn is cut into 26 pieces of 6 vector instructions, two per
+#endif                                              //    quad, each behind an MFMA (whose 8 passes hide them); 0: one block of ~200
 
 // ---- filter transform + packing: U = G g Gt in float64, rounded once -------------------------------------------------------
 // packed float index: (((cot * 32 + ks) * 9 + p / 4) * 64 + lane) * 4 + p % 4, cot = co / 16, ks = ci / 4, lane = (ci & 3) * 16 + (co & 15),
@@ -128,7 +137,7 @@ __device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, fl
 // WAVES = 4: a work-group is one HALF of the output channels of a segment, two work-groups per CU.
 // WAVES = 8: a work-group is ALL 128 output channels of a segment (one per CU): the input transform is made once per segment
 //            instead of once per half -- waves 0..3 produce the k-steps of the even iterations, waves 4..7 those of the odd ones.
-template <bool WT, int WAVES>
+template <bool WT, int WAVES, bool RES2>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void wino4_3x3_c128_kernel(const WnArgs a) {
     __shared__ f32x4 ring[2 * 4 * W4_QUADS * 64];                 // [half][k-step of the iteration][position quad][lane]: 72 KB
@@ -225,11 +234,87 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    // The same transform cut into pieces for the loop (W4_SPREAD): slice k = 0 .. 12 of a turn, two parts each, a part = 6 vector
+    // instructions placed directly behind an MFMA -- the matrix pipe works 8 passes (32 clocks) on it, the vector unit is free for 7
+    // instructions of the same wave meanwhile.  As one block the ~200 instructions of a turn stop the wave's MFMA issue for ~2 k
+    // clocks, 8 times per work-group (stamps: loop 75 k clocks with nothing else on the SIMD against 37 k of MFMA issue).
+    //   k = 0: the outer patch columns from the neighbour lanes;  k = 1 .. 6: Bt over columns 0, 5, 1, 2, 3, 4 (in place);
+    //   k = 7 .. 12: Bt over row k - 7, written to the ring as soon as a position quad is complete.
+    // Same operations in the same order per value as transform_put: bit-identical.
+    float su[6][6], sp = 0.f, sq = 0.f, sr = 0.f, se = 0.f, sa = 0.f, sh4 = 0.f, sh5 = 0.f;
+    auto bt_first = [&](float d0, float d1, float d2, float d3, float d4) __attribute__((always_inline)) {
+        sp = fmaf(-4.f, d2, d4); sq = fmaf(-4.f, d1, d3); sr = d4 - d2; se = d3 - d1;
+        sa = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+    };
+    auto bt_second = [&](float d1, float d3, float d5, float& t0, float& t1, float& t2, float& t3, float& t4, float& t5) __attribute__((always_inline)) {
+        const float a5 = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+        t0 = sa; t1 = sp + sq; t2 = sp - sq; t3 = fmaf(2.f, se, sr); t4 = fmaf(-2.f, se, sr); t5 = a5;
+    };
+    auto slice = [&](int k, int part, int half) __attribute__((always_inline)) {
+        if (k == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                if (part == 0) su[i][0] = dpp_from_left(pe[i], pr[i][3]);
+                else { su[i][5] = dpp_from_right(pe[i], pr[i][0]); su[i][1] = pr[i][0]; su[i][2] = pr[i][1]; su[i][3] = pr[i][2]; su[i][4] = pr[i][3]; }
+            }
+        } else if (k <= 6) {
+            const int c = k == 1 ? 0 : (k == 2 ? 5 : k - 2);
+            if (part == 0) bt_first(su[0][c], su[1][c], su[2][c], su[3][c], su[4][c]);
+            else bt_second(su[1][c], su[3][c], su[5][c], su[0][c], su[1][c], su[2][c], su[3][c], su[4][c], su[5][c]);
+        } else {
+            const int x = k - 7;
+            if (part == 0) bt_first(su[x][0], su[x][1], su[x][2], su[x][3], su[x][4]);
+            else {
+                float v[6];
+                bt_second(su[x][1], su[x][3], su[x][5], v[0], v[1], v[2], v[3], v[4], v[5]);
+                f32x4* dst = &ring[((half * 4 + pw) * W4_QUADS + 3 * (x / 2)) * 64 + lane];
+                if ((x & 1) == 0) { dst[0] = f32x4{v[0], v[1], v[2], v[3]}; sh4 = v[4]; sh5 = v[5]; }
+                else { dst[64] = f32x4{sh4, sh5, v[0], v[1]}; dst[128] = f32x4{v[2], v[3], v[4], v[5]}; }
+            }
+        }
+    };
     // filter fragments: quad index Q = ks * 9 + q of this wave's channel tile: 1 KB per quad
     f32x4 fa[W4_RA];
     auto load_filter = [&](int slot, int Q) __attribute__((always_inline)) {       // slot = Q % W4_RA, passed as a constant
-        const int Qc = Q < 32 * W4_QUADS ? Q : 32 * W4_QUADS - 1;
-        fa[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(fr, fo, (cot * 32 * W4_QUADS + Qc) * 1024, 0));
+        fa[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(fr, fo, (cot * 32 * W4_QUADS + Q) * 1024, 0));
+    };
+
+    // Operands of the epilogue, requested while the last iteration still runs (W4_PRE): BN scale / shift of the lane's four channels
+    // and residual 1 of its first TWO channels.  The epilogue then asks for channel r + 2 when channel r is stored: with one
+    // channel ahead (round 4's first version) every channel waited a full memory latency, 4 x ~5 k clocks at full load, stamps:
+    // epilogue 20 k clocks of a wave's 117 k.  An absent residual is a zero-record descriptor: the load returns 0, no memory access.
+    // The lane geometry is derived from the hardware lane id each time (kept alive across the loop it is spilled).
+    const int img_bytes = WN_C * HW * 4;
+    f32x4 e1a[4], e1b[4];
+    float scv[4], shv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { e1a[i] = e1b[i] = f32x4{0.f, 0.f, 0.f, 0.f}; scv[i] = shv[i] = 0.f; }
+    auto epilogue_lanes = [&](unsigned* lo, int& kq_e) __attribute__((always_inline)) {
+        int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane_e));
+        kq_e = lane_e >> 4;
+        const int tx_e = 16 * sx + (lane_e & 15);
+        const bool col_ok_e = 4 * tx_e < W;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int oy = 4 * ty + i;
+            lo[i] = (col_ok_e && oy < H) ? (unsigned)((4 * kq_e * HW + oy * W + 4 * tx_e) * 4) : WN_OOB;
+        }
+    };
+    auto request_first = [&](int first, int count) __attribute__((always_inline)) {       // residual 1 of channels first .. first + count - 1 (of 0, 1)
+        const __amdgpu_buffer_rsrc_t r1r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res1 ? a.res1 + (size_t)n * WN_C * HW : a.x), 0, a.res1 ? img_bytes : 0, 0x00020000);
+        unsigned lo[4];
+        int kq_e;
+        epilogue_lanes(lo, kq_e);
+        if (first == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { scv[r] = a.scale[16 * cot + 4 * kq_e + r]; shv[r] = a.shift[16 * cot + 4 * kq_e + r]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (first == 0) e1a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1r, lo[i], 16 * cot * HW * 4, 0));
+            if (first + count > 1) e1b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1r, lo[i], (16 * cot + 1) * HW * 4, 0));
+        }
     };
 
     // ---- prologue: the input of iteration 0, the first filter fragments ----
@@ -246,36 +331,46 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
     // One iteration = 4 k-steps = 36 quads of 4 MFMAs.  Per quad, IN THIS ORDER: its 4 MFMAs, then the request of the filter
     // fragments W4_RA - 1 quads ahead into the ring slot the PREVIOUS quad consumed, then the B operands two quads ahead into the
     // slot the previous quad consumed: a register is overwritten by a load issued at least 4 MFMAs after its last reader.
-    for (int jj = 0; jj < 8; jj += 2) {
+    // `last`: the eighth iteration has no next k-steps to prepare; the epilogue's first operands are requested in its place.
+    auto iteration = [&](const int j, const int u2, const bool last) __attribute__((always_inline)) {      // reads ring half u2
+        f32x4 bq[W4_RB];
+        bq[0] = ring[((u2 * 4 + 0) * W4_QUADS + 0) * 64 + lane];
+        bq[1] = ring[((u2 * 4 + 0) * W4_QUADS + 1) * 64 + lane];
+        const bool mine = !last && (WAVES == 4 || ((u2 ^ 1) == pgrp));    // iteration j + 1 has the parity of half u2 ^ 1
 #pragma unroll
-        for (int u2 = 0; u2 < 2; ++u2) {                          // iteration j = jj + u2 reads ring half u2
-            const int j = jj + u2;
-            f32x4 bq[W4_RB];
-            bq[0] = ring[((u2 * 4 + 0) * W4_QUADS + 0) * 64 + lane];
-            bq[1] = ring[((u2 * 4 + 0) * W4_QUADS + 1) * 64 + lane];
+        for (int lq = 0; lq < 36; ++lq) {                         // quad of the iteration: k-step lq / 9, positions 4 (lq % 9) ..
+            const int q = lq % W4_QUADS;
+            const int Q = j * 36 + lq;
+            const int sk = lq - (W4_TURN + W4_GAP);               // slice of the spread turn that rides on this quad
 #pragma unroll
-            for (int lq = 0; lq < 36; ++lq) {                     // quad of the iteration: k-step lq / 9, positions 4 (lq % 9) ..
-                const int q = lq % W4_QUADS;
-                const int Q = j * 36 + lq;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (4 * q + i < W4_ACC_A) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[4 * q + i]) : "v"(fa[lq % W4_RA][i]), "v"(bq[lq % W4_RB][i]));
-                    else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[4 * q + i]) : "v"(fa[lq % W4_RA][i]), "v"(bq[lq % W4_RB][i]));
+            for (int i = 0; i < 4; ++i) {
+                if (4 * q + i < W4_ACC_A) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[4 * q + i]) : "v"(fa[lq % W4_RA][i]), "v"(bq[lq % W4_RB][i]));
+                else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[4 * q + i]) : "v"(fa[lq % W4_RA][i]), "v"(bq[lq % W4_RB][i]));
+                if (W4_SPREAD && !last && i < 2 && sk >= 0 && sk < 13) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (mine) slice(sk, i, u2 ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                load_filter((lq + W4_RA - 1) % W4_RA, Q + W4_RA - 1);      // 36 % W4_RA == 0: the slot depends on lq only
-                if (lq + 2 < 36)
-                    bq[(lq + 2) % W4_RB] = ring[((u2 * 4 + (lq + 2) / W4_QUADS) * W4_QUADS + (lq + 2) % W4_QUADS) * 64 + lane];
-                // the wave's own k-step of the NEXT iteration: requested, then W4_GAP quads later transformed and written into the
-                // other half (a patch kept in registers for longer spills: 144 accumulators + rings leave ~50 registers)
-                const bool mine = WAVES == 4 || ((u2 ^ 1) == pgrp);   // iteration j + 1 has the parity of half u2 ^ 1
-                if (lq == W4_TURN && j + 1 < 8 && mine) load_patch(4 * (j + 1) + pw);
-                if (lq == W4_TURN + W4_GAP && j + 1 < 8 && mine) transform_put(u2 ^ 1);
-                __builtin_amdgcn_sched_barrier(0);                // quads stay in program order: the rings are sized for exactly that
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                         // next half complete, this half read by everybody
+            if (!last || lq + W4_RA - 1 < 36) load_filter((lq + W4_RA - 1) % W4_RA, Q + W4_RA - 1);      // 36 % W4_RA == 0: the slot depends on lq only
+            if (lq + 2 < 36)
+                bq[(lq + 2) % W4_RB] = ring[((u2 * 4 + (lq + 2) / W4_QUADS) * W4_QUADS + (lq + 2) % W4_QUADS) * 64 + lane];
+            // the wave's own k-step of the NEXT iteration: requested, then from W4_GAP quads later on transformed and written into
+            // the other half (W4_SPREAD: in 13 slices behind MFMAs; else as one block)
+            if (lq == W4_TURN && mine) load_patch(4 * (j + 1) + pw);
+            if (!W4_SPREAD && lq == W4_TURN + W4_GAP && mine) transform_put(u2 ^ 1);
+            if (last && lq == W4_PRE) request_first(0, W4_PRE_N);
+            __builtin_amdgcn_sched_barrier(0);                    // quads stay in program order: the rings are sized for exactly that
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                             // next half complete, this half read by everybody
+    };
+    for (int jj = 0; jj < 6; jj += 2) {
+        iteration(jj, 0, false);
+        iteration(jj + 1, 1, false);
     }
+    iteration(6, 0, false);
+    iteration(7, 1, true);
 #ifdef W4_STAMPS
     const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -289,66 +384,70 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
     }
 
     // ---- At M A, BN fold, activation, residuals, store: 4 channels x (4 x 4 pixels) per lane ----
-    const int img_bytes = WN_C * HW * 4;
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (size_t)n * WN_C * HW), 0, img_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r1r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res1 ? a.res1 + (size_t)n * WN_C * HW : a.x), 0, a.res1 ? img_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res2 ? a.res2 + (size_t)n * WN_C * HW : a.x), 0, a.res2 ? img_bytes : 0, 0x00020000);
-    // the epilogue's lane geometry is derived again from the lane id (laundered: kept alive from the prologue across the loop it
-    // would be spilled to scratch next to 144 accumulators)
-    // (mbcnt: the lane id from the hardware -- threadIdx kept alive across the loop is what the compiler spilled)
-    int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    asm volatile("" : "+v"(lane_e));
-    const int kq_e = lane_e >> 4, tx_e = 16 * sx + (lane_e & 15);
-    const bool col_ok_e = 4 * tx_e < W;
+    if (W4_PRE < 0) request_first(0, 2);
+    else if (W4_PRE_N < 2) request_first(1, 1);
     unsigned lo[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int oy = 4 * ty + i;
-        lo[i] = (col_ok_e && oy < H) ? (unsigned)((4 * kq_e * HW + oy * W + 4 * tx_e) * 4) : WN_OOB;
-    }
+    int kq_e;
+    epilogue_lanes(lo, kq_e);
     const float relu_lo = a.relu ? 0.f : -__builtin_inff();
-    // BN scale / shift of the lane's four channels and the first channel's residual rows are requested before anything is
-    // computed; residual 1 of channel r + 1 is requested before channel r is finished (most layers have one residual or none:
-    // conv1 of a block has none, conv2 has the block input, every third block and the stack's end add a second one, which is
-    // fetched inside its channel's turn).  An absent residual is a zero-record descriptor: the load returns 0 without a memory access.
-    float scv[4], shv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { scv[r] = a.scale[16 * cot + 4 * kq_e + r]; shv[r] = a.shift[16 * cot + 4 * kq_e + r]; }
-    f32x4 e1n[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) e1n[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1r, lo[i], 16 * cot * HW * 4, 0));
+    // Most layers have one residual or none (conv1 of a block has none, conv2 has the block input); every third block and the stack's
+    // end add a second one: template parameter RES2, so that the waits of the kernel without one count exactly the operations in
+    // flight (a load that may or may not have been issued makes every wait behind it a wait for everything; two copies of the
+    // epilogue inside one kernel spill).
+    constexpr bool has2 = RES2;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int co = 16 * cot + r;                              // + 4 kq: in the lane offset (4 kq HW)
         const int so = co * HW * 4;
-        f32x4 e1[4], e2[4];
+        f32x4 e2[4];                                              // requested inside its channel's turn
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            e1[i] = e1n[i];
-            e2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2r, lo[i], so, 0));
-        }
-        if (r + 1 < 4) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) e1n[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1r, lo[i], so + HW * 4, 0));
-        }
+        for (int i = 0; i < 4; ++i)
+            e2[i] = has2 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2r, lo[i], so, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        // (fenced step by step: left alone, the scheduler copies most of the 144 accumulators into vector registers first and the
+        // operands requested early no longer fit)
         float w_[6][4];                                           // columns transformed: w_[xi][j]
 #pragma unroll
-        for (int x = 0; x < 6; ++x)
+        for (int x = 0; x < 6; ++x) {
+#pragma unroll
+            for (int v = 0; v < 6; ++v) {                         // (re-fenced at every use: the copy out of the accumulator file stays here)
+                if (6 * x + v < W4_ACC_A) asm volatile("" : "+a"(acc[6 * x + v]));
+                else asm volatile("" : "+v"(acc[6 * x + v]));
+            }
             w4_at(acc[6 * x][r], acc[6 * x + 1][r], acc[6 * x + 2][r], acc[6 * x + 3][r], acc[6 * x + 4][r], acc[6 * x + 5][r],
                   w_[x][0], w_[x][1], w_[x][2], w_[x][3]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         float y[4][4];
 #pragma unroll
-        for (int jx = 0; jx < 4; ++jx)
+        for (int jx = 0; jx < 4; ++jx) {
             w4_at(w_[0][jx], w_[1][jx], w_[2][jx], w_[3][jx], w_[4][jx], w_[5][jx], y[0][jx], y[1][jx], y[2][jx], y[3][jx]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4 o[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            f32x4 o;
 #pragma unroll
-            for (int jx = 0; jx < 4; ++jx) o[jx] = fmaxf(fmaf(y[i][jx], scv[r], shv[r]), relu_lo);
-            o += e1[i];
-            o += e2[i];
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yr, lo[i], so, WT ? 16 : 0);
+            for (int jx = 0; jx < 4; ++jx) o[i][jx] = fmaxf(fmaf(y[i][jx], scv[r], shv[r]), relu_lo);
+            o[i] += (r & 1) ? e1b[i] : e1a[i];
+            if (has2) o[i] += e2[i];
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // residual 1 of channel r + 2 into the registers channel r just freed -- BEFORE this channel's stores: memory operations
+        // complete in order, a load behind 16 stores waits for their acknowledgements
+        if (r + 2 < 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1r, lo[i], so + 2 * HW * 4, 0));
+                if (r & 1) e1b[i] = v; else e1a[i] = v;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[i]), yr, lo[i], so, WT ? 16 : 0);
         __builtin_amdgcn_sched_barrier(0);
     }
 #ifdef W4_STAMPS
@@ -391,15 +490,16 @@ extern "C" int ic_wino4_3x3_c128_bn_act_f32(const float* x, const float* w_packe
     a.prof = (unsigned long long*)g_w4_dbg;
 #endif
     hipStream_t st = (hipStream_t)stream;
-#if W4_WAVES == 8
-    const long long wgs = a.ngroups;
-    if (wgs <= 256) hipLaunchKernelGGL((wino4_3x3_c128_kernel<true, 8>), dim3((unsigned)wgs), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((wino4_3x3_c128_kernel<false, 8>), dim3((unsigned)wgs), dim3(512), 0, st, a);
-#else
-    const long long wgs = 2ll * a.ngroups;
-    if (wgs <= 512) hipLaunchKernelGGL((wino4_3x3_c128_kernel<true, 4>), dim3((unsigned)wgs), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((wino4_3x3_c128_kernel<false, 4>), dim3((unsigned)wgs), dim3(256), 0, st, a);
-#endif
+    const long long wgs = (W4_WAVES == 8 ? 1ll : 2ll) * a.ngroups;
+    const bool wt = wgs <= (W4_WAVES == 8 ? 256 : 512);           // a single round of work-groups: write-through stores
+    const dim3 grid((unsigned)wgs), block(64 * W4_WAVES);
+    if (res2) {
+        if (wt) hipLaunchKernelGGL((wino4_3x3_c128_kernel<true, W4_WAVES, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((wino4_3x3_c128_kernel<false, W4_WAVES, true>), grid, block, 0, st, a);
+    } else {
+        if (wt) hipLaunchKernelGGL((wino4_3x3_c128_kernel<true, W4_WAVES, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((wino4_3x3_c128_kernel<false, W4_WAVES, false>), grid, block, 0, st, a);
+    }
     IC_LAUNCH_CHECK();
     return IC_OK;
 }

@@ -27,7 +27,7 @@ def algo(request, nets):
     plan flag that every encode / decode call of THIS autoencoder passes down -- the library has no process-wide switch."""
     from imgcomp_cvpr_amd import _lib
     ae, _ = nets
-    ae.plan_flags = {'direct3x3': _lib.CONV3_DIRECT, 'winograd3x3': _lib.CONV3_WINO, 'wino_seg3': _lib.CONV3_WINO_SEG3,
+    ae.plan_flags = {'direct3x3': _lib.CONV3_DIRECT, 'winograd3x3': _lib.CONV3_WINO | _lib.CONV3_NO_WINO4, 'wino_seg3': _lib.CONV3_WINO_SEG3,
                      'wino_seg2': _lib.CONV3_WINO_SEG2, 'wino4': _lib.CONV3_WINO4}[request.param]
     yield request.param
     ae.plan_flags = 0
@@ -141,7 +141,7 @@ def test_full_size_properties(cuda, configs, syn_weights, nets, algo):
             ae.plan_flags = form
             e3 = ae.encode(x, False)
             assert torch.equal(z1, e3.z), 'Winograd form {:#x} differs'.format(form)
-        ae.plan_flags = _lib.CONV3_WINO
+        ae.plan_flags = _lib.CONV3_WINO | _lib.CONV3_NO_WINO4
     xo = ae.decode(e1.qhard, False)
     assert xo.shape == x.shape and float(xo.min()) >= 0 and float(xo.max()) <= 255
     bc = pc.bitcost(e1.qbar, e1.symbols, False, pad_value=pc.auto_pad_value(ae))

@@ -306,11 +306,13 @@ def test_conv3x3_c128_auto_selection(cuda):
     wp = torch.empty(L.lib.ic_conv3x3_c128_both_packed_floats(), device=cuda)
     L.check(L.lib.ic_pack_conv3x3_c128_both_f32(L.ptr(wd), L.ptr(wp), 0, L.current_stream()))
     ref = _ref_conv(x, w, scale, shift, 1, 1)
-    # which of the three kernels: F(4x4) where its work-groups fill the chip (alone from 512 of them, with neighbours on other
-    # streams from 384 in total), F(2x2) below that, and never against an explicit form or IC_CONV3_NO_WINO4
+    # which of the three kernels: F(4x4) where two of its work-groups per CU are resident (alone from 512 of them, with the launches
+    # in flight beside it from 384 together) and the map fills its 16-tile segments; F(2x2) otherwise, and always against an
+    # explicit F(2x2) form or IC_CONV3_NO_WINO4
     pf = L.lib.ic_conv3x3_c128_pick_form
     assert pf(1, 128, 192, 0) == 1 and pf(8, 128, 192, 0) == 2 and pf(1, 512, 512, 0) == 2
     assert pf(1, 128, 192, L.CONV3_IN_FLIGHT(6)) == 2 and pf(1, 32, 32, L.CONV3_IN_FLIGHT(6)) == 1
+    assert pf(60, 20, 20, 0) == 1                                          # 600 work-groups, 5 of 16 tiles per segment
     assert pf(8, 128, 192, L.CONV3_NO_WINO4) == 1 and pf(8, 128, 192, L.CONV3_WINO) == 2 and pf(8, 128, 190, 0) == 1
     assert pf(1, 16, 16, L.CONV3_WINO4) == 2 and pf(1, 4096, 2048, 0) == 0
     outs = []
