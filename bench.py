@@ -8,11 +8,14 @@ A "step" is one pass of the hot path over one batch of synthetic input: BASELINE
 Inputs and weights are resident in HBM before the timed region.  Data: seeded synthetic images and
 random-init weights (no network for Kodak or the 0515_1103 checkpoint).
 
-Schedule (--in_flight n, default 6): the images of an evaluation set are independent (val.py:157-158 runs one per sess.run), so
+Schedule (--in_flight n, default 4): the images of an evaluation set are independent (val.py:157-158 runs one per sess.run), so
 n of them are in flight at a time, each a batch-1 step on its own stream with its own network objects and workspace; steps are
 issued round-robin and EVERY step is still one image through the whole path.  The launches of one image fill the kernel-boundary
 bubbles of the others, and a 3x3 launch no longer has to fill the chip alone (IC_CONV3_IN_FLIGHT: the plan takes the form with
 the least CU-time).  --in_flight 1 is one image at a time (what rounds 1-2 reported; kept in the line as `one_image_at_a_time`).
+The HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues, 4 unless set: with more streams than
+queues, streams that share a queue run one after the other.  bench.py asks for 8 below, before the runtime starts (round 4:
+4 images in flight 207.7 Mpix/s on 4 queues, 251.5 on 8; 6 images 236 / 240).
 
   python bench.py --gpus N --steps K --warmup W            (--mode train: one cfg3 training step per step)
 N > 1 is launched by torch.distributed.run, one rank per GPU; the path shards by image (independent
@@ -36,6 +39,8 @@ import json
 import os
 import sys
 import time
+
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # one hardware queue per image in flight (+ the default stream); see the docstring
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -166,7 +171,7 @@ def main():
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--no_extras', action='store_true', help='headline only: no stage split, roofline, extra shapes (rocprofv3 runs)')
     p.add_argument('--pipelined', action='store_true', help='also run the informational three-pipelines-in-flight section')
-    p.add_argument('--in_flight', type=int, default=6,
+    p.add_argument('--in_flight', type=int, default=4,
                    help='independent batch-1 images in flight on their own streams (serial arrangement only); 1 = one image at a time')
     p.add_argument('--graphs', type=int, default=0, help='1: every in-flight pipeline replays its step from a captured HIP graph')
     p.add_argument('--calib_copy', action='store_true',
