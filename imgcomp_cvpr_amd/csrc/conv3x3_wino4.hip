@@ -25,10 +25,13 @@
 //   * zero padding is done by the memory system (raw buffer loads, out-of-range lane offsets), as in the F(2x2) kernels.
 // Shapes: W % 4 == 0 (aligned 16-byte rows); anything else keeps the F(2x2) forms (ic_conv3x3_c128_auto_f32).
 //
-// Where the time goes (in-kernel shader-clock stamps, make with -DW4_STAMPS, tools/w4prof.py; batch of 8 Kodak-sized maps, two
-// work-groups per CU): prologue 7.8 k clocks, loop 92 k, epilogue 20 k per wave, against 36.9 k clocks of pure MFMA issue for
-// the wave's 1152 instructions (two waves share a SIMD's matrix pipe: 73.7 k for both).  The loop is within 25 % of that; what is
-// left is the 8 transform turns (~200 VALU instructions each, ~2 k clocks) and the filter-fragment waits.
+// Where the time goes (in-kernel shader-clock stamps, a build with -DW4_STAMPS, tools/w4prof.py; batch of 8 Kodak-sized maps, two
+// work-groups per CU, ~1.9 GHz under this load): per wave prologue 9.5 k clocks, loop 89 k, epilogue 8.5 k, against 36.9 k clocks of
+// MFMA issue for its 1152 instructions -- two waves share a SIMD's matrix pipe, so 73.7 k of every 107 k (0.69).  Alone on its
+// SIMD a wave's loop takes 56 k.  How it got there (round 4, same launch): first correct version 201 us; filter ring 4 -> 6 quads,
+// patch requested ahead of its transform 189 us; the transform of a turn cut into 26 pieces behind MFMAs (loop alone 75 k -> 57 k
+// clocks; no change at full load, where the other wave fills the pipe anyway); epilogue operands two channels ahead and in front
+// of the stores (epilogue 20 k -> 8.5 k clocks) 175 us.  F(2x2) plan on the same input: 242 us.
 //
 // BUILD NOTE (csrc/Makefile): this file is compiled with -fno-slp-vectorize.  With the SLP vectoriser's packed fp32 instructions
 // (v_pk_fma_f32 / v_pk_add_f32) in the input transform the kernel returned wrong values in lanes 12..15 of 16-lane rows, a few
@@ -42,9 +45,6 @@
 #define W4_PACKED_FLOATS (36 * WN_C * WN_C)
 #define W4_ACC_A 32                                 // accumulators (of 36) kept in AGPRs
 // tuning knobs (defaults = the measured best, round 4: 4 waves, rings 6 / 3, turn at quad 6, transform 3 quads after its request)
-#ifndef W4_WAVES
-#define W4_WAVES 4                                  // waves per work-group: 8 = all 128 output channels of a segment
-#endif
 #ifndef W4_RA
 #define W4_RA 6                                     // filter-fragment ring, in quads (36 % W4_RA == 0)
 #endif
@@ -134,11 +134,11 @@ __device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, fl
     y3 = fmaf(8.f, d2, d1) + m5;
 }
 
-// WAVES = 4: a work-group is one HALF of the output channels of a segment, two work-groups per CU.
-// WAVES = 8: a work-group is ALL 128 output channels of a segment (one per CU): the input transform is made once per segment
-//            instead of once per half -- waves 0..3 produce the k-steps of the even iterations, waves 4..7 those of the odd ones.
-template <bool WT, int WAVES, bool RES2>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// A work-group (4 waves) is one HALF of the output channels of a segment, two work-groups per CU.  (An 8-wave work-group -- all
+// 128 channels, the input transform made once per segment instead of once per half -- was built and measured in round 4: 199.5
+// against 190 us on 8 Kodak maps, 53 against 35 us on one; removed.)
+template <bool WT, bool RES2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void wino4_3x3_c128_kernel(const WnArgs a) {
     __shared__ f32x4 ring[2 * 4 * W4_QUADS * 64];                 // [half][k-step of the iteration][position quad][lane]: 72 KB
 #ifdef W4_STAMPS
@@ -147,13 +147,12 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, n16 = lane & 15, kq = lane >> 4;
     const int b = a.xcd_runs ? ic_xcd_run(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-    const int half_co = WAVES == 4 ? (b & 1) : 0;
-    const int seg = (WAVES == 4 ? (b >> 1) : b) + a.g0;
+    const int half_co = b & 1;
+    const int seg = (b >> 1) + a.g0;
     const int sx = seg % a.gcols, t_ = seg / a.gcols;
     const int ty = t_ % a.grows, n = t_ / a.grows;
     const int cot = half_co * 4 + wave;                           // 16-channel tile of this wave
     const int pw = wave & 3;                                      // k-step of an iteration this wave produces
-    const int pgrp = wave >> 2;                                   // WAVES = 8: parity of the iterations it produces for
     const int tx = 16 * sx + n16;
     const int H = a.H, W = a.W, HW = H * W;
 
@@ -318,10 +317,10 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
     };
 
     // ---- prologue: the input of iteration 0, the first filter fragments ----
-    if (WAVES == 4 || pgrp == 0) load_patch(pw);
+    load_patch(pw);
 #pragma unroll
     for (int Q = 0; Q < W4_RA - 1; ++Q) load_filter(Q, Q);
-    if (WAVES == 4 || pgrp == 0) transform_put(0);
+    transform_put(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -336,7 +335,6 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
         f32x4 bq[W4_RB];
         bq[0] = ring[((u2 * 4 + 0) * W4_QUADS + 0) * 64 + lane];
         bq[1] = ring[((u2 * 4 + 0) * W4_QUADS + 1) * 64 + lane];
-        const bool mine = !last && (WAVES == 4 || ((u2 ^ 1) == pgrp));    // iteration j + 1 has the parity of half u2 ^ 1
 #pragma unroll
         for (int lq = 0; lq < 36; ++lq) {                         // quad of the iteration: k-step lq / 9, positions 4 (lq % 9) ..
             const int q = lq % W4_QUADS;
@@ -348,7 +346,7 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
                 else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[4 * q + i]) : "v"(fa[lq % W4_RA][i]), "v"(bq[lq % W4_RB][i]));
                 if (W4_SPREAD && !last && i < 2 && sk >= 0 && sk < 13) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (mine) slice(sk, i, u2 ^ 1);
+                    slice(sk, i, u2 ^ 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -357,8 +355,8 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
                 bq[(lq + 2) % W4_RB] = ring[((u2 * 4 + (lq + 2) / W4_QUADS) * W4_QUADS + (lq + 2) % W4_QUADS) * 64 + lane];
             // the wave's own k-step of the NEXT iteration: requested, then from W4_GAP quads later on transformed and written into
             // the other half (W4_SPREAD: in 13 slices behind MFMAs; else as one block)
-            if (lq == W4_TURN && mine) load_patch(4 * (j + 1) + pw);
-            if (!W4_SPREAD && lq == W4_TURN + W4_GAP && mine) transform_put(u2 ^ 1);
+            if (lq == W4_TURN && !last) load_patch(4 * (j + 1) + pw);
+            if (!W4_SPREAD && lq == W4_TURN + W4_GAP && !last) transform_put(u2 ^ 1);
             if (last && lq == W4_PRE) request_first(0, W4_PRE_N);
             __builtin_amdgcn_sched_barrier(0);                    // quads stay in program order: the rings are sized for exactly that
         }
@@ -453,7 +451,7 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
 #ifdef W4_STAMPS
     if (a.prof && (threadIdx.x & 63) == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long* d = a.prof + 4 * ((size_t)blockIdx.x * WAVES + (threadIdx.x >> 6));
+        unsigned long long* d = a.prof + 4 * ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6));
         d[0] = t_loop0 - t_entry; d[1] = t_loop1 - t_loop0; d[2] = __builtin_amdgcn_s_memtime() - t_loop1; d[3] = t_entry;
     }
 #endif
@@ -472,7 +470,7 @@ extern "C" int ic_wino4_3x3_c128_supported(int N, int H, int W) {
 // work-groups of a launch: (segments of 16 tiles) x 2 channel halves, two per CU
 extern "C" long long ic_wino4_3x3_c128_workgroups(int N, int H, int W) {
     if (!ic_wino4_3x3_c128_supported(N, H, W)) return 0;
-    return (W4_WAVES == 8 ? 1ll : 2ll) * N * ic_cdiv(H, 4) * ic_cdiv(W, 64);
+    return 2ll * N * ic_cdiv(H, 4) * ic_cdiv(W, 64);
 }
 
 extern "C" int ic_wino4_3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
@@ -490,15 +488,15 @@ extern "C" int ic_wino4_3x3_c128_bn_act_f32(const float* x, const float* w_packe
     a.prof = (unsigned long long*)g_w4_dbg;
 #endif
     hipStream_t st = (hipStream_t)stream;
-    const long long wgs = (W4_WAVES == 8 ? 1ll : 2ll) * a.ngroups;
-    const bool wt = wgs <= (W4_WAVES == 8 ? 256 : 512);           // a single round of work-groups: write-through stores
-    const dim3 grid((unsigned)wgs), block(64 * W4_WAVES);
+    const long long wgs = 2ll * a.ngroups;
+    const bool wt = wgs <= 512;                                   // a single round of work-groups: write-through stores
+    const dim3 grid((unsigned)wgs), block(256);
     if (res2) {
-        if (wt) hipLaunchKernelGGL((wino4_3x3_c128_kernel<true, W4_WAVES, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((wino4_3x3_c128_kernel<false, W4_WAVES, true>), grid, block, 0, st, a);
+        if (wt) hipLaunchKernelGGL((wino4_3x3_c128_kernel<true, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((wino4_3x3_c128_kernel<false, true>), grid, block, 0, st, a);
     } else {
-        if (wt) hipLaunchKernelGGL((wino4_3x3_c128_kernel<true, W4_WAVES, false>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((wino4_3x3_c128_kernel<false, W4_WAVES, false>), grid, block, 0, st, a);
+        if (wt) hipLaunchKernelGGL((wino4_3x3_c128_kernel<true, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((wino4_3x3_c128_kernel<false, false>), grid, block, 0, st, a);
     }
     IC_LAUNCH_CHECK();
     return IC_OK;
