@@ -25,6 +25,9 @@ CONV3_WINO_KSPLIT, CONV3_WINO_T16, CONV3_WINO_SEG1, CONV3_WINO_SEG2, CONV3_WINO_
 CONV3_WINO_PAIR = 10
 CONV3_WINO4 = 11                    # Winograd F(4x4,3x3)
 CONV3_NO_WINO4 = 0x800000
+CONV5_BOTH_PACKED = 0x1000000         # h2 / h12 blobs carry the F(4x4)-over-phases fragments too (ic_pack_conv5s2_both_f32)
+CONV5_WINO4 = 0x2000000               # h2 / h12 on the F(4x4) kernel wherever the shape allows
+CONV5_NO_WINO4 = 0x4000000
 CONV3_LEAVE_IDLE_CUS = 0x10
 CONV3_NO_XCD_RUNS = 0x20
 CONV3_PACKED_TRANSFORM = 0x40
@@ -116,6 +119,15 @@ PROTOTYPES = {
     'ic_wino4_3x3_c128_supported': (c_int, [c_int, c_int, c_int]),
     'ic_wino4_3x3_c128_workgroups': (c_longlong, [c_int, c_int, c_int]),
     'ic_wino4_3x3_c128_bn_act_f32': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
+    'ic_wino4_conv5s2_packed_floats': (c_size_t, []),
+    'ic_pack_wino4_conv5s2_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    'ic_wino4_conv5s2_supported': (c_int, [c_int, c_int, c_int]),
+    'ic_wino4_conv5s2_workgroups': (c_longlong, [c_int, c_int, c_int, c_int]),
+    'ic_wino4_conv5s2_c64_c128_bn_act_f32': (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    'ic_wino4_deconv5s2_c128_c64_bn_act_f32': (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    'ic_space_to_depth2_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'ic_conv5s2_both_packed_floats': (c_size_t, [c_int]),
+    'ic_pack_conv5s2_both_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     'ic_msssim_plan_bytes': (c_size_t, [c_int, c_int]),
     'ic_msssim_plan_fill': (c_int, [c_int, c_int, c_void_p, c_size_t]),
     'ic_msssim_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),

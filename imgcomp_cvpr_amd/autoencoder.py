@@ -194,6 +194,7 @@ class _CVPR(_Network):
         st = _lib.current_stream(dev)
         specs = _weights.ae_conv_specs(self._C, self._B, bool(cfg.heatmap))
         self._plan = {}           # scope -> (w_dev, scale_dev, shift_dev); keeps tensors alive
+        self._edge_both = False
         enc_tab, dec_tab = [], []
         packed_n = lib.ic_conv3x3_c128_both_packed_floats()
         for scope, kind, shape in specs:
@@ -211,6 +212,14 @@ class _CVPR(_Network):
                 # direct-form and Winograd fragments side by side; the library picks the form per launch
                 check(lib.ic_pack_conv3x3_c128_both_f32(ptr(w), ptr(wp), 0, st), 'ic_pack_conv3x3_c128_both_f32')
                 w_use = wp
+            elif scope.endswith(('/h2', '/h12')) and (kh, kw, stride) == (5, 5, 2) and {cin, cout} == {64, 128}:
+                # h2 / h12: MFMA fragments and the F(4x4)-over-phases fragments in one blob; the library picks per call
+                # (IC_CONV5_BOTH_PACKED tells it the blob has both, see _encode / _decode)
+                tr = int(kind == 'deconv')
+                wp = torch.empty(lib.ic_conv5s2_both_packed_floats(tr), dtype=torch.float32, device=dev)
+                check(lib.ic_pack_conv5s2_both_f32(ptr(w), ptr(wp), tr, st), 'ic_pack_conv5s2_both_f32')
+                w_use = wp
+                self._edge_both = True
             elif n_mfma and not scope.endswith('/h1'):
                 # h2, to_bn, h12: matrix-core path, filter in MFMA fragment order
                 wp = torch.empty(n_mfma, dtype=torch.float32, device=dev)
@@ -226,6 +235,10 @@ class _CVPR(_Network):
         self._enc_tab = _lib.ptr_table(enc_tab)
         self._dec_tab = _lib.ptr_table(dec_tab)
         self._ws = None
+
+    def _abi_flags(self, plan_flags):
+        """the caller's per-call plan bits + what this object's filter blobs hold"""
+        return int(plan_flags) | (_lib.CONV5_BOTH_PACKED if self._edge_both else 0)
 
     def _workspace(self, N, H, W):
         need = lib.ic_ae_workspace_bytes(N, H, W, self._C)
@@ -248,7 +261,14 @@ class _CVPR(_Network):
         mk = lambda: torch.empty((N, C, hh, ww), dtype=torch.float32, device=x.device)
         heat_on = bool(self.config.heatmap)
         if not self.quantize:
-            raise NotImplementedError('quantize=False is not used by val.py/train.py')
+            # autoencoder.py:127-129: no quantiser -- the encoder hands on the (masked) bottleneck itself, _QuantizerOutput(z, None, None, None)
+            z = mk()
+            heatmap = mk() if heat_on else None
+            ws, need = self._workspace(N, H, W)
+            check(lib.ic_ae_encode_f32(ptr(x), self._enc_tab, self._B, C, self._L, int(heat_on),
+                                       int(self.config.normalization == 'FIXED'), ptr(heatmap), ptr(z), None, None, None, None,
+                                       N, H, W, ptr(ws), need, self._abi_flags(plan_flags), _lib.current_stream(x.device)), 'ic_ae_encode_f32')
+            return EncoderOutput(z, None, None, z, heatmap)
         z, qsoft, qhard = mk(), mk(), mk()
         qbar = mk() if heat_on else None
         heatmap = mk() if heat_on else None
@@ -257,7 +277,7 @@ class _CVPR(_Network):
         check(lib.ic_ae_encode_f32(ptr(x), self._enc_tab, self._B, C, self._L, int(heat_on),
                                    int(self.config.normalization == 'FIXED'),
                                    ptr(heatmap), ptr(z), ptr(qsoft), ptr(qhard), ptr(qbar), ptr(symbols),
-                                   N, H, W, ptr(ws), need, plan_flags, _lib.current_stream(x.device)), 'ic_ae_encode_f32')
+                                   N, H, W, ptr(ws), need, self._abi_flags(plan_flags), _lib.current_stream(x.device)), 'ic_ae_encode_f32')
         if qbar is None:
             qbar = qhard      # forward value of qsoft + stop_gradient(qhard - qsoft)
         self._last_qsoft = qsoft
@@ -274,6 +294,6 @@ class _CVPR(_Network):
         x_out = torch.empty((N, 3, H, W), dtype=torch.float32, device=q.device)
         ws, need = self._workspace(N, H, W)
         check(lib.ic_ae_decode_f32(ptr(q), self._dec_tab, self._B, C, int(self.config.normalization == 'FIXED'),
-                                   ptr(x_out), N, H, W, ptr(ws), need, plan_flags, _lib.current_stream(q.device)),
+                                   ptr(x_out), N, H, W, ptr(ws), need, self._abi_flags(plan_flags), _lib.current_stream(q.device)),
               'ic_ae_decode_f32')
         return x_out

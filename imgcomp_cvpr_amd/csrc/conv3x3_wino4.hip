@@ -68,19 +68,40 @@
 #endif                                              //    quad, each behind an MFMA (whose 8 passes hide them); 0: one block of ~200
 
 // ---- filter transform + packing: U = G g Gt in float64, rounded once -------------------------------------------------------
-// packed float index: (((cot * 32 + ks) * 9 + p / 4) * 64 + lane) * 4 + p % 4, cot = co / 16, ks = ci / 4, lane = (ci & 3) * 16 + (co & 15),
-// p = 6 xi + nu.  backward = 1 packs the adjoint (data-gradient) filter: g'[a][b][in = co][out = ci] = g[2 - a][2 - b][ci][co].
-__global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict__ w_tf, float* __restrict__ out, int backward) {
+// packed float index: (((cot * KS + ks) * 9 + p / 4) * 64 + lane) * 4 + p % 4, cot = co / 16, ks = ci / 4 (KS = Cin / 4 k-steps),
+// lane = (ci & 3) * 16 + (co & 15), p = 6 xi + nu.  What the 3x3 filter g[a][b][ci][co] is (mode):
+//   0  the layer's own [3][3][128][128] array
+//   1  its adjoint (data gradient): g[a][b][in = co][out = ci] = w[2 - a][2 - b][ci][co]
+//   2  a 5x5 / stride-2 SAME convolution [5][5][64][128] (h2, autoencoder.py:223) as ONE 3x3 convolution over the four phases of its
+//      input stacked as 256 channels (ci = (2 py + px) * 64 + c):  Y[i] = sum_a W[a] X[2 i + a - 1], so the odd rows X[2 m + 1] meet
+//      the taps (W[0], W[2], W[4]) at m = i - 1, i, i + 1 and the even rows X[2 m] the taps (0, W[1], W[3])
+//   3  the 5x5 / stride-2 transposed convolution [5][5][64 out][128 in] (h12, autoencoder.py:264) as ONE 3x3 convolution to four
+//      phase planes per output channel (co = 4 c + 2 py + px): output rows 2 m + 1 take (W[4], W[2], W[0]) at input rows
+//      m - 1, m, m + 1, output rows 2 m take (W[3], W[1], 0)
+// (tools/phase_conv_check.py checks both identities against the oracle's convolutions in float64.)
+__device__ __forceinline__ int w4_tap5(int mode, int phase, int a) {          // 5-tap index of 3-tap position a for a phase, -1: none
+    if (mode == 2) return phase ? 2 * a : (a == 0 ? -1 : 2 * a - 1);
+    return phase ? 4 - 2 * a : (a == 2 ? -1 : 3 - 2 * a);
+}
+__global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict__ w_tf, float* __restrict__ out, int mode, int CI, int CO) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= WN_C * WN_C) return;
-    const int cin = idx / WN_C, cout = idx % WN_C;
+    if (idx >= CI * CO) return;
+    const int cin = idx / CO, cout = idx % CO;
     double g[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b)
-            g[a][b] = backward ? (double)w_tf[(((2 - a) * 3 + (2 - b)) * WN_C + cout) * WN_C + cin]
-                               : (double)w_tf[((a * 3 + b) * WN_C + cin) * WN_C + cout];
+        for (int b = 0; b < 3; ++b) {
+            if (mode == 0) g[a][b] = (double)w_tf[((a * 3 + b) * WN_C + cin) * WN_C + cout];
+            else if (mode == 1) g[a][b] = (double)w_tf[(((2 - a) * 3 + (2 - b)) * WN_C + cout) * WN_C + cin];
+            else if (mode == 2) {
+                const int ph = cin >> 6, c = cin & 63, ky = w4_tap5(2, ph >> 1, a), kx = w4_tap5(2, ph & 1, b);
+                g[a][b] = (ky < 0 || kx < 0) ? 0.0 : (double)w_tf[((ky * 5 + kx) * 64 + c) * 128 + cout];
+            } else {
+                const int ph = cout & 3, c = cout >> 2, ky = w4_tap5(3, ph >> 1, a), kx = w4_tap5(3, ph & 1, b);
+                g[a][b] = (ky < 0 || kx < 0) ? 0.0 : (double)w_tf[((ky * 5 + kx) * 64 + c) * 128 + cin];
+            }
+        }
     const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                             {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
     double t[6][3];
@@ -88,7 +109,7 @@ __global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict
     for (int x = 0; x < 6; ++x)
 #pragma unroll
         for (int b = 0; b < 3; ++b) t[x][b] = G[x][0] * g[0][b] + G[x][1] * g[1][b] + G[x][2] * g[2][b];
-    float* o = out + ((size_t)((cout >> 4) * 32 + (cin >> 2)) * W4_QUADS * 64 + ((cin & 3) * 16 + (cout & 15))) * 4;
+    float* o = out + ((size_t)((cout >> 4) * (CI >> 2) + (cin >> 2)) * W4_QUADS * 64 + ((cin & 3) * 16 + (cout & 15))) * 4;
 #pragma unroll
     for (int x = 0; x < 6; ++x)
 #pragma unroll
@@ -102,7 +123,18 @@ extern "C" size_t ic_wino4_3x3_c128_packed_floats(void) { return W4_PACKED_FLOAT
 
 extern "C" int ic_pack_wino4_3x3_c128_f32(const float* w_tf, float* w_packed, int backward, ic_stream_t stream) {
     IC_CHECK_ARG(w_tf && w_packed);
-    hipLaunchKernelGGL(wino4_pack_kernel, dim3(WN_C * WN_C / 256), dim3(256), 0, (hipStream_t)stream, w_tf, w_packed, backward);
+    hipLaunchKernelGGL(wino4_pack_kernel, dim3(WN_C * WN_C / 256), dim3(256), 0, (hipStream_t)stream, w_tf, w_packed, backward ? 1 : 0, WN_C, WN_C);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
+// h2 / h12 in phase form: 36 x 256 x 128 fragments either way
+extern "C" size_t ic_wino4_conv5s2_packed_floats(void) { return (size_t)36 * 256 * 128; }
+
+extern "C" int ic_pack_wino4_conv5s2_f32(const float* w_tf, float* w_packed, int transposed, ic_stream_t stream) {
+    IC_CHECK_ARG(w_tf && w_packed);
+    hipLaunchKernelGGL(wino4_pack_kernel, dim3(256 * 128 / 256), dim3(256), 0, (hipStream_t)stream, w_tf, w_packed, transposed ? 3 : 2,
+                       transposed ? 128 : 256, transposed ? 256 : 128);
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
@@ -137,9 +169,13 @@ __device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, fl
 // A work-group (4 waves) is one HALF of the output channels of a segment, two work-groups per CU.  (An 8-wave work-group -- all
 // 128 channels, the input transform made once per segment instead of once per half -- was built and measured in round 4: 199.5
 // against 190 us on 8 Kodak maps, 53 against 35 us on one; removed.)
-template <bool WT, bool RES2>
+// Template: WT write-through stores (single-round launches); RES how many residual inputs the epilogue serves (0, 1, 2); CIN / COUT
+// channels (128 / 128: the residual layers; 256 / 128: h2 over its input's phases; 128 / 256: h12 to its output's phases); SHUF:
+// the four "channels" of a lane are the four phases of ONE output channel and are stored interleaved into the 2 H x 2 W map.
+template <bool WT, int RES, int CIN, int COUT, bool SHUF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void wino4_3x3_c128_kernel(const WnArgs a) {
+void wino4_3x3_kernel(const WnArgs a) {
+    constexpr int KS = CIN / 4, IT = KS / 4, PARTS = COUT / 64;   // k-steps, iterations of 4 k-steps, work-groups per segment
     __shared__ f32x4 ring[2 * 4 * W4_QUADS * 64];                 // [half][k-step of the iteration][position quad][lane]: 72 KB
 #ifdef W4_STAMPS
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
@@ -147,17 +183,17 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, n16 = lane & 15, kq = lane >> 4;
     const int b = a.xcd_runs ? ic_xcd_run(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-    const int half_co = b & 1;
-    const int seg = (b >> 1) + a.g0;
+    const int part = b % PARTS;
+    const int seg = b / PARTS + a.g0;
     const int sx = seg % a.gcols, t_ = seg / a.gcols;
     const int ty = t_ % a.grows, n = t_ / a.grows;
-    const int cot = half_co * 4 + wave;                           // 16-channel tile of this wave
+    const int cot = part * 4 + wave;                              // 16-channel tile of this wave
     const int pw = wave & 3;                                      // k-step of an iteration this wave produces
     const int tx = 16 * sx + n16;
     const int H = a.H, W = a.W, HW = H * W;
 
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)n * WN_C * HW), 0, WN_C * HW * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, W4_PACKED_FLOATS * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)n * CIN * HW), 0, CIN * HW * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 36 * CIN * COUT * 4, 0x00020000);
     // patch rows 4 ty - 1 .. 4 ty + 4: own aligned 4 pixels (columns 4 tx .. 4 tx + 3); the end lanes of the tile row also fetch
     // the column outside (lane 0: 4 tx - 1, lane 15: 4 tx + 4), every other lane gets an out-of-range offset there
     // Row validity is wave-uniform (one tile row per work-group), column validity per lane: ONE lane offset for the patch's first
@@ -275,7 +311,7 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
     // filter fragments: quad index Q = ks * 9 + q of this wave's channel tile: 1 KB per quad
     f32x4 fa[W4_RA];
     auto load_filter = [&](int slot, int Q) __attribute__((always_inline)) {       // slot = Q % W4_RA, passed as a constant
-        fa[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(fr, fo, (cot * 32 * W4_QUADS + Q) * 1024, 0));
+        fa[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(fr, fo, (cot * KS * W4_QUADS + Q) * 1024, 0));
     };
 
     // Operands of the epilogue, requested while the last iteration still runs (W4_PRE): BN scale / shift of the lane's four channels
@@ -283,7 +319,7 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
     // channel ahead (round 4's first version) every channel waited a full memory latency, 4 x ~5 k clocks at full load, stamps:
     // epilogue 20 k clocks of a wave's 117 k.  An absent residual is a zero-record descriptor: the load returns 0, no memory access.
     // The lane geometry is derived from the hardware lane id each time (kept alive across the loop it is spilled).
-    const int img_bytes = WN_C * HW * 4;
+    const int img_bytes = COUT * HW * 4;
     f32x4 e1a[4], e1b[4];
     float scv[4], shv[4];
 #pragma unroll
@@ -301,18 +337,23 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
         }
     };
     auto request_first = [&](int first, int count) __attribute__((always_inline)) {       // residual 1 of channels first .. first + count - 1 (of 0, 1)
-        const __amdgpu_buffer_rsrc_t r1r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res1 ? a.res1 + (size_t)n * WN_C * HW : a.x), 0, a.res1 ? img_bytes : 0, 0x00020000);
         unsigned lo[4];
         int kq_e;
         epilogue_lanes(lo, kq_e);
         if (first == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { scv[r] = a.scale[16 * cot + 4 * kq_e + r]; shv[r] = a.shift[16 * cot + 4 * kq_e + r]; }
+            for (int r = 0; r < 4; ++r) {
+                const int ch = SHUF ? 4 * cot + kq_e : 16 * cot + 4 * kq_e + r;        // SHUF: one real channel per lane, four phases
+                scv[r] = a.scale[ch]; shv[r] = a.shift[ch];
+            }
         }
+        if (RES > 0) {
+            const __amdgpu_buffer_rsrc_t r1r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res1 ? a.res1 + (size_t)n * COUT * HW : a.x), 0, a.res1 ? img_bytes : 0, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (first == 0) e1a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1r, lo[i], 16 * cot * HW * 4, 0));
-            if (first + count > 1) e1b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1r, lo[i], (16 * cot + 1) * HW * 4, 0));
+            for (int i = 0; i < 4; ++i) {
+                if (first == 0) e1a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1r, lo[i], 16 * cot * HW * 4, 0));
+                if (first + count > 1) e1b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1r, lo[i], (16 * cot + 1) * HW * 4, 0));
+            }
         }
     };
 
@@ -363,12 +404,12 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                             // next half complete, this half read by everybody
     };
-    for (int jj = 0; jj < 6; jj += 2) {
+    for (int jj = 0; jj < IT - 2; jj += 2) {
         iteration(jj, 0, false);
         iteration(jj + 1, 1, false);
     }
-    iteration(6, 0, false);
-    iteration(7, 1, true);
+    iteration(IT - 2, 0, false);
+    iteration(IT - 1, 1, true);
 #ifdef W4_STAMPS
     const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -382,20 +423,86 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
     }
 
     // ---- At M A, BN fold, activation, residuals, store: 4 channels x (4 x 4 pixels) per lane ----
-    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (size_t)n * WN_C * HW), 0, img_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r1r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res1 ? a.res1 + (size_t)n * WN_C * HW : a.x), 0, a.res1 ? img_bytes : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r2r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res2 ? a.res2 + (size_t)n * WN_C * HW : a.x), 0, a.res2 ? img_bytes : 0, 0x00020000);
     if (W4_PRE < 0) request_first(0, 2);
     else if (W4_PRE_N < 2) request_first(1, 1);
     unsigned lo[4];
     int kq_e;
     epilogue_lanes(lo, kq_e);
     const float relu_lo = a.relu ? 0.f : -__builtin_inff();
+    // At M A of "channel" r of the lane: (fenced step by step: left alone, the scheduler copies most of the 144 accumulators into
+    // vector registers first and the operands requested early no longer fit; re-fenced at every use: the copy out of the
+    // accumulator file stays where it is used)
+    auto out_tile = [&](int r, float (&y)[4][4]) __attribute__((always_inline)) {
+        float w_[6][4];                                           // columns transformed: w_[xi][j]
+#pragma unroll
+        for (int x = 0; x < 6; ++x) {
+#pragma unroll
+            for (int v = 0; v < 6; ++v) {
+                if (6 * x + v < W4_ACC_A) asm volatile("" : "+a"(acc[6 * x + v]));
+                else asm volatile("" : "+v"(acc[6 * x + v]));
+            }
+            w4_at(acc[6 * x][r], acc[6 * x + 1][r], acc[6 * x + 2][r], acc[6 * x + 3][r], acc[6 * x + 4][r], acc[6 * x + 5][r],
+                  w_[x][0], w_[x][1], w_[x][2], w_[x][3]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) {
+            w4_at(w_[0][jx], w_[1][jx], w_[2][jx], w_[3][jx], w_[4][jx], w_[5][jx], y[0][jx], y[1][jx], y[2][jx], y[3][jx]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (SHUF) {
+        // the lane's four "channels" are the phases (py, px) of ONE channel c = 4 cot + kq of the 2 H x 2 W output: rows 2 (4 ty + i) + py,
+        // columns 8 tx + 2 j + px -- the two px phases of a row interleave into 8 consecutive pixels = two 16-byte stores
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (size_t)n * COUT * HW), 0, img_bytes, 0x00020000);
+        int lane_s = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane_s));
+        const int tx_s = 16 * sx + (lane_s & 15);
+        const bool col_ok_s = 4 * tx_s < W;
+        const int so = 4 * cot * 4 * HW * 4;                      // channel 4 cot (+ kq: in the lane offset), 4 HW pixels per channel
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+            f32x4 o0[4], o1[4];                                   // phase px = 0 / 1 of the row phase py, activated
+            {
+                float y[4][4];
+                out_tile(2 * py, y);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx) o0[i][jx] = fmaxf(fmaf(y[i][jx], scv[0], shv[0]), relu_lo);
+                    asm volatile("" : "+v"(o0[i]));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                float y[4][4];
+                out_tile(2 * py + 1, y);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx) o1[i][jx] = fmaxf(fmaf(y[i][jx], scv[0], shv[0]), relu_lo);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int oy = 4 * ty + i;
+                const unsigned lo_s = (col_ok_s && oy < H) ? (unsigned)(((lane_s >> 4) * 4 * HW + (2 * oy + py) * 2 * W + 8 * tx_s) * 4) : WN_OOB;
+                const f32x4 oa = f32x4{o0[i][0], o1[i][0], o0[i][1], o1[i][1]}, ob = f32x4{o0[i][2], o1[i][2], o0[i][3], o1[i][3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oa), yr, lo_s, so, WT ? 16 : 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ob), yr, lo_s + 16u, so, WT ? 16 : 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (size_t)n * COUT * HW), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res1 ? a.res1 + (size_t)n * COUT * HW : a.x), 0, a.res1 ? img_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res2 ? a.res2 + (size_t)n * COUT * HW : a.x), 0, a.res2 ? img_bytes : 0, 0x00020000);
     // Most layers have one residual or none (conv1 of a block has none, conv2 has the block input); every third block and the stack's
-    // end add a second one: template parameter RES2, so that the waits of the kernel without one count exactly the operations in
-    // flight (a load that may or may not have been issued makes every wait behind it a wait for everything; two copies of the
+    // end add a second one: template parameter RES, so that the waits of the kernel without a second one count exactly the operations
+    // in flight (a load that may or may not have been issued makes every wait behind it a wait for everything; two copies of the
     // epilogue inside one kernel spill).
-    constexpr bool has2 = RES2;
+    constexpr bool has1 = RES >= 1, has2 = RES >= 2;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int co = 16 * cot + r;                              // + 4 kq: in the lane offset (4 kq HW)
@@ -404,38 +511,20 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             e2[i] = has2 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2r, lo[i], so, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
-        // (fenced step by step: left alone, the scheduler copies most of the 144 accumulators into vector registers first and the
-        // operands requested early no longer fit)
-        float w_[6][4];                                           // columns transformed: w_[xi][j]
-#pragma unroll
-        for (int x = 0; x < 6; ++x) {
-#pragma unroll
-            for (int v = 0; v < 6; ++v) {                         // (re-fenced at every use: the copy out of the accumulator file stays here)
-                if (6 * x + v < W4_ACC_A) asm volatile("" : "+a"(acc[6 * x + v]));
-                else asm volatile("" : "+v"(acc[6 * x + v]));
-            }
-            w4_at(acc[6 * x][r], acc[6 * x + 1][r], acc[6 * x + 2][r], acc[6 * x + 3][r], acc[6 * x + 4][r], acc[6 * x + 5][r],
-                  w_[x][0], w_[x][1], w_[x][2], w_[x][3]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
         float y[4][4];
-#pragma unroll
-        for (int jx = 0; jx < 4; ++jx) {
-            w4_at(w_[0][jx], w_[1][jx], w_[2][jx], w_[3][jx], w_[4][jx], w_[5][jx], y[0][jx], y[1][jx], y[2][jx], y[3][jx]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        out_tile(r, y);
         f32x4 o[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int jx = 0; jx < 4; ++jx) o[i][jx] = fmaxf(fmaf(y[i][jx], scv[r], shv[r]), relu_lo);
-            o[i] += (r & 1) ? e1b[i] : e1a[i];
+            if (has1) o[i] += (r & 1) ? e1b[i] : e1a[i];
             if (has2) o[i] += e2[i];
         }
         __builtin_amdgcn_sched_barrier(0);
         // residual 1 of channel r + 2 into the registers channel r just freed -- BEFORE this channel's stores: memory operations
         // complete in order, a load behind 16 stores waits for their acknowledgements
-        if (r + 2 < 4) {
+        if (has1 && r + 2 < 4) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1r, lo[i], so + 2 * HW * 4, 0));
@@ -447,6 +536,7 @@ void wino4_3x3_c128_kernel(const WnArgs a) {
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[i]), yr, lo[i], so, WT ? 16 : 0);
         __builtin_amdgcn_sched_barrier(0);
+    }
     }
 #ifdef W4_STAMPS
     if (a.prof && (threadIdx.x & 63) == 0) {
@@ -473,12 +563,9 @@ extern "C" long long ic_wino4_3x3_c128_workgroups(int N, int H, int W) {
     return 2ll * N * ic_cdiv(H, 4) * ic_cdiv(W, 64);
 }
 
-extern "C" int ic_wino4_3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
-                                            const float* res1, const float* res2, float* y, int N, int H, int W, int relu,
-                                            int flags, ic_stream_t stream) {
-    IC_CHECK_ARG(x && w_packed && scale && shift && y);
-    IC_CHECK_ARG(N > 0 && H > 0 && W > 0);
-    if (!ic_wino4_3x3_c128_supported(N, H, W)) return IC_ERR_UNSUPPORTED;
+template <int RES, int CIN, int COUT, bool SHUF>
+static int w4_launch(const float* x, const float* w_packed, const float* scale, const float* shift, const float* res1, const float* res2,
+                     float* y, int N, int H, int W, int relu, int flags, hipStream_t st) {
     WnArgs a{};
     a.x = x; a.wp = w_packed; a.scale = scale; a.shift = shift; a.res1 = res1; a.res2 = res2; a.y = y;
     a.N = N; a.H = H; a.W = W; a.relu = relu;
@@ -487,17 +574,64 @@ extern "C" int ic_wino4_3x3_c128_bn_act_f32(const float* x, const float* w_packe
 #ifdef W4_STAMPS
     a.prof = (unsigned long long*)g_w4_dbg;
 #endif
-    hipStream_t st = (hipStream_t)stream;
-    const long long wgs = 2ll * a.ngroups;
-    const bool wt = wgs <= 512;                                   // a single round of work-groups: write-through stores
+    const long long wgs = (long long)(COUT / 64) * a.ngroups;
     const dim3 grid((unsigned)wgs), block(256);
-    if (res2) {
-        if (wt) hipLaunchKernelGGL((wino4_3x3_c128_kernel<true, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((wino4_3x3_c128_kernel<false, true>), grid, block, 0, st, a);
-    } else {
-        if (wt) hipLaunchKernelGGL((wino4_3x3_c128_kernel<true, false>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((wino4_3x3_c128_kernel<false, false>), grid, block, 0, st, a);
+    if (wgs <= 512) hipLaunchKernelGGL((wino4_3x3_kernel<true, RES, CIN, COUT, SHUF>), grid, block, 0, st, a);     // a single round: write-through stores
+    else hipLaunchKernelGGL((wino4_3x3_kernel<false, RES, CIN, COUT, SHUF>), grid, block, 0, st, a);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
+extern "C" int ic_wino4_3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
+                                            const float* res1, const float* res2, float* y, int N, int H, int W, int relu,
+                                            int flags, ic_stream_t stream) {
+    IC_CHECK_ARG(x && w_packed && scale && shift && y);
+    IC_CHECK_ARG(N > 0 && H > 0 && W > 0);
+    if (!ic_wino4_3x3_c128_supported(N, H, W)) return IC_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (res2) return w4_launch<2, 128, 128, false>(x, w_packed, scale, shift, res1, res2, y, N, H, W, relu, flags, st);
+    return w4_launch<1, 128, 128, false>(x, w_packed, scale, shift, res1, nullptr, y, N, H, W, relu, flags, st);
+}
+
+// ---- the two large 5x5 / stride-2 layers as F(4x4) 3x3 convolutions over phases (packing modes 2 / 3 above) -------------------------
+// h2 (autoencoder.py:223): x_phases [N][4 x 64][H][W] = the four phases of the 64-channel 2H x 2W input (channel (2 py + px) * 64 + c
+// holds X[c][2 i + py][2 j + px]; h1 writes it that way on request, ic_space_to_depth2_f32 makes it from a plain tensor) -> y [N][128][H][W].
+// h12 (autoencoder.py:264): x [N][128][H][W] -> y [N][64][2H][2W], plain layouts.  W % 4 == 0; 10.07 GFLOP direct -> 3.62 executed.
+extern "C" int ic_wino4_conv5s2_supported(int N, int H, int W) {
+    return N > 0 && H > 0 && W > 0 && (W & 3) == 0 && (long long)256 * H * W * 4 < (1ll << 31);
+}
+extern "C" long long ic_wino4_conv5s2_workgroups(int N, int H, int W, int transposed) {
+    if (!ic_wino4_conv5s2_supported(N, H, W)) return 0;
+    return (transposed ? 4ll : 2ll) * N * ic_cdiv(H, 4) * ic_cdiv(W, 64);
+}
+extern "C" int ic_wino4_conv5s2_c64_c128_bn_act_f32(const float* x_phases, const float* w_packed, const float* scale, const float* shift,
+                                                    float* y, int N, int H, int W, int relu, int flags, ic_stream_t stream) {
+    IC_CHECK_ARG(x_phases && w_packed && scale && shift && y);
+    if (!ic_wino4_conv5s2_supported(N, H, W)) return IC_ERR_UNSUPPORTED;
+    return w4_launch<0, 256, 128, false>(x_phases, w_packed, scale, shift, nullptr, nullptr, y, N, H, W, relu, flags, (hipStream_t)stream);
+}
+extern "C" int ic_wino4_deconv5s2_c128_c64_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
+                                                      float* y, int N, int H, int W, int relu, int flags, ic_stream_t stream) {
+    IC_CHECK_ARG(x && w_packed && scale && shift && y);
+    if (!ic_wino4_conv5s2_supported(N, H, W)) return IC_ERR_UNSUPPORTED;
+    return w4_launch<0, 128, 256, true>(x, w_packed, scale, shift, nullptr, nullptr, y, N, H, W, relu, flags, (hipStream_t)stream);
+}
+
+// [N][C][2H][2W] -> [N][4][C][H][W]: phase (py, px) of every channel as its own plane (what ic_wino4_conv5s2_c64_c128_bn_act_f32 reads)
+__global__ __launch_bounds__(256) void space_to_depth2_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int H, int W, long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int w = (int)(i % W); long long t = i / W;
+        const int h = (int)(t % H); t /= H;
+        const int c = (int)(t % C); t /= C;
+        const int ph = (int)(t & 3); const long long n = t >> 2;
+        y[i] = x[((n * C + c) * 2 * H + 2 * h + (ph >> 1)) * 2 * W + 2 * w + (ph & 1)];
     }
+}
+extern "C" int ic_space_to_depth2_f32(const float* x, float* y, int N, int C, int H2, int W2, ic_stream_t stream) {
+    IC_CHECK_ARG(x && y && N > 0 && C > 0 && H2 > 0 && W2 > 0 && !(H2 & 1) && !(W2 & 1));
+    const long long total = (long long)N * C * H2 * W2;
+    const long long g = (total + 255) / 256;
+    hipLaunchKernelGGL(space_to_depth2_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, (hipStream_t)stream, x, y, C, H2 / 2, W2 / 2, total);
     IC_LAUNCH_CHECK();
     return IC_OK;
 }

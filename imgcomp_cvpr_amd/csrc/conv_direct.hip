@@ -111,6 +111,7 @@ int icx_conv2d(ConvArgs a, bool transposed, hipStream_t st) {
             const int rc = icx_conv5s2_cin3_mfma(a, st);
             if (rc != IC_ERR_UNSUPPORTED) return rc;
         }
+        if (a.out_phases) return IC_ERR_UNSUPPORTED;    // only the h1 kernel writes phase planes
         return launch_direct<false>(a, st);
     }
     a.stride = 2; a.OH = 2 * a.H; a.OW = 2 * a.W;

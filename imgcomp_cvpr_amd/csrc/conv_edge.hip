@@ -332,7 +332,10 @@ __global__ __launch_bounds__(256) void conv5s2_cin3_mfma_kernel(const ConvArgs a
     const int gy = oy0 + wave, gx = ox0 + j;
     if (gy >= a.OH || gx >= a.OW) return;
     const size_t ohw = (size_t)a.OH * a.OW;
-    const size_t o0 = ((size_t)n * 64 + 4 * kh) * ohw + (size_t)gy * a.OW + gx;
+    // plain [n][co][gy][gx], or the four phases of the map as planes [n][2 py + px][co][gy / 2][gx / 2] (a.out_phases)
+    const size_t cs = a.out_phases ? ohw / 4 : ohw;
+    const size_t o0 = a.out_phases ? (((size_t)n * 4 + 2 * (gy & 1) + (gx & 1)) * 64 + 4 * kh) * cs + (size_t)(gy >> 1) * (a.OW >> 1) + (gx >> 1)
+                                   : ((size_t)n * 64 + 4 * kh) * ohw + (size_t)gy * a.OW + gx;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(256) void conv5s2_cin3_mfma_kernel(const ConvArgs a
             const int co = 32 * t + (r & 3) + 8 * (r >> 2);          // + 4 kh in the pointers
             float v = fmaf(t ? acc1[r] : acc0[r], a.scale[co + 4 * kh], a.shift[co + 4 * kh]);
             if (a.relu) v = fmaxf(v, 0.f);
-            const size_t o = o0 + (size_t)co * ohw;
+            const size_t o = o0 + (size_t)co * cs;
             if (a.res1) v += a.res1[o];
             if (a.res2) v += a.res2[o];
             a.y[o] = v;
@@ -352,6 +355,7 @@ int icx_conv5s2_cin3_mfma(const ConvArgs& a, hipStream_t st) {
         a.out_mean || (a.builtin_norm & ~1))
         return IC_ERR_UNSUPPORTED;
     if ((long long)a.H * a.W * 3 >= (1ll << 31)) return IC_ERR_UNSUPPORTED;
+    if (a.out_phases && ((a.OH | a.OW) & 1 || a.res1 || a.res2)) return IC_ERR_UNSUPPORTED;
     const int tiles_x = ic_cdiv(a.OW, H1_TC), tiles_y = ic_cdiv(a.OH, H1_TR);
     hipLaunchKernelGGL(conv5s2_cin3_mfma_kernel, dim3((unsigned)(tiles_x * tiles_y * a.N)), dim3(256), 0, st, a, tiles_x,
                        tiles_y);

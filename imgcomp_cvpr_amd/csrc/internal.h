@@ -11,6 +11,8 @@ struct ConvArgs {
     int tune;           // h13 kernel: tiles per work-group (0 = automatic); from the caller's per-call flags
     int builtin_norm;   // bit 0: normalise the input with the reference's fixed image statistics,
                         // bit 1: de-normalise + clip the output with them (autoencoder.py:136-169), bit 2: clip only
+    int out_phases;     // h1 kernel: 1 = write the output as four phase planes [N][4][Cout][OH/2][OW/2] (plane 2 py + px holds the
+                        // pixels (2 i + py, 2 j + px)): what h2 reads in its F(4x4)-over-phases form (conv3x3_wino4.hip); OH, OW even
 };
 
 // fills OH/OW/pads/filter strides for a TF-SAME conv (transposed = stride-2 conv2d_transpose) and launches

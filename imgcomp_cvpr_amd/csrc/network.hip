@@ -159,6 +159,25 @@ extern "C" int ic_ae_res_stack_f32(const float* x, const void* const* tab, int B
     return e == hipSuccess ? IC_OK : (int)e;
 }
 
+// ---- h2 / h12: direct MFMA kernels or the F(4x4)-over-phases form (conv3x3_wino4.hip) ----
+// The caller says with IC_CONV5_BOTH_PACKED that the two filter blobs carry both fragment sets; the F(4x4) form runs where the residual
+// stack of the same call runs F(4x4) (same map, at least as many work-groups), or wherever the shape allows with IC_CONV5_WINO4.
+static bool edge_layers_wino4(int N, int H4, int W4, int flags) {
+    if (!(flags & IC_CONV5_BOTH_PACKED) || (flags & IC_CONV5_NO_WINO4) || !ic_wino4_conv5s2_supported(N, H4, W4)) return false;
+    if (flags & IC_CONV5_WINO4) return true;
+    return ic_conv3x3_c128_pick_form(N, H4, W4, flags) == 2;
+}
+extern "C" size_t ic_conv5s2_both_packed_floats(int transposed) {
+    return ic_conv2d_mfma_packed_floats(5, 5, transposed ? 128 : 64, transposed ? 64 : 128, 2, transposed ? 1 : 0) + ic_wino4_conv5s2_packed_floats();
+}
+extern "C" int ic_pack_conv5s2_both_f32(const float* w_tf, float* w_packed, int transposed, ic_stream_t stream) {
+    IC_CHECK_ARG(w_tf && w_packed);
+    const int tr = transposed ? 1 : 0, cin = tr ? 128 : 64, cout = tr ? 64 : 128;
+    const int rc = ic_pack_conv2d_mfma_f32(w_tf, w_packed, 5, 5, cin, cout, 2, tr, stream);
+    if (rc != IC_OK) return rc;
+    return ic_pack_wino4_conv5s2_f32(w_tf, w_packed + ic_conv2d_mfma_packed_floats(5, 5, cin, cout, 2, tr), tr, stream);
+}
+
 extern "C" int ic_ae_encode_f32(const float* x, const void* const* tab, int B, int C, int L, int heatmap_on,
                                 int normalize_on, float* heatmap, float* z, float* qsoft, float* qhard, float* qbar,
                                 int64_t* symbols, int N, int H, int W,
@@ -178,10 +197,22 @@ extern "C" int ic_ae_encode_f32(const float* x, const void* const* tab, int B, i
     a.x = x; a.w = t[0]; a.scale = t[1]; a.shift = t[2]; a.y = half;
     a.N = N; a.Cin = 3; a.H = H; a.W = W; a.Cout = 64; a.KH = 5; a.KW = 5; a.stride = 2; a.relu = 1;
     a.builtin_norm = normalize_on ? 1 : 0;
-    if ((rc = icx_conv2d(a, false, st))) return rc;
-    // h2: 64 -> 128, 5x5 / 2, BN, ReLU (matrix cores, packed filter)
-    if ((rc = ic_conv2d_mfma_bn_act_f32(half, t[3], t[4], t[5], bufs[0], N, 64, H / 2, W / 2, 128, 5, 5, 2, 0, 1, st)))
-        return rc;
+    // h2: 64 -> 128, 5x5 / 2, BN, ReLU: F(4x4) over the four phases of h1's output (h1 then writes phase planes), or the direct form
+    rc = IC_ERR_UNSUPPORTED;
+    if (edge_layers_wino4(N, H / 4, W / 4, flags)) {
+        a.out_phases = 1;
+        rc = icx_conv2d(a, false, st);
+        if (rc == IC_OK)
+            rc = ic_wino4_conv5s2_c64_c128_bn_act_f32(half, t[3] + ic_conv2d_mfma_packed_floats(5, 5, 64, 128, 2, 0), t[4], t[5], bufs[0],
+                                                      N, H / 4, W / 4, 1, flags, stream);
+        else if (rc != IC_ERR_UNSUPPORTED) return rc;
+        a.out_phases = 0;
+    }
+    if (rc == IC_ERR_UNSUPPORTED) {
+        if ((rc = icx_conv2d(a, false, st))) return rc;
+        rc = ic_conv2d_mfma_bn_act_f32(half, t[3], t[4], t[5], bufs[0], N, 64, H / 2, W / 2, 128, 5, 5, 2, 0, 1, st);
+    }
+    if (rc) return rc;
     int o;
     if ((rc = res_stack(tab + 6, B, bufs, N, H / 4, W / 4, flags, st, &o, (unsigned*)((char*)workspace + ae_sync_offset(N, H, W, C))))) return rc;
     // to_bn: 128 -> C(+1), 5x5 / 2, BN, linear
@@ -200,6 +231,7 @@ extern "C" int ic_ae_encode_f32(const float* x, const void* const* tab, int B, i
         if (e != hipSuccess) return (int)e;
     }
     if (qbar) return IC_ERR_UNSUPPORTED;   // qbar == qhard in value; request qhard instead
+    if (!qsoft && !qhard && !symbols) return IC_OK;      // a network built with quantize=False (autoencoder.py:127-129): z only
     return ic_quantize_f32(bott, centers, L, 1.0f, qsoft, qhard, symbols, cnt, stream);
 }
 
@@ -225,8 +257,13 @@ extern "C" int ic_ae_decode_f32(const float* q, const void* const* tab, int B, i
     if ((rc = res_stack(tab + 3, B, bufs, N, H / 4, W / 4, flags, st, &o, (unsigned*)((char*)workspace + ae_sync_offset(N, H, W, C))))) return rc;
     const float* const* th = t + 3 + 3 * nconv;
     // h12: 128 -> 64, 5x5 transposed / 2, BN, ReLU
-    if ((rc = ic_conv2d_mfma_bn_act_f32(bufs[o], th[0], th[1], th[2], half, N, 128, H / 4, W / 4, 64, 5, 5, 2, 1, 1, st)))
-        return rc;
+    rc = IC_ERR_UNSUPPORTED;
+    if (edge_layers_wino4(N, H / 4, W / 4, flags))
+        rc = ic_wino4_deconv5s2_c128_c64_bn_act_f32(bufs[o], th[0] + ic_conv2d_mfma_packed_floats(5, 5, 128, 64, 2, 1), th[1], th[2], half,
+                                                    N, H / 4, W / 4, 1, flags, stream);
+    if (rc == IC_ERR_UNSUPPORTED)
+        rc = ic_conv2d_mfma_bn_act_f32(bufs[o], th[0], th[1], th[2], half, N, 128, H / 4, W / 4, 64, 5, 5, 2, 1, 1, st);
+    if (rc) return rc;
     // h13: 64 -> 3, 5x5 transposed / 2, BN, linear, de-normalise, clip to [0, 255]
     a = ConvArgs{};
     a.x = half; a.w = th[3]; a.scale = th[4]; a.shift = th[5]; a.y = x_out;

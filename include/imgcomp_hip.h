@@ -61,6 +61,13 @@ typedef void* ic_stream_t;
 #define IC_CONV3_WINO4            0x0b   /* Winograd F(4x4,3x3) (conv3x3_wino4.hip; W % 4 == 0, else the F(2x2) plan) */
 #define IC_CONV3_NO_WINO4         0x800000   /* automatic plan: F(2x2) forms only (A/B runs, bit-identity tests between F(2x2) forms) */
 #define IC_CONV3_WINO4_BITS       0          /* (no flag bits of its own besides the form) */
+/* h2 / h12 of the whole-network entry points (ic_ae_encode_f32 / ic_ae_decode_f32): their filter blobs were packed by
+ * ic_pack_conv5s2_both_f32 (MFMA fragments followed by the F(4x4)-over-phases fragments), so the library may run them on the
+ * F(4x4) kernel where ic_conv3x3_c128_pick_form picks it for the residual stack of the same call; _WINO4: wherever the shape
+ * allows; _NO_WINO4: never.  Without IC_CONV5_BOTH_PACKED the blobs are ic_pack_conv2d_mfma_f32's and the direct kernels run. */
+#define IC_CONV5_BOTH_PACKED      0x1000000
+#define IC_CONV5_WINO4            0x2000000
+#define IC_CONV5_NO_WINO4         0x4000000
 /* IC_CONV3_WINO_T16, IC_CONV3_WINO_PAIR and IC_CONV3_STACK_KERNEL name forms that were built, tested bit-identical and measured
  * slower than or level with what the plan picks.  The shipped library does not carry them (`make TUNING=1` does):
  * ic_build_has_tuning_forms() tells, forcing T16 / PAIR without them returns IC_ERR_UNSUPPORTED, IC_CONV3_STACK_KERNEL is ignored. */
@@ -458,6 +465,32 @@ long long ic_wino4_3x3_c128_workgroups(int N, int H, int W);
 int ic_wino4_3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
                                  const float* res1, const float* res2, float* y, int N, int H, int W, int relu,
                                  int flags, ic_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The two large 5x5 / stride-2 layers on the same kernel (csrc/conv3x3_wino4.hip): a 5x5 / stride-2 SAME convolution is ONE 3x3 /
+ * stride-1 convolution over the four phases of its input stacked as channels, the transposed one is ONE 3x3 convolution to four
+ * phase planes per output channel (tools/phase_conv_check.py) -- in F(4x4,3x3) form 3.62 instead of 10.07 GFLOP per Kodak image.
+ *   h2  (slim.conv2d 64 -> 128, [5,5], stride 2, BN, ReLU; autoencoder.py:223):
+ *        x_phases [N][4][64][H][W]: plane (2 py + px, c) holds X[c][2 i + py][2 j + px] of the [N][64][2H][2W] input
+ *        (ic_space_to_depth2_f32 makes it; ic_ae_encode_f32 has h1 write it directly) -> y [N][128][H][W]
+ *   h12 (slim.conv2d_transpose 128 -> 64, [5,5], stride 2, BN, ReLU; autoencoder.py:264):  x [N][128][H][W] -> y [N][64][2H][2W]
+ * Filters: ic_pack_wino4_conv5s2_f32 from the TF arrays ([5][5][64][128] for both: conv [kh][kw][in][out], transposed
+ * [kh][kw][out][in]), 36 x 256 x 128 floats.  W % 4 == 0 and 256 H W floats below 2 GiB (ic_wino4_conv5s2_supported).
+ * --------------------------------------------------------------------------------------------- */
+size_t ic_wino4_conv5s2_packed_floats(void);
+int ic_pack_wino4_conv5s2_f32(const float* w_tf, float* w_packed, int transposed, ic_stream_t stream);
+int ic_wino4_conv5s2_supported(int N, int H, int W);
+long long ic_wino4_conv5s2_workgroups(int N, int H, int W, int transposed);
+int ic_wino4_conv5s2_c64_c128_bn_act_f32(const float* x_phases, const float* w_packed, const float* scale, const float* shift,
+                                         float* y, int N, int H, int W, int relu, int flags, ic_stream_t stream);
+int ic_wino4_deconv5s2_c128_c64_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
+                                           float* y, int N, int H, int W, int relu, int flags, ic_stream_t stream);
+/* both filter forms of h2 (transposed = 0) / h12 (transposed = 1) in one blob: ic_pack_conv2d_mfma_f32's fragments, then
+ * ic_pack_wino4_conv5s2_f32's at float offset ic_conv2d_mfma_packed_floats(5, 5, cin, cout, 2, transposed) */
+size_t ic_conv5s2_both_packed_floats(int transposed);
+int ic_pack_conv5s2_both_f32(const float* w_tf, float* w_packed, int transposed, ic_stream_t stream);
+/* x [N][C][H2][W2] (H2, W2 even) -> y [N][4][C][H2/2][W2/2], plane 2 py + px = the pixels (2 i + py, 2 j + px) */
+int ic_space_to_depth2_f32(const float* x, float* y, int N, int C, int H2, int W2, ic_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * MS-SSIM training distortion and its gradient (csrc/msssim.hip).  Reference: code/ms_ssim.py:3-186 (5 scales, separable

@@ -257,6 +257,49 @@ def test_conv3x3_c128_winograd_f4(cuda, N, H, W):
                                               L.current_stream()) != 0
 
 
+# h2 / h12 as F(4x4) over phases: a 3x3 layer with K = 256 x 9 (h2) resp. the same transform constants on 5x5 filters; the float32
+# emulation (tools/phase_conv_check.py) gives 1.1e-5 / 8.0e-6 of the tensor scale on N(0, 1) input
+W5_RTOL = 3e-5
+
+
+@pytest.mark.parametrize('N,H,W', [(1, 8, 16), (2, 13, 20), (1, 5, 4), (1, 32, 48), (1, 128, 192)])
+def test_conv5s2_layers_as_winograd_over_phases(cuda, N, H, W):
+    """h2 (5x5 / stride-2 conv 64 -> 128) and h12 (5x5 / stride-2 transposed conv 128 -> 64) on the F(4x4,3x3) kernel -- one 3x3
+    convolution over the four phases of the input / to the four phases of the output (csrc/conv3x3_wino4.hip, packing modes 2 / 3)
+    -- against the oracle's own strided convolutions (TF SAME pads 1 / 2, the transposed crop rule), BN + ReLU folded in."""
+    L = _lib()
+    assert L.lib.ic_wino4_conv5s2_supported(N, H, W) == 1 and L.lib.ic_wino4_conv5s2_supported(N, H, W + 2) == 0
+    rs = np.random.RandomState(900 + H)
+    st = L.current_stream()
+    # ---- h2
+    x = rs.normal(0, 1, (N, 64, 2 * H, 2 * W)).astype(np.float32)
+    w = rs.normal(0, 0.03, (5, 5, 64, 128)).astype(np.float32)
+    scale, shift = _bn(rs, 128)
+    xd, wd, sd, hd = dev(x, cuda), dev(w, cuda), dev(scale, cuda), dev(shift, cuda)
+    xs = torch.empty((N, 4 * 64, H, W), device=cuda)
+    L.check(L.lib.ic_space_to_depth2_f32(L.ptr(xd), L.ptr(xs), N, 64, 2 * H, 2 * W, st))
+    torch.cuda.synchronize()
+    assert torch.equal(xs.view(N, 2, 2, 64, H, W), xd.view(N, 64, H, 2, W, 2).permute(0, 3, 5, 1, 2, 4))
+    wp = torch.empty(L.lib.ic_wino4_conv5s2_packed_floats(), device=cuda)
+    L.check(L.lib.ic_pack_wino4_conv5s2_f32(L.ptr(wd), L.ptr(wp), 0, st))
+    for relu in (1, 0):
+        y = torch.full((N, 128, H, W), float('nan'), device=cuda)
+        L.check(L.lib.ic_wino4_conv5s2_c64_c128_bn_act_f32(L.ptr(xs), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(y), N, H, W, relu, 0, st))
+        torch.cuda.synchronize()
+        assert_close(y, _ref_conv(x, w, scale, shift, 2, relu), 'h2 as F(4x4) over phases {}x{} relu {}'.format(H, W, relu), W5_RTOL)
+    # ---- h12
+    x = rs.normal(0, 1, (N, 128, H, W)).astype(np.float32)
+    w = rs.normal(0, 0.03, (5, 5, 64, 128)).astype(np.float32)              # TF transposed layout [kh][kw][out][in]
+    scale, shift = _bn(rs, 64)
+    xd, wd, sd, hd = dev(x, cuda), dev(w, cuda), dev(scale, cuda), dev(shift, cuda)
+    L.check(L.lib.ic_pack_wino4_conv5s2_f32(L.ptr(wd), L.ptr(wp), 1, st))
+    for relu in (1, 0):
+        y = torch.full((N, 64, 2 * H, 2 * W), float('nan'), device=cuda)
+        L.check(L.lib.ic_wino4_deconv5s2_c128_c64_bn_act_f32(L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(y), N, H, W, relu, 0, st))
+        torch.cuda.synchronize()
+        assert_close(y, _ref_conv(x, w, scale, shift, 2, relu, transposed=True), 'h12 as F(4x4) to phases {}x{} relu {}'.format(H, W, relu), W5_RTOL)
+
+
 def test_conv3x3_c128_winograd_f4_full_load_is_deterministic(cuda):
     """the failure this kernel had in development showed only with two work-groups per CU and several rounds of them (wrong values
     in lanes 12..15 of a 16-lane row; gone without the SLP vectoriser's packed fp32 ops, csrc/Makefile): 1152 work-groups, launches
