@@ -436,7 +436,7 @@ def main():
         try:
             go_enc()
             go_dec()
-            extra['layers_5x5'] = edge_layer_table(torch, lib, _lib, W, ae, ae_cfg, pipe.x, enc.qhard, go_enc.out, go_dec.out, timed, st, N, H, Wd)
+            extra['layers_5x5'] = edge_layer_table(torch, lib, _lib, W, ae, ae_cfg, pipe.x, enc.qhard, go_enc.out, go_dec.out, timed, st, N, H, Wd, step_flags)
         except Exception as ex:                                        # informational only
             extra['layers_5x5'] = {'error': str(ex)[:300]}
         for e in ev:
@@ -556,7 +556,7 @@ def self_launch(n):
     return rc
 
 
-def edge_layer_table(torch, lib, _lib, W, ae, ae_cfg, x, qhard, stack_out_enc, stack_out_dec, timed, st, N, H, Wd):
+def edge_layer_table(torch, lib, _lib, W, ae, ae_cfg, x, qhard, stack_out_enc, stack_out_dec, timed, st, N, H, Wd, step_flags=0):
     """h1, h2, to_bn (autoencoder.py:222,223,237) and from_bn, h12, h13 (:251,264,265) one by one through the generic C-ABI
     entry points, each fed the tensor it sees inside the step.  Per layer: time, algorithmic FLOPs (dense, 2 FLOP per
     MAC) against the fp32 MFMA peak, algorithmic bytes (input + output activation once) against the 8 TB/s HBM peak."""
@@ -593,18 +593,41 @@ def edge_layer_table(torch, lib, _lib, W, ae, ae_cfg, x, qhard, stack_out_enc, s
                                                                                P(xo), N, 64, H // 2, Wd // 2, 3, 5, 5, 0, None, None, 0, st),
          2.0 * 25 * 64 * 3 * px / 4, 4.0 * (64 * px / 4 + 3 * px)),
     ]
+    # h2 / h12 in the form the step runs when the 3x3 stack of the same call runs F(4x4): ONE 3x3 convolution over / to phases on
+    # the F(4x4) kernel (csrc/conv3x3_wino4.hip); FLOPs stay the dense 5x5 figure (the form executes 36 / 100 of them)
+    h4, w4 = H // 4, Wd // 4
+    in_step_w4 = bool(getattr(ae, '_edge_both', False)) and lib.ic_wino4_conv5s2_supported(N, h4, w4) == 1 and \
+        not (step_flags & _lib.CONV5_NO_WINO4) and (bool(step_flags & _lib.CONV5_WINO4) or lib.ic_conv3x3_c128_pick_form(N, h4, w4, step_flags) == 2)
+    if bool(getattr(ae, '_edge_both', False)) and lib.ic_wino4_conv5s2_supported(N, h4, w4) == 1:
+        half_p = torch.empty((N, 256, h4, w4), device=dev)
+        _lib.check(lib.ic_conv2d_bn_act_f32(P(x), P(pl[E + '/h1'][0]), P(pl[E + '/h1'][1]), P(pl[E + '/h1'][2]), None, None, P(half), N, 3, H, Wd, 64, 5, 5, 2, 1,
+                                            None, None, st), 'h1')
+        _lib.check(lib.ic_space_to_depth2_f32(P(half), P(half_p), N, 64, H // 2, Wd // 2, st))
+        off2 = lib.ic_conv2d_mfma_packed_floats(5, 5, 64, 128, 2, 0) * 4
+        off12 = lib.ic_conv2d_mfma_packed_floats(5, 5, 128, 64, 2, 1) * 4
+        w2 = ctypes.c_void_p(pl[E + '/h2'][0].data_ptr() + off2)
+        w12 = ctypes.c_void_p(pl[D + '/h12'][0].data_ptr() + off12)
+        layers.insert(2, ('h2 as F(4x4) over phases', 'wino4_3x3_kernel<256, 128>',
+                          lambda: lib.ic_wino4_conv5s2_c64_c128_bn_act_f32(P(half_p), w2, P(pl[E + '/h2'][1]), P(pl[E + '/h2'][2]), P(quar), N, h4, w4, 1, 0, st),
+                          2.0 * 25 * 64 * 128 * px / 16, 4.0 * (64 * px / 4 + 128 * px / 16)))
+        layers.insert(6, ('h12 as F(4x4) to phases', 'wino4_3x3_kernel<128, 256>',
+                          lambda: lib.ic_wino4_deconv5s2_c128_c64_bn_act_f32(P(stack_out_dec), w12, P(pl[D + '/h12'][1]), P(pl[D + '/h12'][2]), P(half_d), N, h4, w4, 1, 0, st),
+                          2.0 * 25 * 128 * 64 * px / 16, 4.0 * (128 * px / 16 + 64 * px / 4)))
     out, total = [], 0.0
     for name, kernel, fn, flop, nbytes in layers:
         _lib.check(fn(), name)                       # also produces the next layer's input (half -> h2, half_d -> h13)
         us = timed(fn, 20, warm=3) * 1e3
-        total += us
+        runs = (' as F(4x4)' in name) if (name.split(' ')[0] in ('h2', 'h12') and in_step_w4) else (' as F(4x4)' not in name)
+        if runs:
+            total += us
         tf, gbs = flop / us / 1e6, nbytes / us / 1e3
         out.append({'layer': name, 'kernel': kernel, 'us': round(us, 2), 'algorithmic_tflops': round(tf, 1),
                     'frac_of_mfma_peak': round(tf / PEAK_F32_MFMA_TFLOPS, 3), 'algorithmic_bytes': int(nbytes),
                     'hbm_gb_per_s': round(gbs, 0), 'frac_of_hbm_peak': round(gbs / 8000.0, 3),
-                    'bound': 'mfma' if flop / (PEAK_F32_MFMA_TFLOPS * 1e6) > nbytes / 8e6 else 'hbm'})
+                    'bound': 'mfma' if flop / (PEAK_F32_MFMA_TFLOPS * 1e6) > nbytes / 8e6 else 'hbm', 'form_of_the_step': bool(runs)})
     return {'layers': out, 'total_us': round(total, 1),
-            'note': 'each layer alone on the stream on the tensor it sees in the step; FLOPs dense (SURVEY 8(d)), bytes = input + output once'}
+            'note': 'each layer alone on the stream on the tensor it sees in the step; FLOPs dense (SURVEY 8(d)), bytes = input + output once; '
+                    'total_us sums the forms the step runs (form_of_the_step)'}
 
 
 def load_counters(root):
@@ -637,7 +660,7 @@ def plan_name(lib, _lib, N, h4, w4, flags):
         return {'kernel': 'conv3x3_c128_kernel', 'cus': 256, 'form': 'direct'}
     if form == 2:
         wgs = int(lib.ic_wino4_3x3_c128_workgroups(N, h4, w4))
-        return {'kernel': 'wino4_3x3_c128_kernel', 'cus': min(256, wgs), 'form': 'winograd F(4x4,3x3)', 'work_groups': wgs}
+        return {'kernel': 'wino4_3x3_kernel<128, 128>', 'cus': min(256, wgs), 'form': 'winograd F(4x4,3x3)', 'work_groups': wgs}
     pl = (ctypes.c_longlong * 5)()
     _lib.check(lib.ic_wino3x3_c128_plan(N, h4, w4, flags, pl))
     names = []

@@ -541,8 +541,11 @@ void wino4_3x3_kernel(const WnArgs a) {
 #ifdef W4_STAMPS
     if (a.prof && (threadIdx.x & 63) == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long* d = a.prof + 4 * ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6));
-        d[0] = t_loop0 - t_entry; d[1] = t_loop1 - t_loop0; d[2] = __builtin_amdgcn_s_memtime() - t_loop1; d[3] = t_entry;
+        unsigned long long* d = a.prof + 6 * ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6));
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        d[0] = t_loop0 - t_entry; d[1] = t_loop1 - t_loop0; d[2] = t_end - t_loop1; d[3] = t_entry; d[4] = t_end;
+        // HW_ID (wave slot, SIMD, CU, SE) and XCC_ID: which waves followed each other on the same slot (tools/w4prof.py: turnover)
+        d[5] = (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) | ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32);
     }
 #endif
 }

@@ -33,6 +33,8 @@ def short(name):
         base = m.group(1)
         if base == 'wino3x3_c128_tn_kernel' or base == 'wino3x3_c128_stack_kernel':
             return '{}<{}>'.format(base, lead[0])
+        if base == 'wino4_3x3_kernel' and len(ints) >= 4:        # <WT, RES, CIN, COUT, SHUF>: one name per layer type
+            return '{}<{}, {}>'.format(base, ints[2], ints[3])
         if base.startswith(('wino3x3_c128', 'wino4_3x3_c128')):
             return base
         return base + ('<{}>'.format(', '.join(ints)) if ints else '')
@@ -137,7 +139,7 @@ cfg = line.get('config', {})
 # launches of different images overlap (bench.py --in_flight): concurrency = sum of the kernel durations inside the span of the
 # steps / that span.  A kernel's share of the chip's time per launch is avg_us / concurrency.
 # (steady state only: the window from the middle 3x3 launch of the run to the last one -- the first steps load code objects)
-k3s = sorted(t for t in all_k if t[2].startswith(('wino3x3', 'wino4_3x3', 'conv3x3_c128')))
+k3s = sorted(t for t in all_k if t[2].startswith(('wino3x3', 'wino4_3x3_kernel<128, 128>', 'conv3x3_c128')))
 span_us = in_span = 0.0
 if len(k3s) >= 4:
     w0, w1 = k3s[len(k3s) // 2][0], max(t[1] for t in k3s)
@@ -216,7 +218,7 @@ for k in names:
         if n in ent:
             lines.append('   -> {:30s} {}'.format(n, ent[n]))
     lines.append('')
-k3 = [k for k in out['kernels'] if k.startswith(('wino3x3_c128', 'wino4_3x3_c128', 'conv3x3_c128'))]
+k3 = [k for k in out['kernels'] if k.startswith(('wino3x3_c128', 'wino4_3x3_kernel<128, 128>', 'conv3x3_c128'))]
 out['plan_3x3'] = ' + '.join(sorted(k3, key=lambda k: -out['kernels'][k]['launches_per_step'])) if k3 else None
 open(os.path.join(P, tag + '_counters.txt'), 'w').write('\n'.join(lines) + '\n')
 json.dump(out, open(os.path.join(P, tag + '_counters.json'), 'w'), indent=1)
