@@ -597,7 +597,8 @@ def edge_layer_table(torch, lib, _lib, W, ae, ae_cfg, x, qhard, stack_out_enc, s
     # the F(4x4) kernel (csrc/conv3x3_wino4.hip); FLOPs stay the dense 5x5 figure (the form executes 36 / 100 of them)
     h4, w4 = H // 4, Wd // 4
     in_step_w4 = bool(getattr(ae, '_edge_both', False)) and lib.ic_wino4_conv5s2_supported(N, h4, w4) == 1 and \
-        not (step_flags & _lib.CONV5_NO_WINO4) and (bool(step_flags & _lib.CONV5_WINO4) or lib.ic_conv3x3_c128_pick_form(N, h4, w4, step_flags) == 2)
+        not (step_flags & _lib.CONV5_NO_WINO4) and (bool(step_flags & _lib.CONV5_WINO4) or lib.ic_conv3x3_c128_pick_form(N, h4, w4, step_flags) == 2
+                                                    or lib.ic_wino4_conv5s2_workgroups(N, h4, w4, 0) >= 160)
     if bool(getattr(ae, '_edge_both', False)) and lib.ic_wino4_conv5s2_supported(N, h4, w4) == 1:
         half_p = torch.empty((N, 256, h4, w4), device=dev)
         _lib.check(lib.ic_conv2d_bn_act_f32(P(x), P(pl[E + '/h1'][0]), P(pl[E + '/h1'][1]), P(pl[E + '/h1'][2]), None, None, P(half), N, 3, H, Wd, 64, 5, 5, 2, 1,

@@ -358,6 +358,9 @@ void wino4_3x3_kernel(const WnArgs a) {
     };
 
     // ---- prologue: the input of iteration 0, the first filter fragments ----
+    // (what a persistent work-group that inherits its first k-steps from its predecessor would save was measured with this block
+    // compiled out -- wrong results, right timing: 8 Kodak maps 177.0 -> 170.8 us, a 4K map 434 -> 418 us, the bench step +1.5 %:
+    // the other wave of the SIMD fills most of it.  Not built.)
     load_patch(pw);
 #pragma unroll
     for (int Q = 0; Q < W4_RA - 1; ++Q) load_filter(Q, Q);

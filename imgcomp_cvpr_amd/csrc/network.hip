@@ -161,11 +161,14 @@ extern "C" int ic_ae_res_stack_f32(const float* x, const void* const* tab, int B
 
 // ---- h2 / h12: direct MFMA kernels or the F(4x4)-over-phases form (conv3x3_wino4.hip) ----
 // The caller says with IC_CONV5_BOTH_PACKED that the two filter blobs carry both fragment sets; the F(4x4) form runs where the residual
-// stack of the same call runs F(4x4) (same map, at least as many work-groups), or wherever the shape allows with IC_CONV5_WINO4.
+// stack of the same call runs F(4x4) (same map, at least as many work-groups) or the map is at least Kodak-sized, or wherever the
+// shape allows with IC_CONV5_WINO4.
 static bool edge_layers_wino4(int N, int H4, int W4, int flags) {
     if (!(flags & IC_CONV5_BOTH_PACKED) || (flags & IC_CONV5_NO_WINO4) || !ic_wino4_conv5s2_supported(N, H4, W4)) return false;
     if (flags & IC_CONV5_WINO4) return true;
-    return ic_conv3x3_c128_pick_form(N, H4, W4, flags) == 2;
+    // (>= 160 work-groups of h2's launch, i.e. from one Kodak map on, also one image at a time: 85 + 93 -> 53 + 51 us alone, the
+    // one-at-a-time step 159.8 -> 163.0 Mpix/s; smaller maps keep the direct kernels: 28 / 39 against 49 / 44 us at 64 x 64)
+    return ic_conv3x3_c128_pick_form(N, H4, W4, flags) == 2 || ic_wino4_conv5s2_workgroups(N, H4, W4, 0) >= 160;
 }
 extern "C" size_t ic_conv5s2_both_packed_floats(int transposed) {
     return ic_conv2d_mfma_packed_floats(5, 5, transposed ? 128 : 64, transposed ? 64 : 128, 2, transposed ? 1 : 0) + ic_wino4_conv5s2_packed_floats();

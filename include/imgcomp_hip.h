@@ -63,8 +63,8 @@ typedef void* ic_stream_t;
 #define IC_CONV3_WINO4_BITS       0          /* (no flag bits of its own besides the form) */
 /* h2 / h12 of the whole-network entry points (ic_ae_encode_f32 / ic_ae_decode_f32): their filter blobs were packed by
  * ic_pack_conv5s2_both_f32 (MFMA fragments followed by the F(4x4)-over-phases fragments), so the library may run them on the
- * F(4x4) kernel where ic_conv3x3_c128_pick_form picks it for the residual stack of the same call; _WINO4: wherever the shape
- * allows; _NO_WINO4: never.  Without IC_CONV5_BOTH_PACKED the blobs are ic_pack_conv2d_mfma_f32's and the direct kernels run. */
+ * F(4x4) kernel where ic_conv3x3_c128_pick_form picks it for the residual stack of the same call or h2's launch has >= 160
+ * work-groups (a Kodak map); _WINO4: wherever the shape allows; _NO_WINO4: never.  Without IC_CONV5_BOTH_PACKED the blobs are ic_pack_conv2d_mfma_f32's and the direct kernels run. */
 #define IC_CONV5_BOTH_PACKED      0x1000000
 #define IC_CONV5_WINO4            0x2000000
 #define IC_CONV5_NO_WINO4         0x4000000
