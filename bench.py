@@ -470,6 +470,18 @@ def main():
                            'plan_3x3': plan_name(lib, _lib, n2, h2 // 4, w2 // 4, 0)['kernel']})
             ps.branch.close()
         extra['shapes'] = shapes
+        # BASELINE configs[4]: the high-rate configuration on a 4K frame (one image per GPU; a frame fills the chip by itself:
+        # 8100 F(4x4) work-groups per 3x3 launch), one frame at a time
+        try:
+            p4 = Pipeline(dev, 'hi', share, seed=rank).set_input(1, 2160, 3840)
+            dt4, out4 = run(p4, 6, 2)
+            extra['cfg5_4k'] = {'workload': 'BASELINE configs[4]: ae_configs/cvpr/hi + pc_configs/cvpr/res_shallow on one 3840x2160 frame, encode + bitcost + decode',
+                                'value': round(2160 * 3840 * 6 / dt4 / 1e6, 3), 'unit': 'Mpix/s', 'ms_per_step': round(dt4 / 6 * 1e3, 3),
+                                'plan_3x3': plan_name(lib, _lib, 1, 540, 960, 0)['kernel']}
+            p4.branch.close()
+            del p4
+        except Exception as ex:                                        # informational only
+            extra['cfg5_4k'] = {'error': str(ex)[:300]}
         if a.pipelined:
             extra['in_flight_sweep'] = pipelined_section(torch, dev, a, N, H, Wd, pipe)
         if world == 1:

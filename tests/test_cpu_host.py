@@ -159,6 +159,17 @@ def _header_prototypes():
     return set(re.findall(r'\b(ic_[a-z0-9_]+)\s*\(', text))
 
 
+def test_package_asks_for_enough_hardware_queues():
+    """the images in flight (val.py --in_flight, bench.py) have one stream each and the HIP runtime maps all streams onto
+    GPU_MAX_HW_QUEUES hardware queues, 4 by default: importing the package asks for 8 unless the caller has decided."""
+    import subprocess
+    import sys
+    code = 'import os; os.environ.pop("GPU_MAX_HW_QUEUES", None); import imgcomp_cvpr_amd; print(os.environ["GPU_MAX_HW_QUEUES"])'
+    assert subprocess.check_output([sys.executable, '-c', code], cwd=ROOT).decode().strip() == '8'
+    code = 'import os; os.environ["GPU_MAX_HW_QUEUES"] = "2"; import imgcomp_cvpr_amd; print(os.environ["GPU_MAX_HW_QUEUES"])'
+    assert subprocess.check_output([sys.executable, '-c', code], cwd=ROOT).decode().strip() == '2'
+
+
 def test_abi_header_bindings_and_exports_agree():
     """every ic_* prototype of include/imgcomp_hip.h is bound in _lib.PROTOTYPES and exported by the .so
     (no compute calls here: there is no GPU)."""
