@@ -116,6 +116,7 @@ PROTOTYPES = {
     'ic_conv3x3_c128_pick_form': (c_int, [c_int, c_int, c_int, c_int]),
     'ic_wino4_3x3_c128_packed_floats': (c_size_t, []),
     'ic_pack_wino4_3x3_c128_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    'ic_pack_wino4_3x3_c128_batch_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'ic_wino4_3x3_c128_supported': (c_int, [c_int, c_int, c_int]),
     'ic_wino4_3x3_c128_workgroups': (c_longlong, [c_int, c_int, c_int]),
     'ic_wino4_3x3_c128_bn_act_f32': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),

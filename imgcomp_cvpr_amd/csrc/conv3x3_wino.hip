@@ -1054,8 +1054,8 @@ extern "C" int ic_conv3x3_c128_pick_algo(int N, int H, int W, int flags) {
 // of a network: 64 layers x 2.36 MB):
 //   * a launch of >= 512 work-groups (N >= 3 Kodak maps, a 4K map: 426 against 622 us; 8 Kodak maps 175 against 242 us), or
 //   * several independent launches in flight (IC_CONV3_IN_FLIGHT: the images of an evaluation set) with >= 384 work-groups together;
-//   * and only where the map fills its 16-tile segments: 30 maps of 20 x 20 (the training crops: 5 of 16 tiles per segment) take
-//     42.8 against 31.5 us.
+//   * and only where the map fills its 16-tile segments (1 x 16 tiles, or 2 x 8 on narrow maps: whichever needs fewer): 30 maps of
+//     40 x 40 (62 % full) 68 against 95 us; below 55 % the F(2x2) plan stays.
 // One Kodak map alone (192 work-groups, one per CU) is 29.4 against 32.8 us in a loop over ONE layer (tools/w4sweep.py) but loses in
 // the network, where every layer brings new filters: 2.85 against 2.47 ms per image one at a time (bench.py, round 4).
 extern "C" int ic_conv3x3_c128_pick_form(int N, int H, int W, int flags) {
@@ -1066,7 +1066,7 @@ extern "C" int ic_conv3x3_c128_pick_form(int N, int H, int W, int flags) {
     if (!ic_wino4_3x3_c128_supported(N, H, W) || (flags & (IC_CONV3_LEAVE_IDLE_CUS | IC_CONV3_NO_WINO4))) return 1;
     const long long wgs = ic_wino4_3x3_c128_workgroups(N, H, W);
     const long long tiles = (long long)N * ic_cdiv(H, 4) * ic_cdiv(W, 4);
-    if (tiles * 10 < wgs * 8 * 7) return 1;                                       // segments less than 70 % full (16 tiles x 2 halves per segment)
+    if (tiles * 100 < wgs * 8 * 55) return 1;                                     // segments less than 55 % full (16 tiles x 2 halves per segment)
     const int in_flight = (flags >> 19) & 0xf;
     return (wgs >= 512 || (in_flight >= 2 && wgs * in_flight >= 384)) ? 2 : 1;
 }

@@ -83,9 +83,12 @@ __device__ __forceinline__ int w4_tap5(int mode, int phase, int a) {          //
     if (mode == 2) return phase ? 2 * a : (a == 0 ? -1 : 2 * a - 1);
     return phase ? 4 - 2 * a : (a == 2 ? -1 : 3 - 2 * a);
 }
-__global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict__ w_tf, float* __restrict__ out, int mode, int CI, int CO) {
+// (blockIdx.y = layer of a batch: w_tab, when given, holds every layer's filter pointer and the fragments follow each other in out)
+__global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict__ w_tf, const float* const* __restrict__ w_tab, float* __restrict__ out,
+                                                        int mode, int CI, int CO) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= CI * CO) return;
+    if (w_tab) { w_tf = w_tab[blockIdx.y]; out += (size_t)blockIdx.y * 36 * CI * CO; }
     const int cin = idx / CO, cout = idx % CO;
     double g[3][3];
 #pragma unroll
@@ -123,7 +126,16 @@ extern "C" size_t ic_wino4_3x3_c128_packed_floats(void) { return W4_PACKED_FLOAT
 
 extern "C" int ic_pack_wino4_3x3_c128_f32(const float* w_tf, float* w_packed, int backward, ic_stream_t stream) {
     IC_CHECK_ARG(w_tf && w_packed);
-    hipLaunchKernelGGL(wino4_pack_kernel, dim3(WN_C * WN_C / 256), dim3(256), 0, (hipStream_t)stream, w_tf, w_packed, backward ? 1 : 0, WN_C, WN_C);
+    hipLaunchKernelGGL(wino4_pack_kernel, dim3(WN_C * WN_C / 256), dim3(256), 0, (hipStream_t)stream, w_tf, nullptr, w_packed, backward ? 1 : 0, WN_C, WN_C);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
+// every 3x3 filter of a network in one launch (training re-packs them at every step): w_tf_table_dev[l] -> w_packed + l * packed_floats
+extern "C" int ic_pack_wino4_3x3_c128_batch_f32(const float* const* w_tf_table_dev, float* w_packed, int layers, int backward, ic_stream_t stream) {
+    IC_CHECK_ARG(w_tf_table_dev && w_packed && layers > 0);
+    hipLaunchKernelGGL(wino4_pack_kernel, dim3(WN_C * WN_C / 256, layers), dim3(256), 0, (hipStream_t)stream, nullptr, w_tf_table_dev, w_packed,
+                       backward ? 1 : 0, WN_C, WN_C);
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
@@ -133,7 +145,7 @@ extern "C" size_t ic_wino4_conv5s2_packed_floats(void) { return (size_t)36 * 256
 
 extern "C" int ic_pack_wino4_conv5s2_f32(const float* w_tf, float* w_packed, int transposed, ic_stream_t stream) {
     IC_CHECK_ARG(w_tf && w_packed);
-    hipLaunchKernelGGL(wino4_pack_kernel, dim3(256 * 128 / 256), dim3(256), 0, (hipStream_t)stream, w_tf, w_packed, transposed ? 3 : 2,
+    hipLaunchKernelGGL(wino4_pack_kernel, dim3(256 * 128 / 256), dim3(256), 0, (hipStream_t)stream, w_tf, nullptr, w_packed, transposed ? 3 : 2,
                        transposed ? 128 : 256, transposed ? 256 : 128);
     IC_LAUNCH_CHECK();
     return IC_OK;
@@ -172,7 +184,11 @@ __device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, fl
 // Template: WT write-through stores (single-round launches); RES how many residual inputs the epilogue serves (0, 1, 2); CIN / COUT
 // channels (128 / 128: the residual layers; 256 / 128: h2 over its input's phases; 128 / 256: h12 to its output's phases); SHUF:
 // the four "channels" of a lane are the four phases of ONE output channel and are stored interleaved into the 2 H x 2 W map.
-template <bool WT, int RES, int CIN, int COUT, bool SHUF>
+// SEG2: the 16 tiles of a segment are 2 rows x 8 columns (lanes 0..7 / 8..15 of a 16-lane row) instead of 1 x 16 -- maps narrower than
+// 16 tiles (training crops: 32 x 32 maps = 8 x 8 tiles) then fill their segments.  Row validity and row offsets become per-lane (two
+// values per wave: scalar conditions combined with the lane's half), and the lanes 7 / 8 in the middle of a DPP row take the column
+// outside from their own edge load like the lanes 0 / 15 at its ends.
+template <bool WT, int RES, int CIN, int COUT, bool SHUF, bool SEG2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void wino4_3x3_kernel(const WnArgs a) {
     constexpr int KS = CIN / 4, IT = KS / 4, PARTS = COUT / 64;   // k-steps, iterations of 4 k-steps, work-groups per segment
@@ -189,23 +205,27 @@ void wino4_3x3_kernel(const WnArgs a) {
     const int ty = t_ % a.grows, n = t_ / a.grows;
     const int cot = part * 4 + wave;                              // 16-channel tile of this wave
     const int pw = wave & 3;                                      // k-step of an iteration this wave produces
-    const int tx = 16 * sx + n16;
+    const int hrow = SEG2 ? (n16 >> 3) : 0;                       // SEG2: which of the segment's two tile rows this lane works on
+    const int tx = SEG2 ? 8 * sx + (n16 & 7) : 16 * sx + n16;
     const int H = a.H, W = a.W, HW = H * W;
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)n * CIN * HW), 0, CIN * HW * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 36 * CIN * COUT * 4, 0x00020000);
-    // patch rows 4 ty - 1 .. 4 ty + 4: own aligned 4 pixels (columns 4 tx .. 4 tx + 3); the end lanes of the tile row also fetch
-    // the column outside (lane 0: 4 tx - 1, lane 15: 4 tx + 4), every other lane gets an out-of-range offset there
-    // Row validity is wave-uniform (one tile row per work-group), column validity per lane: ONE lane offset for the patch's first
-    // row (out of range when the tile lies beyond the map) and one for the end column; a row outside the image swaps in the
+    // patch rows 4 ty - 1 .. 4 ty + 4: own aligned 4 pixels (columns 4 tx .. 4 tx + 3); the end lanes of a tile row also fetch the
+    // column outside (first lane: 4 tx - 1, last lane: 4 tx + 4), every other lane gets an out-of-range offset there.
+    // Row validity is wave-uniform (SEG2: one value per half), column validity per lane: ONE lane offset for the patch's first row
+    // (out of range when the tile lies beyond the map) and one for the end column; a row outside the image swaps in the
     // out-of-range offset by a scalar condition.
     const bool col_ok = 4 * tx < W;
-    const int ecol = n16 == 0 ? 4 * tx - 1 : (n16 == 15 ? 4 * tx + 4 : -1);
+    const bool first_lane = SEG2 ? (n16 & 7) == 0 : n16 == 0, last_lane = SEG2 ? (n16 & 7) == 7 : n16 == 15;
+    const bool mid_l = SEG2 && n16 == 8, mid_r = SEG2 && n16 == 7;       // lanes whose DPP neighbour belongs to the other tile row
+    const int ecol = first_lane ? 4 * tx - 1 : (last_lane ? 4 * tx + 4 : -1);
     const bool e_ok = col_ok && ecol >= 0 && ecol < W;
-    const int r_first = 4 * ty - 1;
+    const int tyr = SEG2 ? 2 * ty : ty;                           // (first) tile row of the segment: scalar
+    const int r_first = 4 * tyr - 1;
     // (offsets are formed in int: r_first may be -1; the rows actually used are >= 0)
-    const int obase = (kq * HW + r_first * W + 4 * tx) * 4;
-    const int ebase = (kq * HW + r_first * W + ecol) * 4;
+    const int obase = (kq * HW + (r_first + 4 * hrow) * W + 4 * tx) * 4;
+    const int ebase = (kq * HW + (r_first + 4 * hrow) * W + ecol) * 4;
     const unsigned fo = (unsigned)lane * 16u;
 
     // Accumulators are tied to the MFMA's destination by inline asm: the builtin lets the allocator put the result into ANOTHER
@@ -232,7 +252,9 @@ void wino4_3x3_kernel(const WnArgs a) {
         asm volatile("" : "+v"(ob), "+v"(eb));
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const bool row_ok = r_first + i >= 0 && r_first + i < H;          // scalar
+            const bool row_lo = r_first + i >= 0 && r_first + i < H;          // scalar
+            const bool row_hi = r_first + 4 + i < H;                          // scalar: the same patch row of the segment's second tile row
+            const bool row_ok = SEG2 ? (hrow ? row_hi : row_lo) : row_lo;
             const unsigned o1 = (row_ok && col_ok) ? (unsigned)(ob + i * W * 4) : WN_OOB;
             const unsigned o2 = (row_ok && e_ok) ? (unsigned)(eb + i * W * 4) : WN_OOB;
             pr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, o1, so, 0));
@@ -248,6 +270,7 @@ void wino4_3x3_kernel(const WnArgs a) {
         for (int i = 0; i < 6; ++i) {
             u[i][0] = dpp_from_left(pe[i], pr[i][3]);            // column 4 tx - 1 = the left neighbour's last pixel
             u[i][5] = dpp_from_right(pe[i], pr[i][0]);           // column 4 tx + 4 = the right neighbour's first pixel
+            if (SEG2) { u[i][0] = mid_l ? pe[i] : u[i][0]; u[i][5] = mid_r ? pe[i] : u[i][5]; }     // the row's middle is an end too
             u[i][1] = pr[i][0]; u[i][2] = pr[i][1]; u[i][3] = pr[i][2]; u[i][4] = pr[i][3];
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -289,8 +312,14 @@ void wino4_3x3_kernel(const WnArgs a) {
         if (k == 0) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                if (part == 0) su[i][0] = dpp_from_left(pe[i], pr[i][3]);
-                else { su[i][5] = dpp_from_right(pe[i], pr[i][0]); su[i][1] = pr[i][0]; su[i][2] = pr[i][1]; su[i][3] = pr[i][2]; su[i][4] = pr[i][3]; }
+                if (part == 0) {
+                    su[i][0] = dpp_from_left(pe[i], pr[i][3]);
+                    if (SEG2) su[i][0] = mid_l ? pe[i] : su[i][0];
+                } else {
+                    su[i][5] = dpp_from_right(pe[i], pr[i][0]);
+                    if (SEG2) su[i][5] = mid_r ? pe[i] : su[i][5];
+                    su[i][1] = pr[i][0]; su[i][2] = pr[i][1]; su[i][3] = pr[i][2]; su[i][4] = pr[i][3];
+                }
             }
         } else if (k <= 6) {
             const int c = k == 1 ? 0 : (k == 2 ? 5 : k - 2);
@@ -328,11 +357,11 @@ void wino4_3x3_kernel(const WnArgs a) {
         int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         asm volatile("" : "+v"(lane_e));
         kq_e = lane_e >> 4;
-        const int tx_e = 16 * sx + (lane_e & 15);
+        const int tx_e = SEG2 ? 8 * sx + (lane_e & 7) : 16 * sx + (lane_e & 15);
         const bool col_ok_e = 4 * tx_e < W;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int oy = 4 * ty + i;
+            const int oy = 4 * (SEG2 ? 2 * ty + ((lane_e >> 3) & 1) : ty) + i;
             lo[i] = (col_ok_e && oy < H) ? (unsigned)((4 * kq_e * HW + oy * W + 4 * tx_e) * 4) : WN_OOB;
         }
     };
@@ -460,7 +489,8 @@ void wino4_3x3_kernel(const WnArgs a) {
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (size_t)n * COUT * HW), 0, img_bytes, 0x00020000);
         int lane_s = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         asm volatile("" : "+v"(lane_s));
-        const int tx_s = 16 * sx + (lane_s & 15);
+        const int tx_s = SEG2 ? 8 * sx + (lane_s & 7) : 16 * sx + (lane_s & 15);
+        const int ty_s = SEG2 ? 2 * ty + ((lane_s >> 3) & 1) : ty;
         const bool col_ok_s = 4 * tx_s < W;
         const int so = 4 * cot * 4 * HW * 4;                      // channel 4 cot (+ kq: in the lane offset), 4 HW pixels per channel
 #pragma unroll
@@ -489,7 +519,7 @@ void wino4_3x3_kernel(const WnArgs a) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int oy = 4 * ty + i;
+                const int oy = 4 * ty_s + i;
                 const unsigned lo_s = (col_ok_s && oy < H) ? (unsigned)(((lane_s >> 4) * 4 * HW + (2 * oy + py) * 2 * W + 8 * tx_s) * 4) : WN_OOB;
                 const f32x4 oa = f32x4{o0[i][0], o1[i][0], o0[i][1], o1[i][1]}, ob = f32x4{o0[i][2], o1[i][2], o0[i][3], o1[i][3]};
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oa), yr, lo_s, so, WT ? 16 : 0);
@@ -563,29 +593,44 @@ extern "C" int ic_wino4_3x3_c128_supported(int N, int H, int W) {
     return N > 0 && H > 0 && W > 0 && (W & 3) == 0 && (long long)WN_C * H * W * 4 < (1ll << 31);
 }
 
-// work-groups of a launch: (segments of 16 tiles) x 2 channel halves, two per CU
+// segments of 16 tiles: 1 x 16 (wide maps) or 2 x 8 -- whichever covers the map with fewer of them (a tie keeps 1 x 16)
+static inline long long w4_segments(int H, int W, bool seg2) {
+    const long long th = ic_cdiv(H, 4), tw = ic_cdiv(W, 4);
+    return seg2 ? ((th + 1) / 2) * ((tw + 7) / 8) : th * ((tw + 15) / 16);
+}
+static inline bool w4_seg2(int H, int W) { return w4_segments(H, W, true) < w4_segments(H, W, false); }
+
+// work-groups of a launch: segments x 2 channel halves, two per CU
 extern "C" long long ic_wino4_3x3_c128_workgroups(int N, int H, int W) {
     if (!ic_wino4_3x3_c128_supported(N, H, W)) return 0;
-    return 2ll * N * ic_cdiv(H, 4) * ic_cdiv(W, 64);
+    return 2ll * N * w4_segments(H, W, w4_seg2(H, W));
 }
 
-template <int RES, int CIN, int COUT, bool SHUF>
-static int w4_launch(const float* x, const float* w_packed, const float* scale, const float* shift, const float* res1, const float* res2,
-                     float* y, int N, int H, int W, int relu, int flags, hipStream_t st) {
+template <int RES, int CIN, int COUT, bool SHUF, bool SEG2>
+static int w4_launch2(const float* x, const float* w_packed, const float* scale, const float* shift, const float* res1, const float* res2,
+                      float* y, int N, int H, int W, int relu, int flags, hipStream_t st) {
     WnArgs a{};
     a.x = x; a.wp = w_packed; a.scale = scale; a.shift = shift; a.res1 = res1; a.res2 = res2; a.y = y;
     a.N = N; a.H = H; a.W = W; a.relu = relu;
-    a.grows = ic_cdiv(H, 4); a.gcols = ic_cdiv(W, 64); a.xcd_runs = (flags & IC_CONV3_NO_XCD_RUNS) ? 0 : 1;
+    a.grows = SEG2 ? ic_cdiv(ic_cdiv(H, 4), 2) : ic_cdiv(H, 4);
+    a.gcols = SEG2 ? ic_cdiv(W, 32) : ic_cdiv(W, 64);
+    a.xcd_runs = (flags & IC_CONV3_NO_XCD_RUNS) ? 0 : 1;
     a.g0 = 0; a.ngroups = N * a.grows * a.gcols;
 #ifdef W4_STAMPS
     a.prof = (unsigned long long*)g_w4_dbg;
 #endif
     const long long wgs = (long long)(COUT / 64) * a.ngroups;
     const dim3 grid((unsigned)wgs), block(256);
-    if (wgs <= 512) hipLaunchKernelGGL((wino4_3x3_kernel<true, RES, CIN, COUT, SHUF>), grid, block, 0, st, a);     // a single round: write-through stores
-    else hipLaunchKernelGGL((wino4_3x3_kernel<false, RES, CIN, COUT, SHUF>), grid, block, 0, st, a);
+    if (wgs <= 512) hipLaunchKernelGGL((wino4_3x3_kernel<true, RES, CIN, COUT, SHUF, SEG2>), grid, block, 0, st, a);     // a single round: write-through stores
+    else hipLaunchKernelGGL((wino4_3x3_kernel<false, RES, CIN, COUT, SHUF, SEG2>), grid, block, 0, st, a);
     IC_LAUNCH_CHECK();
     return IC_OK;
+}
+template <int RES, int CIN, int COUT, bool SHUF>
+static int w4_launch(const float* x, const float* w_packed, const float* scale, const float* shift, const float* res1, const float* res2,
+                     float* y, int N, int H, int W, int relu, int flags, hipStream_t st) {
+    if (w4_seg2(H, W)) return w4_launch2<RES, CIN, COUT, SHUF, true>(x, w_packed, scale, shift, res1, res2, y, N, H, W, relu, flags, st);
+    return w4_launch2<RES, CIN, COUT, SHUF, false>(x, w_packed, scale, shift, res1, res2, y, N, H, W, relu, flags, st);
 }
 
 extern "C" int ic_wino4_3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
@@ -608,7 +653,7 @@ extern "C" int ic_wino4_conv5s2_supported(int N, int H, int W) {
 }
 extern "C" long long ic_wino4_conv5s2_workgroups(int N, int H, int W, int transposed) {
     if (!ic_wino4_conv5s2_supported(N, H, W)) return 0;
-    return (transposed ? 4ll : 2ll) * N * ic_cdiv(H, 4) * ic_cdiv(W, 64);
+    return (transposed ? 4ll : 2ll) * N * w4_segments(H, W, w4_seg2(H, W));
 }
 extern "C" int ic_wino4_conv5s2_c64_c128_bn_act_f32(const float* x_phases, const float* w_packed, const float* scale, const float* shift,
                                                     float* y, int N, int H, int W, int relu, int flags, ic_stream_t stream) {

@@ -191,8 +191,8 @@ class TrainGraph(object):
 
     # ---- raw convolution (no BN, no activation): forward and data-gradient use ----
     def _pack_all_3x3(self, N, H, W):
-        """Winograd fragments of every 3x3 filter, forward and adjoint, in two launches (the filters change every step).
-        No-op when the shape runs the direct form."""
+        """Winograd fragments of every 3x3 filter, forward and adjoint, in two launches (the filters change every step): F(4x4)
+        fragments where that kernel takes the shape (TrainGraph.WINO4), else F(2x2).  No-op when the shape runs the direct form."""
         self._wino_pk = None
         if lib.ic_conv3x3_c128_pick_algo(N, H, W, 0) != 1:
             return
@@ -202,11 +202,20 @@ class TrainGraph(object):
             self._w3_index = {n: i for i, n in enumerate(self._w3_names)}
             self._w3_table = torch.tensor([self.params[n].data_ptr() for n in self._w3_names], dtype=torch.int64,
                                           device=self.dev)
-            self._w3_buf = self._new(2, len(self._w3_names), lib.ic_wino3x3_c128_packed_floats())
+            self._w3_bufs = {}
+        # F(4x4) from ~160 work-groups on (a work-group's serial chain is ~25 us however small the launch; tools/w4sweep.py: 32 maps of
+        # 32 x 32 31.8 against 40.3 us, 30 of 40 x 40 68 against 95) and where at least half of the segments' tiles exist
+        wgs = int(lib.ic_wino4_3x3_c128_workgroups(N, H, W))
+        tiles = N * (-(-H // 4)) * (-(-W // 4))
+        self._w3_f4 = bool(self.WINO4) and wgs >= 160 and 2 * tiles >= 8 * wgs
+        if self._w3_f4 not in self._w3_bufs:
+            n_pk = lib.ic_wino4_3x3_c128_packed_floats() if self._w3_f4 else lib.ic_wino3x3_c128_packed_floats()
+            self._w3_bufs[self._w3_f4] = self._new(2, len(self._w3_names), n_pk)
+        buf = self._w3_bufs[self._w3_f4]
+        pack = lib.ic_pack_wino4_3x3_c128_batch_f32 if self._w3_f4 else lib.ic_pack_wino3x3_c128_batch_f32
         for b in (0, 1):
-            check(lib.ic_pack_wino3x3_c128_batch_f32(ptr(self._w3_table), ptr(self._w3_buf[b]), len(self._w3_names), b,
-                                                     self._st()), 'batched winograd pack')
-        self._wino_pk = self._w3_buf
+            check(pack(ptr(self._w3_table), ptr(buf[b]), len(self._w3_names), b, self._st()), 'batched winograd pack')
+        self._wino_pk = buf
 
     def _conv3x3(self, x, name, backward=False, res1=None, res2=None):
         """raw 3x3 128->128 conv (backward: its adjoint = the data gradient), + res1 + res2 in the kernel's epilogue (the skip
@@ -219,6 +228,11 @@ class TrainGraph(object):
         if lib.ic_conv3x3_c128_pick_algo(N, H, W, 0) == 1:
             if isinstance(name, str) and getattr(self, '_wino_pk', None) is not None:
                 wp = self._wino_pk[int(backward), self._w3_index[name]]
+                if self._w3_f4:
+                    # Winograd F(4x4,3x3) (csrc/conv3x3_wino4.hip; 2 x 8-tile segments on the crops' small maps): same contract
+                    check(lib.ic_wino4_3x3_c128_bn_act_f32(ptr(x), ptr(wp), ptr(self.ones), ptr(self.zeros), ptr(res1), ptr(res2), ptr(y),
+                                                           N, H, W, 0, 0, st), 'conv3x3 (winograd F(4x4))')
+                    return y
             else:
                 wp = self._new(lib.ic_wino3x3_c128_packed_floats())
                 check(lib.ic_pack_wino3x3_c128_f32(ptr(w_tf), ptr(wp), int(backward), st))
@@ -669,6 +683,12 @@ class TrainGraph(object):
     # HIP_LOSS: the MS-SSIM distortion and its gradient from csrc/msssim.hip (one launch per scale and direction) instead of the
     # ~300 torch kernels of ms_ssim.py -- no graph, no static buffers, any shape with five scales.  False: torch, eagerly.
     HIP_LOSS = True
+    # WINO4: forward and data-gradient 3x3 convolutions in Winograd F(4x4,3x3) form (2 x 8-tile segments on the crops' small maps;
+    # filter gradients stay in the F(2x2) domain, conv3x3_wgrad_wino.hip).  OFF: measured in round 4 on the cfg3 step -- 16.31 against
+    # 16.10 ms (a launch is 31.8 against 40.3 us in a loop over one layer, tools/w4sweep.py, but here every launch brings 2.36 MB of
+    # freshly packed fragments and 256 work-groups leave one wave per SIMD to wait for them), and the gradients through 35 layers
+    # leave the cfg3 bounds (test_cfg3_training_step_full_size).  Kept as a switch for A/B runs.
+    WINO4 = False
 
     def _hip_distortion(self, x):
         """the HIP distortion of this input shape, or None when MS-SSIM is undefined for it (fewer than five scales)"""

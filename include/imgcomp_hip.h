@@ -460,6 +460,8 @@ int ic_peer_allreduce_f64_bounded(double* vals, int n, void* const* regions_host
 int ic_conv3x3_c128_pick_form(int N, int H, int W, int flags);
 size_t ic_wino4_3x3_c128_packed_floats(void);
 int ic_pack_wino4_3x3_c128_f32(const float* w_tf, float* w_packed, int backward, ic_stream_t stream);
+/* all 3x3 filters of a network in one launch: w_tf_table_dev (device array of device pointers) -> fragments l at w_packed + l * packed_floats */
+int ic_pack_wino4_3x3_c128_batch_f32(const float* const* w_tf_table_dev, float* w_packed, int layers, int backward, ic_stream_t stream);
 int ic_wino4_3x3_c128_supported(int N, int H, int W);
 long long ic_wino4_3x3_c128_workgroups(int N, int H, int W);
 int ic_wino4_3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,

@@ -222,7 +222,7 @@ def test_conv3x3_c128_winograd(cuda, shape, N, H, W):
 W4_RTOL = 2e-5
 
 
-@pytest.mark.parametrize('N,H,W', [(1, 16, 64), (2, 13, 20), (1, 7, 4), (1, 40, 72), (3, 10, 36), (1, 128, 192)])
+@pytest.mark.parametrize('N,H,W', [(1, 16, 64), (2, 13, 20), (1, 7, 4), (1, 40, 72), (3, 10, 36), (1, 128, 192), (4, 32, 32), (2, 21, 28)])
 def test_conv3x3_c128_winograd_f4(cuda, N, H, W):
     """Winograd F(4x4,3x3) (csrc/conv3x3_wino4.hip) against the float64 conv: interior and border segments, heights that are
     not multiples of 4, widths with tiles beyond the map, ReLU / one / two residuals, the adjoint packing; odd widths refuse."""
@@ -300,6 +300,24 @@ def test_conv5s2_layers_as_winograd_over_phases(cuda, N, H, W):
         assert_close(y, _ref_conv(x, w, scale, shift, 2, relu, transposed=True), 'h12 as F(4x4) to phases {}x{} relu {}'.format(H, W, relu), W5_RTOL)
 
 
+def test_wino4_batched_packer_equals_the_single_one(cuda):
+    """ic_pack_wino4_3x3_c128_batch_f32 (every 3x3 filter of a network in one launch, forward and adjoint) writes the fragments
+    ic_pack_wino4_3x3_c128_f32 writes layer by layer."""
+    L = _lib()
+    g = torch.Generator().manual_seed(11)
+    ws = [(torch.randn((3, 3, 128, 128), generator=g) * 0.05).to(cuda) for _ in range(3)]
+    table = torch.tensor([w.data_ptr() for w in ws], dtype=torch.int64, device=cuda)
+    n = L.lib.ic_wino4_3x3_c128_packed_floats()
+    for backward in (0, 1):
+        batch = torch.full((3, n), float('nan'), device=cuda)
+        L.check(L.lib.ic_pack_wino4_3x3_c128_batch_f32(L.ptr(table), L.ptr(batch), 3, backward, L.current_stream()))
+        for l, w in enumerate(ws):
+            one = torch.full((n,), float('nan'), device=cuda)
+            L.check(L.lib.ic_pack_wino4_3x3_c128_f32(L.ptr(w), L.ptr(one), backward, L.current_stream()))
+            torch.cuda.synchronize()
+            assert torch.equal(batch[l], one), 'layer {} backward {}'.format(l, backward)
+
+
 def test_conv3x3_c128_winograd_f4_full_load_is_deterministic(cuda):
     """the failure this kernel had in development showed only with two work-groups per CU and several rounds of them (wrong values
     in lanes 12..15 of a 16-lane row; gone without the SLP vectoriser's packed fp32 ops, csrc/Makefile): 1152 work-groups, launches
@@ -355,7 +373,7 @@ def test_conv3x3_c128_auto_selection(cuda):
     pf = L.lib.ic_conv3x3_c128_pick_form
     assert pf(1, 128, 192, 0) == 1 and pf(8, 128, 192, 0) == 2 and pf(1, 512, 512, 0) == 2
     assert pf(1, 128, 192, L.CONV3_IN_FLIGHT(6)) == 2 and pf(1, 32, 32, L.CONV3_IN_FLIGHT(6)) == 1
-    assert pf(60, 20, 20, 0) == 1                                          # 600 work-groups, 5 of 16 tiles per segment
+    assert pf(200, 12, 12, 0) == 1 and pf(30, 40, 40, 0) == 2              # 800 work-groups 28 % full; 600 work-groups 62 % full
     assert pf(8, 128, 192, L.CONV3_NO_WINO4) == 1 and pf(8, 128, 192, L.CONV3_WINO) == 2 and pf(8, 128, 190, 0) == 1
     assert pf(1, 16, 16, L.CONV3_WINO4) == 2 and pf(1, 4096, 2048, 0) == 0
     outs = []

@@ -26,7 +26,7 @@ def timed(x, r, y, flags, reps=100):
 
 
 for shape in ((1, 32, 32), (1, 64, 64), (2, 64, 64), (4, 64, 64), (8, 64, 64), (1, 64, 96), (1, 96, 128), (1, 128, 128), (1, 128, 192), (2, 128, 192),
-              (3, 128, 192), (1, 192, 256), (1, 256, 384), (30, 20, 20), (1, 20, 20)):
+              (3, 128, 192), (1, 192, 256), (1, 256, 384), (30, 20, 20), (1, 20, 20), (32, 32, 32), (30, 40, 40), (8, 32, 32)):
     x = torch.relu(torch.randn((shape[0], 128) + shape[1:], device=dev))
     r, y = torch.randn_like(x), torch.empty_like(x)
     t4, t2 = timed(x, r, y, L.CONV3_WINO4), timed(x, r, y, L.CONV3_NO_WINO4)
