@@ -63,6 +63,9 @@
 #ifndef W4_PRE
 #define W4_PRE 31                                   // quad of the LAST iteration at which the epilogue's first operands are requested (-1: in the epilogue)
 #endif
+#ifndef W4_WT_MAX
+#define W4_WT_MAX 512                                // launches of at most this many work-groups (a single round) store write-through
+#endif
 #ifndef W4_SPREAD
 #define W4_SPREAD 1                                 // 1: the transform of a turn is cut into 26 pieces of 6 vector instructions, two per
 #endif                                              //    quad, each behind an MFMA (whose 8 passes hide them); 0: one block of ~200
@@ -621,7 +624,7 @@ static int w4_launch2(const float* x, const float* w_packed, const float* scale,
 #endif
     const long long wgs = (long long)(COUT / 64) * a.ngroups;
     const dim3 grid((unsigned)wgs), block(256);
-    if (wgs <= 512) hipLaunchKernelGGL((wino4_3x3_kernel<true, RES, CIN, COUT, SHUF, SEG2>), grid, block, 0, st, a);     // a single round: write-through stores
+    if (wgs <= W4_WT_MAX) hipLaunchKernelGGL((wino4_3x3_kernel<true, RES, CIN, COUT, SHUF, SEG2>), grid, block, 0, st, a);     // a single round: write-through stores
     else hipLaunchKernelGGL((wino4_3x3_kernel<false, RES, CIN, COUT, SHUF, SEG2>), grid, block, 0, st, a);
     IC_LAUNCH_CHECK();
     return IC_OK;
