@@ -416,10 +416,14 @@ def main():
         roofline = {'kernel': enc_l['plan']['kernel'] + ' (ic_conv3x3_c128_auto_f32, encoder residual stack, in-step)',
                     'algorithm': {0: 'direct', 1: 'winograd F(2x2,3x3)', 2: 'winograd F(4x4,3x3)'}[form3], 'bound': 'mfma',
                     'achieved': enc_l['achieved'], 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': enc_l['frac'],
+                    # the same launch in the FLOPs of the direct form (SURVEY 8(d)'s 294,912 per output pixel): what the layer delivers;
+                    # > 1 for the Winograd forms, which execute 16/36 (F(2x2)) or 36/144 (F(4x4)) of them
+                    'direct_equivalent_tflops': enc_l['direct_equivalent_tflops'], 'direct_equivalent_frac': enc_l['direct_equivalent_frac'],
                     'traffic': traffic, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': traffic_src,
                     'algorithmic_bytes_per_launch': int(3 * 512 * N * h4 * w4 + {0: 589824, 1: 1048576, 2: 2359296}[form3]),
                     'launches_per_step': 2 * (6 * int(ae_cfg.arch_param_B) + 2),
-                    'note': 'achieved = FLOPs the matrix pipe executes (Winograd F(2x2): 16/36 of the direct form, F(4x4): 36/144) / the time in which the chip '
+                    'note': 'frac is against the 2.4 GHz peak; under this load the chip sustains ~1.75 GHz (DESIGN section 3: in-kernel stamps, 0.70 of the '
+                            'matrix-pipe cycles).  achieved = FLOPs the matrix pipe executes (Winograd F(2x2): 16/36 of the direct form, F(4x4): 36/144) / the time in which the chip '
                             'completes one launch of the stack: HIP events around {} stacks in flight, one per stream, as in the step; '
                             '`encoder.alone` = the same launch with nothing beside it (its duration in a kernel trace, on plan.cus of 256 CUs)'.format(n_flight),
                     'from_profiles': from_profiles, 'encoder': enc_l, 'decoder': dec_l}
