@@ -1057,7 +1057,10 @@ extern "C" int ic_conv3x3_c128_pick_algo(int N, int H, int W, int flags) {
 //   * and only where the map fills its 16-tile segments (1 x 16 tiles, or 2 x 8 on narrow maps: whichever needs fewer): 30 maps of
 //     40 x 40 (62 % full) 68 against 95 us; below 55 % the F(2x2) plan stays.
 // One Kodak map alone (192 work-groups, one per CU) is 29.4 against 32.8 us in a loop over ONE layer (tools/w4sweep.py) but loses in
-// the network, where every layer brings new filters: 2.85 against 2.47 ms per image one at a time (bench.py, round 4).
+// the network, where every layer brings new filters: 2.85 against 2.47 ms per image one at a time (bench.py, round 4).  That the cold
+// fragments are the reason was checked by having every launch touch the NEXT layer's fragments once per XCD (a prototype in the
+// kernel's prologue): one image at a time with F(4x4) forced 140.7 -> 164.1 Mpix/s -- level with the F(2x2) plan's 162.5, so the plan
+// stays as it is --, and 261.8 -> 257.3 with images in flight, where other launches hide the misses already.  Not kept.
 extern "C" int ic_conv3x3_c128_pick_form(int N, int H, int W, int flags) {
     if (ic_conv3x3_c128_pick_algo(N, H, W, flags) == 0) return 0;
     const int form = flags & IC_CONV3_FORM_MASK;
