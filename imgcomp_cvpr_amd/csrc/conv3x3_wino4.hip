@@ -181,6 +181,10 @@ __device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, fl
     y3 = fmaf(8.f, d2, d1) + m5;
 }
 
+// (Also built and measured in round 4 for launches that are alone on the chip -- one Kodak map, 192 work-groups, one wave per SIMD --:
+// an 8-wave K-split work-group, waves 0..3 the first half of the k-steps, waves 4..7 the second, two rings, the partial sums
+// exchanged through LDS and each group finishing two of a lane's four channels.  Correct, and slower: 37.4 against 29.2 us per
+// launch (the exchange, 144 KB of LDS per work-group and 512-thread barriers cost more than the halved chain gives back).  Removed.)
 // A work-group (4 waves) is one HALF of the output channels of a segment, two work-groups per CU.  (An 8-wave work-group -- all
 // 128 channels, the input transform made once per segment instead of once per half -- was built and measured in round 4: 199.5
 // against 190 us on 8 Kodak maps, 53 against 35 us on one; removed.)
