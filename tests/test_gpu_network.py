@@ -69,6 +69,26 @@ def test_encode_matches_oracle(cuda, configs, syn_weights, nets, shape, kind, al
     assert torch.equal(enc.qbar.cpu(), (ae._last_qsoft + (enc.qhard - ae._last_qsoft)).cpu())
 
 
+@pytest.mark.parametrize('shape', [(1, 3, 32, 96), (3, 3, 48, 32), (2, 3, 96, 160)])
+def test_f4_everywhere_small_and_narrow_maps(cuda, configs, syn_weights, nets, shape):
+    """F(4x4) forced for the 3x3 layers AND for h2 / h12 (phase form) on maps that take the 2 x 8-tile segments (8 x 24, 12 x 8) and
+    on one that takes 1 x 16 (24 x 40): encoder and decoder against the oracle."""
+    from imgcomp_cvpr_amd import weights as W, _lib
+    from oracle import oracle as O
+    ae, _ = nets
+    ae_cfg, _ = configs
+    flags = _lib.CONV3_WINO4 | _lib.CONV5_WINO4
+    x = W.synthetic_image(shape, 'natural', seed=9)
+    enc = ae.encode(dev(x, cuda), is_training=False, plan_flags=flags)
+    torch.cuda.synchronize()
+    ref = O.encode(torch.as_tensor(x).double(), syn_weights, ae_cfg.as_dict())
+    assert_close(enc.z, ref.z, 'F(4x4) everywhere, z {}'.format(shape), NET_RTOL)
+    assert_close(enc.heatmap, ref.heatmap, 'F(4x4) everywhere, heatmap {}'.format(shape), HEATMAP_RTOL)
+    xo = ae.decode(dev(ref.qhard.float().numpy(), cuda), is_training=False, plan_flags=flags)
+    assert_close(xo, O.decode(ref.qhard, syn_weights, ae_cfg.as_dict()), 'F(4x4) everywhere, x_out {}'.format(shape), NET_RTOL)
+    assert not torch.equal(enc.z, ae.encode(dev(x, cuda), is_training=False, plan_flags=_lib.CONV5_NO_WINO4 | _lib.CONV3_NO_WINO4).z)
+
+
 @pytest.mark.parametrize('heatmap', [True, False])
 def test_encode_without_quantizer(cuda, configs, syn_weights, heatmap):
     """_Network(config, quantize=False) (autoencoder.py:34-36, :127-129): the encoder output is the (masked) bottleneck itself --
