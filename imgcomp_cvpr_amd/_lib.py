@@ -126,6 +126,8 @@ PROTOTYPES = {
     'ic_wino4_conv5s2_workgroups': (c_longlong, [c_int, c_int, c_int, c_int]),
     'ic_wino4_conv5s2_c64_c128_bn_act_f32': (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     'ic_wino4_deconv5s2_c128_c64_bn_act_f32': (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    'ic_val_metrics_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'ic_val_metrics_u8_f64': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'ic_space_to_depth2_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ic_conv5s2_both_packed_floats': (c_size_t, [c_int]),
     'ic_pack_conv5s2_both_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),

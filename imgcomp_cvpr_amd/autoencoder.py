@@ -240,6 +240,16 @@ class _CVPR(_Network):
         """the caller's per-call plan bits + what this object's filter blobs hold"""
         return int(plan_flags) | (_lib.CONV5_BOTH_PACKED if self._edge_both else 0)
 
+    def sharing_weights(self):
+        """a second object of this network over the SAME device weights, packed filters and pointer tables, with its own workspace
+        and per-call state -- for a caller that keeps several images in flight, one object per stream (val.py), without uploading
+        and packing the weights once per stream."""
+        import copy
+        other = copy.copy(self)
+        other._ws = None
+        other._last_qsoft = None
+        return other
+
     def _workspace(self, N, H, W):
         need = lib.ic_ae_workspace_bytes(N, H, W, self._C)
         if self._ws is None or self._ws.numel() < need:

@@ -145,6 +145,32 @@ def msssim_nchw_uint8_device(x, y):
     return msssim_from_scale_values(msssim_scale_values_device(x, y).tolist())       # one device -> host transfer
 
 
+_VM_WS = {}
+
+
+def val_metrics_device(x, y):
+    """both metrics of val.py for uint8 NCHW tensors ON A HIP DEVICE in one call of the library (csrc/val_metrics.hip: float64,
+    the numpy code's operations in the numpy code's order, 16 launches): -> (the 5 scale values msssim_from_scale_values takes,
+    the mean squared error) as views of ONE float64 device tensor, nothing waited for."""
+    import torch
+    from . import _lib
+    assert x.dtype == torch.uint8 and y.dtype == torch.uint8, 'Expected uint8 input'
+    if x.shape != y.shape:
+        raise RuntimeError('Input images must have the same shape ({} vs. {}).'.format(tuple(x.shape), tuple(y.shape)))
+    _lib.require_cuda(x, 'x')
+    x, y = x.contiguous(), y.contiguous()
+    N, C, H, W = x.shape
+    need = _lib.lib.ic_val_metrics_workspace_bytes(N, C, H, W)
+    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
+    ws = _VM_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _VM_WS[key] = torch.empty(need, dtype=torch.uint8, device=x.device)       # one per device and stream: calls on a stream are ordered
+    out = torch.empty(6, dtype=torch.float64, device=x.device)
+    _lib.check(_lib.lib.ic_val_metrics_u8_f64(_lib.ptr(x), _lib.ptr(y), N, C, H, W, _lib.ptr(out), _lib.ptr(ws), need,
+                                              _lib.current_stream(x.device)), 'ic_val_metrics_u8_f64')
+    return out[:5], out[5]
+
+
 def msssim_scale_values_device(x, y):
     """the device half of msssim_nchw_uint8_device: the per-scale contrast terms and the last scale's SSIM as ONE float64 device
     tensor, nothing waited for (val.py keeps several images in flight and reads the values later)"""
@@ -152,6 +178,9 @@ def msssim_scale_values_device(x, y):
     assert x.dtype == torch.uint8 and y.dtype == torch.uint8, 'Expected uint8 input'
     if x.shape != y.shape:
         raise RuntimeError('Input images must have the same shape ({} vs. {}).'.format(tuple(x.shape), tuple(y.shape)))
+    if x.is_cuda:
+        return val_metrics_device(x, y)[0]
+    # (CPU tensors: the torch twin of the numpy code, tap by tap)
     im1 = x.permute(0, 2, 3, 1).to(torch.float64)
     im2 = y.permute(0, 2, 3, 1).to(torch.float64)
     mssim, mcs = [], []
@@ -175,6 +204,8 @@ def msssim_from_scale_values(vals):
 def mse_uint8_device(a, b):
     import torch
     assert a.dtype == torch.uint8 and b.dtype == torch.uint8, 'Expected uint8 input'
+    if a.is_cuda and a.dim() == 4:
+        return val_metrics_device(a, b)[1]
     return ((a.to(torch.float64) - b.to(torch.float64)) ** 2).mean()
 
 

@@ -199,6 +199,17 @@ class _ResShallow(_Network3D):
         self._tab_tensors = tabs + [packed]
         self._tab = _lib.ptr_table(self._tab_tensors)
 
+    def sharing_weights(self):
+        """a second object of this network over the SAME device weights and packed filters with its own workspace and caches: one
+        per stream for a caller that keeps several images in flight (val.py)."""
+        import copy
+        other = copy.copy(self)
+        other._ws = None
+        other._last_logits = None
+        if hasattr(other, '_pad_cache'):
+            del other._pad_cache
+        return other
+
     def _workspace(self, N, C, h, w):
         need = lib.ic_pc_workspace_bytes(N, C, h, w, self._k)
         if self._ws is None or self._ws.numel() < need:

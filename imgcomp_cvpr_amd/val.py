@@ -161,16 +161,21 @@ class ValuesAggregator(object):
 class Fetcher(object):
     """builds the networks once, then maps one padded uint8 CHW image to its measures."""
 
-    def __init__(self, ae_config, pc_config, weights, device, host_metrics=False, plan_flags=0):
+    def __init__(self, ae_config, pc_config, weights, device, host_metrics=False, plan_flags=0, share_with=None):
         self.device = torch.device(device)
         self.host_metrics = host_metrics        # True: MS-SSIM / PSNR in numpy on the host, as the reference does
-        self.ae = autoencoder.get_network_cls(ae_config)(ae_config).load_weights(weights, self.device)
-        self.pc = probclass.get_network_cls(pc_config)(pc_config, num_centers=ae_config.num_centers).load_weights(
-            weights, self.device)
+        if share_with is not None:
+            # another stream of the same evaluation: the first fetcher's device weights and packed filters, own workspaces
+            self.ae, self.pc = share_with.ae.sharing_weights(), share_with.pc.sharing_weights()
+        else:
+            self.ae = autoencoder.get_network_cls(ae_config)(ae_config).load_weights(weights, self.device)
+            self.pc = probclass.get_network_cls(pc_config)(pc_config, num_centers=ae_config.num_centers).load_weights(
+                weights, self.device)
         self.ae.plan_flags = int(plan_flags)          # e.g. _lib.CONV3_IN_FLIGHT(n): validate() keeps n fetchers busy at once
         self.pc_config = pc_config
         self._bpp_fetcher = None
         self._streams = streams.BranchStreams(self.device)
+        self._copy_stream = None
 
     def __call__(self, img_chw_uint8, want_symbols=False, want_image=False):
         return self.collect(self.enqueue(img_chw_uint8, want_symbols, want_image))
@@ -181,8 +186,18 @@ class Fetcher(object):
         x_uint8 = torch.as_tensor(img_chw_uint8)[None]
         outer, main = torch.cuda.current_stream(self.device), self._streams.main
         main.wait_stream(outer)
+        x_dev = None
+        if self.device.type == 'cuda':
+            # the image goes up on a stream of its own: a copy from pageable memory makes the host wait until its stream has reached
+            # it, which on the compute stream means waiting for the image before this one (2.1 of the 2.6 ms an enqueue took,
+            # tools/val_host_profile.py, tools/h2d_probe.py)
+            if self._copy_stream is None:
+                self._copy_stream = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(self._copy_stream):
+                x_dev = x_uint8.to(self.device)
+            main.wait_stream(self._copy_stream)
         with torch.cuda.stream(main):
-            return self._measure(x_uint8, want_symbols, want_image)
+            return self._measure(x_uint8, want_symbols, want_image, x_dev)
 
     def collect(self, pending):
         main = self._streams.main
@@ -196,8 +211,11 @@ class Fetcher(object):
         torch.cuda.current_stream(self.device).wait_stream(main)
         return otp
 
-    def _measure(self, x_uint8, want_symbols, want_image):
-        x_uint8_dev = x_uint8.to(self.device, non_blocking=True)
+    def _measure(self, x_uint8, want_symbols, want_image, x_uint8_dev=None):
+        if x_uint8_dev is None:
+            x_uint8_dev = x_uint8.to(self.device, non_blocking=True)
+        else:
+            x_uint8_dev.record_stream(torch.cuda.current_stream(self.device))        # allocated on the copy stream, used on this one
         x = x_uint8_dev.float()
         enc = self.ae.encode(x, is_training=False)
         # decoder and context model are independent consumers of the encoder output: with a CU-range arrangement (streams.py) the
@@ -218,10 +236,9 @@ class Fetcher(object):
             ms = float(metrics.msssim_nchw_uint8(x_uint8.numpy(), x_out_uint8))
             ps = float(metrics.psnr_uint8(x_uint8.numpy(), x_out_uint8))
         else:
-            # the same float64 computation on the device: 0.5 s of numpy per Kodak image would dwarf the 2.4 ms GPU path
+            # the same float64 computation on the device (csrc/val_metrics.hip): 0.5 s of numpy per Kodak image would dwarf the 2.4 ms GPU path
             # (device tensors, nothing waited for here: collect() finishes them on the host)
-            ms = metrics.msssim_scale_values_device(x_uint8_dev, x_out_uint8_dev)
-            ps = metrics.mse_uint8_device(x_uint8_dev, x_out_uint8_dev)
+            ms, ps = metrics.val_metrics_device(x_uint8_dev, x_out_uint8_dev)
         if want_symbols:
             arrays['sym'] = enc.symbols
         if want_image:
@@ -236,8 +253,31 @@ class Fetcher(object):
         return self._bpp_fetcher.get_bpp(symbols, num_pixels)
 
 
+def _decoded_ahead(image_paths, indices, pad, threads):
+    """(index, CHW uint8 image) in order, the PNGs decoded by a few host threads a bounded distance ahead of the consumer: a
+    Kodak-sized PNG takes the host ~10 ms to decode and the device ~1.5 ms to code (PIL's decoder and zlib release the GIL)."""
+    if threads <= 1 or len(indices) <= 1:
+        for idx in indices:
+            yield idx, load_image_chw(image_paths[idx], pad)
+        return
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        ahead, it = deque(), iter(indices)
+        for idx in it:
+            ahead.append((idx, pool.submit(load_image_chw, image_paths[idx], pad)))
+            if len(ahead) >= 2 * threads:
+                break
+        while ahead:
+            idx, fut = ahead.popleft()
+            nxt = next(it, None)
+            if nxt is not None:
+                ahead.append((nxt, pool.submit(load_image_chw, image_paths[nxt], pad)))
+            yield idx, fut.result()
+
+
 def validate(ae_config, pc_config, weights, image_paths, out_dir, flags, device='cuda', verbose=True, host_metrics=False,
-             in_flight=4):
+             in_flight=4, loader_threads=8):
     """-> dict of averages; writes out_dir/measures.csv (rank 0).
     in_flight: images of this rank processed concurrently, each by its own Fetcher (networks, workspace, stream): the images
     are independent (the reference runs one per sess.run, val.py:157-158), and the launches of one fill the kernel-boundary
@@ -245,9 +285,9 @@ def validate(ae_config, pc_config, weights, image_paths, out_dir, flags, device=
     from collections import deque
     rank, world = sharding.rank_and_world()
     n_f = 1 if (flags.real_bpp or host_metrics) else max(1, int(in_flight))
-    fetchers = [Fetcher(ae_config, pc_config, weights, device, host_metrics=host_metrics,
-                        plan_flags=_lib.CONV3_IN_FLIGHT(n_f) if n_f > 1 else 0) for _ in range(n_f)]
-    fetcher = fetchers[0]
+    fetcher = Fetcher(ae_config, pc_config, weights, device, host_metrics=host_metrics, plan_flags=_lib.CONV3_IN_FLIGHT(n_f) if n_f > 1 else 0)
+    fetchers = [fetcher] + [Fetcher(ae_config, pc_config, weights, device, host_metrics=host_metrics,
+                                    plan_flags=_lib.CONV3_IN_FLIGHT(n_f), share_with=fetcher) for _ in range(n_f - 1)]
     pad = fetcher.ae.get_subsampling_factor()
     local = []
     pending = deque()
@@ -268,9 +308,8 @@ def validate(ae_config, pc_config, weights, image_paths, out_dir, flags, device=
             save_img(path.basename(p), otp.pop('img_out'), out_dir)
         local.append((idx, (path.basename(p), otp)))
 
-    for k, idx in enumerate(sharding.shard_indices(len(image_paths), rank, world)):
+    for k, (idx, img) in enumerate(_decoded_ahead(image_paths, list(sharding.shard_indices(len(image_paths), rank, world)), pad, loader_threads)):
         p = image_paths[idx]
-        img = load_image_chw(p, pad)
         f = fetchers[k % n_f]
         if len(pending) == n_f:
             finish()                                  # the oldest image ran on this fetcher: its buffers are free again
@@ -332,6 +371,7 @@ def main(argv=None):
     p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                    help='process group of a multi-rank run (nccl = RCCL, one GPU per rank; gloo lets ranks share a GPU in tests)')
     p.add_argument('--in_flight', type=int, default=4, help='images processed concurrently per GPU, one stream each (1 = one at a time)')
+    p.add_argument('--loader_threads', type=int, default=8, help='host threads decoding PNGs ahead of the device (1 = decode in the loop)')
     flags, unknown = p.parse_known_args(argv)
     if unknown:
         print('Unknown flags: {}'.format(unknown))
@@ -366,7 +406,7 @@ def main(argv=None):
             sharding.barrier()
         avgs = validate(ae_config, pc_config, weights, image_paths, out_dir,
                         OutputFlags(flags.save_ours, -1, flags.real_bpp), device, host_metrics=bool(flags.host_metrics),
-                        in_flight=flags.in_flight)
+                        in_flight=flags.in_flight, loader_threads=flags.loader_threads)
         if sharding.rank_and_world()[0] == 0:
             print('Validation completed: {} | {}'.format(out_dir, avgs))
     print('*** All given job_ids validated.')

@@ -495,6 +495,16 @@ int ic_pack_conv5s2_both_f32(const float* w_tf, float* w_packed, int transposed,
 int ic_space_to_depth2_f32(const float* x, float* y, int N, int C, int H2, int W2, ic_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * val.py's image metrics (val.py:92-96, ms_ssim_np.py:49-110) of two uint8 NCHW batches, float64 on the device (csrc/val_metrics.hip):
+ * out6[s] = mean contrast-structure term of scale s (s = 0 .. 3), out6[4] = mean SSIM of scale 4, out6[5] = mean squared error.
+ * MS-SSIM = prod_s out6[s] ^ w_s with ms_ssim_np.py's weights, PSNR = 10 log10(255^2 / out6[5]) (imgcomp_cvpr_amd/metrics.py).
+ * Every scale needs at least one 'valid' blur output (any image of 16 x 16 pixels or more).
+ * --------------------------------------------------------------------------------------------- */
+size_t ic_val_metrics_workspace_bytes(int N, int C, int H, int W);
+int ic_val_metrics_u8_f64(const unsigned char* x, const unsigned char* y, int N, int C, int H, int W, double* out6,
+                          void* workspace, size_t workspace_bytes, ic_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * MS-SSIM training distortion and its gradient (csrc/msssim.hip).  Reference: code/ms_ssim.py:3-186 (5 scales, separable
  * Gaussian 'VALID' blur with REFLECT pads on small scales, 2x2 box between scales), train.py:352-394
  * (d_loss_scaled = K_ms_ssim * (1 - MS-SSIM(x, x_out)); TensorFlow derives d / d x_out, here it is written out).

@@ -396,6 +396,11 @@ def test_device_metrics_match_numpy(cuda):
         ad, bd = torch.as_tensor(a).to(cuda), torch.as_tensor(b).to(cuda)
         assert abs(metrics.msssim_nchw_uint8_device(ad, bd) - float(metrics.msssim_nchw_uint8(a, b))) < 1e-6
         assert abs(metrics.psnr_uint8_device(ad, bd) - float(metrics.psnr_uint8(a, b))) < 1e-4
+        # the library's kernels (csrc/val_metrics.hip) against the tap-by-tap torch twin on the CPU: same operations in the same order
+        vals, mse = metrics.val_metrics_device(ad, bd)
+        twin = metrics.msssim_scale_values_device(torch.as_tensor(a), torch.as_tensor(b))
+        assert float((vals.cpu() - twin).abs().max()) < 1e-12, (vals.cpu(), twin)
+        assert float(mse) == float(metrics.mse_uint8_device(torch.as_tensor(a), torch.as_tensor(b)))
     assert metrics.psnr_uint8_device(ad, ad) == float('inf') and metrics.msssim_nchw_uint8_device(ad, ad) == 1.0
 
 

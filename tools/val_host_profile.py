@@ -1,0 +1,37 @@
+import os, sys, time
+sys.path.insert(0, '/root/repo')
+import numpy as np, torch
+from imgcomp_cvpr_amd import val, metrics, config_parser as cp, weights as W
+ae, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'low'))
+pc, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
+wts = W.synthetic_weights(ae, pc)
+f = val.Fetcher(ae, pc, wts, 'cuda')
+img = np.clip(W.synthetic_image((1, 3, 512, 768), 'natural', seed=0)[0], 0, 255).astype(np.uint8)
+for _ in range(3): f(img)
+torch.cuda.synchronize()
+def t(fn, n=20):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): r = fn()
+    th = time.perf_counter() - t0
+    torch.cuda.synchronize(); tt = time.perf_counter() - t0
+    return th / n * 1e3, tt / n * 1e3
+print('enqueue (host ms, host+device ms):', t(lambda: f.enqueue(img)))
+print('whole __call__:', t(lambda: f(img)))
+xd = torch.as_tensor(img)[None].cuda(); yd = xd.clone()
+print('msssim device:', t(lambda: metrics.msssim_scale_values_device(xd, yd)))
+print('mse device:', t(lambda: metrics.mse_uint8_device(xd, yd)))
+x = xd.float()
+print('encode:', t(lambda: f.ae.encode(x, False)))
+enc = f.ae.encode(x, False)
+print('bitcost+bpp:', t(lambda: val.bits.bitcost_to_bpp(f.pc.bitcost(enc.qbar, enc.symbols, False, pad_value=f.pc.auto_pad_value(f.ae)), x)))
+print('decode:', t(lambda: f.ae.decode(enc.qhard, False)))
+print('h2d + float:', t(lambda: torch.as_tensor(img)[None].to('cuda', non_blocking=True).float()))
+import cProfile, pstats
+pr = cProfile.Profile()
+torch.cuda.synchronize()
+pr.enable()
+for _ in range(30):
+    f.enqueue(img)
+pr.disable()
+torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats('cumulative').print_stats(22)
