@@ -145,13 +145,24 @@ def msssim_nchw_uint8_device(x, y):
     return msssim_from_scale_values(msssim_scale_values_device(x, y).tolist())       # one device -> host transfer
 
 
-_VM_WS = {}
+class ValMetricsWorkspace(object):
+    """scratch of val_metrics_device, owned by the caller that issues the calls of ONE stream (val.Fetcher): grown on demand, reused"""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            import torch
+            self.buf = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+        return self.buf
 
 
-def val_metrics_device(x, y):
+def val_metrics_device(x, y, workspace=None):
     """both metrics of val.py for uint8 NCHW tensors ON A HIP DEVICE in one call of the library (csrc/val_metrics.hip: float64,
     the numpy code's operations in the numpy code's order, 16 launches): -> (the 5 scale values msssim_from_scale_values takes,
-    the mean squared error) as views of ONE float64 device tensor, nothing waited for."""
+    the mean squared error) as views of ONE float64 device tensor, nothing waited for.  workspace: a ValMetricsWorkspace of the
+    calling stream (None: a fresh allocation for this call)."""
     import torch
     from . import _lib
     assert x.dtype == torch.uint8 and y.dtype == torch.uint8, 'Expected uint8 input'
@@ -161,10 +172,7 @@ def val_metrics_device(x, y):
     x, y = x.contiguous(), y.contiguous()
     N, C, H, W = x.shape
     need = _lib.lib.ic_val_metrics_workspace_bytes(N, C, H, W)
-    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
-    ws = _VM_WS.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _VM_WS[key] = torch.empty(need, dtype=torch.uint8, device=x.device)       # one per device and stream: calls on a stream are ordered
+    ws = (workspace or ValMetricsWorkspace()).get(need, x.device)
     out = torch.empty(6, dtype=torch.float64, device=x.device)
     _lib.check(_lib.lib.ic_val_metrics_u8_f64(_lib.ptr(x), _lib.ptr(y), N, C, H, W, _lib.ptr(out), _lib.ptr(ws), need,
                                               _lib.current_stream(x.device)), 'ic_val_metrics_u8_f64')

@@ -176,6 +176,7 @@ class Fetcher(object):
         self._bpp_fetcher = None
         self._streams = streams.BranchStreams(self.device)
         self._copy_stream = None
+        self._metrics_ws = metrics.ValMetricsWorkspace()
 
     def __call__(self, img_chw_uint8, want_symbols=False, want_image=False):
         return self.collect(self.enqueue(img_chw_uint8, want_symbols, want_image))
@@ -238,7 +239,7 @@ class Fetcher(object):
         else:
             # the same float64 computation on the device (csrc/val_metrics.hip): 0.5 s of numpy per Kodak image would dwarf the 2.4 ms GPU path
             # (device tensors, nothing waited for here: collect() finishes them on the host)
-            ms, ps = metrics.val_metrics_device(x_uint8_dev, x_out_uint8_dev)
+            ms, ps = metrics.val_metrics_device(x_uint8_dev, x_out_uint8_dev, self._metrics_ws)
         if want_symbols:
             arrays['sym'] = enc.symbols
         if want_image:

@@ -159,6 +159,26 @@ def _header_prototypes():
     return set(re.findall(r'\b(ic_[a-z0-9_]+)\s*\(', text))
 
 
+def test_val_decodes_images_ahead_in_order(tmp_path):
+    """val.py's loader threads hand the images to the loop in the order of the file list, whatever order they finish in, and
+    one thread (or one image) is the plain loop."""
+    from PIL import Image
+    from imgcomp_cvpr_amd import val
+    paths = []
+    for i in range(13):
+        a = np.full((8 + i, 16, 3), i, np.uint8)
+        p = str(tmp_path / 'img{:02d}.png'.format(i))
+        Image.fromarray(a).save(p)
+        paths.append(p)
+    idx = [12, 0, 5, 7, 1, 2, 3, 11, 4]
+    for threads in (1, 3, 8):
+        got = list(val._decoded_ahead(paths, idx, 8, threads))
+        assert [g[0] for g in got] == idx
+        for i, img in got:
+            assert img.shape[0] == 3 and img.shape[1] % 8 == 0 and int(img[0, img.shape[1] // 2, 8]) == i
+    assert list(val._decoded_ahead(paths, [], 8, 4)) == []
+
+
 def test_package_asks_for_enough_hardware_queues():
     """the images in flight (val.py --in_flight, bench.py) have one stream each and the HIP runtime maps all streams onto
     GPU_MAX_HW_QUEUES hardware queues, 4 by default: importing the package asks for 8 unless the caller has decided."""
