@@ -475,7 +475,7 @@ def main():
             ps.branch.close()
         extra['shapes'] = shapes
         # BASELINE configs[4]: the high-rate configuration on a 4K frame (one image per GPU; a frame fills the chip by itself:
-        # 8100 F(4x4) work-groups per 3x3 launch), one frame at a time
+        # 4050 F(4x4) work-groups per 3x3 launch), one frame at a time
         try:
             p4 = Pipeline(dev, 'hi', share, seed=rank).set_input(1, 2160, 3840)
             dt4, out4 = run(p4, 6, 2)

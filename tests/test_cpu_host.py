@@ -159,6 +159,24 @@ def _header_prototypes():
     return set(re.findall(r'\b(ic_[a-z0-9_]+)\s*\(', text))
 
 
+def test_conv3x3_plan_queries_are_host_logic():
+    """which kernel a 3x3 launch runs is decided on the host (ic_conv3x3_c128_pick_form and friends: no device call): the rules of
+    DESIGN section 3 -- F(4x4) where two of its work-groups per CU are resident and the map fills its segments, in the better of the
+    two segment shapes; h2 / h12 in phase form where the width allows."""
+    from imgcomp_cvpr_amd import _lib as L
+    pf, wg = L.lib.ic_conv3x3_c128_pick_form, L.lib.ic_wino4_3x3_c128_workgroups
+    assert wg(1, 128, 192) == 192 and wg(8, 128, 192) == 1536 and wg(1, 540, 960) == 4050
+    assert wg(32, 32, 32) == 256 and wg(1, 32, 32) == 8            # 8 x 8 tiles: 2 x 8-tile segments (1 x 16 would need 16)
+    assert wg(1, 128, 190) == 0 and pf(1, 128, 190, 0) == 1        # W % 4 != 0: F(2x2)
+    assert pf(1, 128, 192, 0) == 1 and pf(1, 128, 192, L.CONV3_IN_FLIGHT(4)) == 2 and pf(8, 128, 192, 0) == 2
+    assert pf(8, 128, 192, L.CONV3_NO_WINO4) == 1 and pf(8, 128, 192, L.CONV3_DIRECT) == 0 and pf(1, 4096, 2048, 0) == 0
+    assert pf(30, 40, 40, 0) == 2 and pf(200, 12, 12, 0) == 1      # 62 % / 28 % of the segments' tiles exist
+    assert L.lib.ic_wino4_conv5s2_supported(1, 128, 192) == 1 and L.lib.ic_wino4_conv5s2_supported(1, 128, 190) == 0
+    assert L.lib.ic_wino4_conv5s2_workgroups(1, 128, 192, 0) == 192 and L.lib.ic_wino4_conv5s2_workgroups(1, 128, 192, 1) == 384
+    assert L.lib.ic_conv5s2_both_packed_floats(0) == L.lib.ic_conv2d_mfma_packed_floats(5, 5, 64, 128, 2, 0) + 36 * 256 * 128
+    assert L.lib.ic_conv3x3_c128_both_packed_floats() == 9 * 128 * 128 + 2 * 16 * 128 * 128 + 36 * 128 * 128
+
+
 def test_val_decodes_images_ahead_in_order(tmp_path):
     """val.py's loader threads hand the images to the loop in the order of the file list, whatever order they finish in, and
     one thread (or one image) is the plain loop."""

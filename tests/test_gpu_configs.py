@@ -67,7 +67,7 @@ def test_cfg5_full_4k_tile_properties(cuda):
     assert tuple(s1.shape) == (1, 64, 270, 480) and bool(torch.isfinite(z1).all())
     e2 = ae.encode(x, False)
     assert torch.equal(z1, e2.z) and torch.equal(s1, e2.symbols), 'encode is not deterministic at 4K'
-    # the automatic choice at this size is F(4x4) (8100 work-groups); forcing it changes nothing
+    # the automatic choice at this size is F(4x4) (4050 work-groups); forcing it changes nothing
     assert _lib.lib.ic_conv3x3_c128_pick_form(1, 540, 960, 0) == 2
     assert torch.equal(z1, ae.encode(x, False, plan_flags=_lib.CONV3_WINO4).z), 'forcing the automatic choice changes the result'
     # the F(2x2) multi-round plan against one forced F(2x2) form: bit-identical (same operations per output)
