@@ -1,5 +1,7 @@
 """-m gpu: the BASELINE.json configurations at (or near) their real sizes -- the cases the small parity tests leave out:
 
+  cfg2  Kodak-shaped 512 x 768 image, low + res_shallow: the whole path against the float64 oracle at FULL size in every plan the
+        benchmark's step runs (the oracle takes 4 s on the GPU box's host);
   cfg3  ae_configs/cvpr/med + res_shallow, 32 x 3 x 128 x 128 crops, MS-SSIM loss: one training step, forward values and a
         spread of parameter gradients against float64 autograd of the oracle;
   cfg4  --real_bpp on a full Kodak-sized symbol volume (32 x 64 x 96 = 196,608 symbols): the parallel pass feeds the
@@ -24,6 +26,39 @@ def _nets(cuda, ae_name, pc_name, seed=1234):
     ae = autoencoder.get_network_cls(ae_cfg)(ae_cfg).load_weights(wts, cuda)
     pc = probclass.get_network_cls(pc_cfg)(pc_cfg, num_centers=ae_cfg.num_centers).load_weights(wts, cuda)
     return ae_cfg, pc_cfg, wts, ae, pc
+
+
+@pytest.mark.parametrize('plan', ['in_flight', 'one_at_a_time', 'direct'])
+def test_cfg2_kodak_size_matches_oracle_in_every_plan(cuda, plan):
+    """BASELINE configs[1] at its FULL size (512 x 768, low + res_shallow) against the float64 oracle, in the plans the benchmark's step
+    runs: with images in flight (F(4x4) for the 64 3x3 layers and for h2 / h12), one image at a time (F(2x2) 3x3 layers, F(4x4) h2 /
+    h12) and all-direct.  z, heatmap, symbols (bit-exact outside the fp32 band of a decision midpoint; measured: no flip at all),
+    bit cost, bpp, x_out."""
+    from imgcomp_cvpr_amd import bits, weights as W, _lib
+    from oracle import oracle as O
+    ae_cfg, pc_cfg, wts, ae, pc = _nets(cuda, 'low', 'res_shallow')
+    flags = {'in_flight': _lib.CONV3_IN_FLIGHT(4), 'one_at_a_time': 0, 'direct': _lib.CONV3_DIRECT | _lib.CONV5_NO_WINO4}[plan]
+    assert _lib.lib.ic_conv3x3_c128_pick_form(1, 128, 192, flags) == {'in_flight': 2, 'one_at_a_time': 1, 'direct': 0}[plan]
+    x = W.synthetic_image((1, 3, 512, 768), 'natural', seed=0)
+    xd = dev(x, cuda)
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        ref = O.encode(torch.as_tensor(x).double(), wts, ae_cfg.as_dict())
+        centers = wts['autoencoder/encoder/centers']
+        rb, _ = O.bitcost(ref.qhard, ref.symbols, wts, float(centers[0]))
+        ref_xo = O.decode(ref.qhard, wts, ae_cfg.as_dict())
+    enc = ae.encode(xd, False, plan_flags=flags)
+    torch.cuda.synchronize()
+    assert_close(enc.z, ref.z, 'cfg2 512x768 z ({})'.format(plan), NET_RTOL)
+    assert_close(enc.heatmap, ref.heatmap, 'cfg2 512x768 heatmap ({})'.format(plan), HEATMAP_RTOL)
+    flips = (enc.symbols.cpu() != ref.symbols).numpy()
+    assert record_flips('cfg2 512x768 ' + plan, flips) < 2e-3
+    q = torch.as_tensor(centers)[ref.symbols].double()
+    bc = pc.bitcost(dev(q.numpy(), cuda), dev(ref.symbols.numpy(), cuda, torch.int64), False, pad_value=pc.auto_pad_value(ae))
+    assert_close(bc, rb, 'cfg2 512x768 bit cost ({})'.format(plan), NET_RTOL)
+    assert abs(float(bits.bitcost_to_bpp(bc, xd)) - O.bitcost_to_bpp(rb, torch.as_tensor(x))) < 1e-4
+    xo = ae.decode(dev(ref.qhard.float().numpy(), cuda), False, plan_flags=flags)
+    assert_close(xo, ref_xo, 'cfg2 512x768 x_out ({})'.format(plan), NET_RTOL)
 
 
 def test_cfg5_hi_res_shallow_matches_oracle(cuda):
