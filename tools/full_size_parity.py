@@ -1,6 +1,7 @@
 """BASELINE configs[1] at its full size against the float64 oracle (too slow for the test-suite: ~1 min of CPU): one Kodak-shaped image
 through the plans the benchmark's step runs -- F(4x4) for the 3x3 layers and h2 / h12 (as with images in flight) and the one-at-a-time
-plan -- z, heatmap, symbol flips, bit cost and bpp, x_out.      python tools/full_size_parity.py"""
+plan -- z, heatmap, symbol flips, bit cost and bpp, x_out.      python tools/full_size_parity.py [ae_config H W]
+(`hi 2160 3840` = BASELINE configs[4] on a whole 4K frame: ~2 min of float64 oracle on 16 host threads)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,12 +10,13 @@ from oracle import oracle as O
 
 torch.set_num_threads(16)
 dev = torch.device('cuda:0')
-ae_cfg, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'low'))
+AE, H, Wd = (sys.argv[1], int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else ('low', 512, 768)
+ae_cfg, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', AE))
 pc_cfg, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
 wts = W.synthetic_weights(ae_cfg, pc_cfg)
 ae = autoencoder.get_network_cls(ae_cfg)(ae_cfg).load_weights(wts, dev)
 pc = probclass.get_network_cls(pc_cfg)(pc_cfg, num_centers=ae_cfg.num_centers).load_weights(wts, dev)
-x = W.synthetic_image((1, 3, 512, 768), 'natural', seed=0)
+x = W.synthetic_image((1, 3, H, Wd), 'natural', seed=0)
 t0 = time.time()
 with torch.no_grad():
     ref = O.encode(torch.as_tensor(x).double(), wts, ae_cfg.as_dict())
