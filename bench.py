@@ -641,7 +641,9 @@ def edge_layer_table(torch, lib, _lib, W, ae, ae_cfg, x, qhard, stack_out_enc, s
         out.append({'layer': name, 'kernel': kernel, 'us': round(us, 2), 'algorithmic_tflops': round(tf, 1),
                     'frac_of_mfma_peak': round(tf / PEAK_F32_MFMA_TFLOPS, 3), 'algorithmic_bytes': int(nbytes),
                     'hbm_gb_per_s': round(gbs, 0), 'frac_of_hbm_peak': round(gbs / 8000.0, 3),
-                    'bound': 'mfma' if flop / (PEAK_F32_MFMA_TFLOPS * 1e6) > nbytes / 8e6 else 'hbm', 'form_of_the_step': bool(runs)})
+                    'bound': 'mfma' if flop / (PEAK_F32_MFMA_TFLOPS * 1e6) > nbytes / 8e6 else 'hbm', 'form_of_the_step': bool(runs),
+                    # the F(4x4)-over-phases form executes 36 of every 100 dense multiplies: its frac_of_mfma_peak (dense FLOPs) can pass 1
+                    'executed_fraction_of_dense_flops': 0.36 if ' as F(4x4)' in name else 1.0})
     return {'layers': out, 'total_us': round(total, 1),
             'note': 'each layer alone on the stream on the tensor it sees in the step; FLOPs dense (SURVEY 8(d)), bytes = input + output once; '
                     'total_us sums the forms the step runs (form_of_the_step)'}
