@@ -300,6 +300,40 @@ def test_conv5s2_layers_as_winograd_over_phases(cuda, N, H, W):
         assert_close(y, _ref_conv(x, w, scale, shift, 2, relu, transposed=True), 'h12 as F(4x4) to phases {}x{} relu {}'.format(H, W, relu), W5_RTOL)
 
 
+def test_conv5s2_phase_forms_agree_with_the_direct_kernels_on_random_shapes(cuda):
+    """fuzz: h2 / h12 in F(4x4)-over-phases form against the direct MFMA kernels of the same layers (each is checked against the oracle
+    above) on random map sizes -- odd heights, widths of one to many 4-pixel tiles, both segment shapes, batches."""
+    L = _lib()
+    rs = np.random.RandomState(77)
+    st = L.current_stream()
+    w = torch.as_tensor(rs.normal(0, 0.03, (5, 5, 64, 128)).astype(np.float32)).to(cuda)
+    wp4 = torch.empty(L.lib.ic_wino4_conv5s2_packed_floats(), device=cuda)
+    shapes = [(1, 1, 4), (2, 3, 8), (1, 9, 36), (3, 16, 32)] + [(int(rs.randint(1, 4)), int(rs.randint(1, 40)), 4 * int(rs.randint(1, 20))) for _ in range(10)]
+    for tr in (0, 1):
+        cin, cout = (128, 64) if tr else (64, 128)
+        sc, sh = torch.rand(cout, device=cuda) + 0.5, torch.randn(cout, device=cuda) * 0.1
+        wpm = torch.empty(L.lib.ic_conv2d_mfma_packed_floats(5, 5, cin, cout, 2, tr), device=cuda)
+        L.check(L.lib.ic_pack_conv2d_mfma_f32(L.ptr(w), L.ptr(wpm), 5, 5, cin, cout, 2, tr, st))
+        L.check(L.lib.ic_pack_wino4_conv5s2_f32(L.ptr(w), L.ptr(wp4), tr, st))
+        for N, H, W in shapes:
+            if tr:
+                x = torch.randn((N, 128, H, W), device=cuda)
+                y_d, y_w = torch.full((N, 64, 2 * H, 2 * W), float('nan'), device=cuda), torch.full((N, 64, 2 * H, 2 * W), float('nan'), device=cuda)
+                L.check(L.lib.ic_conv2d_mfma_bn_act_f32(L.ptr(x), L.ptr(wpm), L.ptr(sc), L.ptr(sh), L.ptr(y_d), N, 128, H, W, 64, 5, 5, 2, 1, 1, st))
+                L.check(L.lib.ic_wino4_deconv5s2_c128_c64_bn_act_f32(L.ptr(x), L.ptr(wp4), L.ptr(sc), L.ptr(sh), L.ptr(y_w), N, H, W, 1, 0, st))
+            else:
+                x = torch.randn((N, 64, 2 * H, 2 * W), device=cuda)
+                xs = torch.empty((N, 256, H, W), device=cuda)
+                y_d, y_w = torch.full((N, 128, H, W), float('nan'), device=cuda), torch.full((N, 128, H, W), float('nan'), device=cuda)
+                L.check(L.lib.ic_space_to_depth2_f32(L.ptr(x), L.ptr(xs), N, 64, 2 * H, 2 * W, st))
+                L.check(L.lib.ic_conv2d_mfma_bn_act_f32(L.ptr(x), L.ptr(wpm), L.ptr(sc), L.ptr(sh), L.ptr(y_d), N, 64, 2 * H, 2 * W, 128, 5, 5, 2, 0, 1, st))
+                L.check(L.lib.ic_wino4_conv5s2_c64_c128_bn_act_f32(L.ptr(xs), L.ptr(wp4), L.ptr(sc), L.ptr(sh), L.ptr(y_w), N, H, W, 1, 0, st))
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(y_w).all()), (tr, N, H, W)
+            err = float((y_w - y_d).abs().max()) / max(1.0, float(y_d.abs().max()))
+            assert err < W5_RTOL, 'transposed {} shape {}: {}'.format(tr, (N, H, W), err)
+
+
 def test_wino4_batched_packer_equals_the_single_one(cuda):
     """ic_pack_wino4_3x3_c128_batch_f32 (every 3x3 filter of a network in one launch, forward and adjoint) writes the fragments
     ic_pack_wino4_3x3_c128_f32 writes layer by layer."""
