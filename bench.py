@@ -114,11 +114,13 @@ class Pipeline(object):
         enc = self.ae.encode(self.x, is_training=False)
         if self.serial:
             bc = self.pc.bitcost(enc.qbar, enc.symbols, is_training=False, pad_value=self.pad_value)
+            self.last = (enc, bc)       # references only (tests/test_gpu_bench.py compares z / symbols / bits of this very schedule)
             return bits.bitcost_to_bpp(bc, self.x), self.ae.decode(enc.qhard, is_training=False)
         self.side.wait_stream(cur)
         with torch.cuda.stream(self.side):
             bc = self.pc.bitcost(enc.qbar, enc.symbols, is_training=False, pad_value=self.pad_value)
             bpp = bits.bitcost_to_bpp(bc, self.x)
+        self.last = (enc, bc)
         # per-call plan flag: next to a CU-range side stream the decoder's 3x3 launches leave that stream's CUs alone
         x_out = self.ae.decode(enc.qhard, is_training=False, plan_flags=self.dec_flags)
         cur.wait_stream(self.side)

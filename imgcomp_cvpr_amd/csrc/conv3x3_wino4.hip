@@ -33,11 +33,24 @@
 // clocks; no change at full load, where the other wave fills the pipe anyway); epilogue operands two channels ahead and in front
 // of the stores (epilogue 20 k -> 8.5 k clocks) 175 us.  F(2x2) plan on the same input: 242 us.
 //
-// BUILD NOTE (csrc/Makefile): this file is compiled with -fno-slp-vectorize.  With the SLP vectoriser's packed fp32 instructions
-// (v_pk_fma_f32 / v_pk_add_f32) in the input transform the kernel returned wrong values in lanes 12..15 of 16-lane rows, a few
-// per 10^7 outputs, never twice in the same place, ONLY when two waves shared a SIMD -- not with one work-group per CU, not with
-// the LDS ring enlarged, not with extra barriers or MFMA drains (tools/w4dbg.py, tools/w4conc.py: ~50 % of launches wrong with,
-// 0 of 75 without).  tests/test_gpu_ops.py::test_conv3x3_c128_winograd_f4_full_load_is_deterministic holds the full-load case.
+// INLINE-ASM MFMAs AND THE COMPILER (round 5; experiment log: profiles/r05_w4_rootcause.md).  The MFMAs below are asm statements so that
+// the accumulator stays tied to the destination.  hipcc orders an asm statement by its operands but does not know it is an MFMA, so it
+// pads none of the matrix-pipe hazards the hardware leaves to software:
+//   (A) a non-MFMA instruction touching an MFMA's destination needs >= 11 wait states behind it (8-pass XDL; hipcc: s_nop 9 + 1),
+//   (B) a VALU write of a register an MFMA reads needs 2 wait states before it (hipcc: s_nop 1).
+// The code written here keeps both by construction: A / B operands come from LDS and buffer loads (waited for, no wait states
+// needed), accumulators are touched only behind the `s_nop 15 x 2` pad after the loop.  What it cannot control is the REGISTER
+// ALLOCATOR: under more pressure -- round 4: the SLP vectoriser's 64-bit temporaries in the input transform -- it spills and copies
+// the four VGPR-resident accumulators (scratch_store_dwordx4 / v_mov_b64) directly behind and in front of the MFMAs that own
+// them.  That was round 4's "packed fp32" failure: wrong values in the columns 12..15 of 16-lane rows (the part of an MFMA result
+// that lands last), a different place at every launch, only with a second wave on the SIMD competing for the matrix pipe.  Proof:
+// s_nops for (A) and (B) patched into the failing build's assembly make it bit-exact (0 wrong launches of 150 against 150 of 150;
+// (A) alone leaves 3e-4 of the errors, (B) alone all of them; packed-op, DPP, ds_write and SrcA/B write-after-read spacing change
+// nothing).  The packed instructions themselves are innocent: today's source built WITH the vectoriser has no such spill and no
+// failure.  Guard: csrc/isa_audit.py checks the assembly of this file for (A), (B) at every build (csrc/Makefile) and fails it on
+// a finding -- whatever flags or compiler made it; -fno-slp-vectorize stays as a speed choice (packed fp32 next to MFMAs costs
+// issue slots and registers).  Run-time half: tests/test_gpu_ops.py::test_conv3x3_c128_winograd_f4_full_load_is_deterministic (every
+// instantiation, two work-groups per CU) and tests/test_gpu_bench.py::test_in_flight_schedule_is_bit_identical_to_serial.
 #include "wino_common.h"
 #include "internal.h"
 

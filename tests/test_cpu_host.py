@@ -666,3 +666,60 @@ def test_adam_step_count_from_tf_beta_powers():
         assert tr._adam_steps_from_checkpoint(ck, 'Adam_AE', Opt) == t, t
     assert tr._adam_steps_from_checkpoint({'beta1_power_1': np.array(0.9 ** 4, np.float32)}, 'Adam_PC', Opt) == 3
     assert tr._adam_steps_from_checkpoint({}, 'Adam_AE', Opt) == 777                      # no beta powers: the global step
+
+
+# ---- csrc/isa_audit.py: the build gate for the kernels whose MFMAs are inline asm (profiles/r05_w4_rootcause.md) ----
+_AUDIT_HEAD = '_Z1kv:\n'
+_AUDIT_TAIL = '.Lfunc_end0:\n'
+
+
+def _audit(tmp_path, body):
+    sys.path.insert(0, os.path.join(ROOT, 'imgcomp_cvpr_amd', 'csrc'))
+    import isa_audit
+    p = tmp_path / 'k.s'
+    p.write_text(_AUDIT_HEAD + body + _AUDIT_TAIL)
+    out = []
+    for name, lines in isa_audit.kernels(str(p)):
+        n, f = isa_audit.audit_kernel(name, lines)
+        out += f
+    return out
+
+
+def test_isa_audit_flags_the_two_hazards_and_nothing_else(tmp_path):
+    """the exact instruction pairs of round 4's failing build are findings; the shipped patterns (operands from LDS / buffer loads,
+    accumulators read behind an s_nop pad, a VALU instruction overwriting SrcA / SrcB right BEHIND the MFMA) are not"""
+    mf = '\tv_mfma_f32_16x16x4_f32 v[38:41], v25, v33, v[38:41]\n'
+    # (A) spill of the accumulator 0 wait states behind its MFMA; a copy 3 instructions later; an AGPR read
+    assert any('(A)' in f for f in _audit(tmp_path, mf + '\tscratch_store_dwordx4 off, v[38:41], off offset:16\n'))
+    assert any('(A)' in f for f in _audit(tmp_path, mf + '\ts_add_i32 s1, s2, 4\n\tv_add_f32_e32 v1, v2, v3\n\tv_mov_b64_e32 v[10:11], v[40:41]\n'))
+    assert any('(A)' in f for f in _audit(tmp_path, '\tv_mfma_f32_16x16x4_f32 a[0:3], v1, v2, a[0:3]\n\tv_accvgpr_read_b32 v9, a2\n'))
+    assert any('(A)' in f for f in _audit(tmp_path, mf + '\ts_nop 9\n\tv_add_f32_e32 v38, 1.0, v38\n'))          # 10 states: the gate asks for 12
+    assert not _audit(tmp_path, mf + '\ts_nop 11\n\tv_add_f32_e32 v38, 1.0, v38\n')
+    assert not _audit(tmp_path, mf + '\ts_nop 15\n\ts_nop 15\n\tbuffer_store_dwordx4 v[38:41], v0, s[0:3], 0 offen\n')
+    # (B) the allocator's copy feeding SrcC / a VALU result feeding SrcB with fewer than 2 wait states
+    assert any('(B)' in f for f in _audit(tmp_path, '\tv_mov_b64_e32 v[10:11], v[44:45]\n\tv_mfma_f32_16x16x4_f32 v[8:11], v41, v21, v[8:11]\n'))
+    assert any('(B)' in f for f in _audit(tmp_path, '\tv_fma_f32 v21, v1, v2, v3\n\ts_nop 0\n\tv_mfma_f32_16x16x4_f32 a[8:11], v41, v21, a[8:11]\n'))
+    assert not _audit(tmp_path, '\tv_fma_f32 v21, v1, v2, v3\n\ts_nop 1\n\tv_mfma_f32_16x16x4_f32 a[8:11], v41, v21, a[8:11]\n')
+    # not hazards: loads into the operands (waited for by s_waitcnt), the accumulate chain, write-after-read of SrcA / SrcB
+    assert not _audit(tmp_path, '\tds_read_b128 v[20:23], v84\n\tbuffer_load_dwordx4 v[40:43], v84, s[48:51], s79 offen\n\ts_waitcnt vmcnt(0) lgkmcnt(0)\n'
+                                '\tv_mfma_f32_16x16x4_f32 a[8:11], v41, v21, a[8:11]\n\tv_mfma_f32_16x16x4_f32 a[8:11], v42, v22, a[8:11]\n'
+                                '\tv_fma_f32 v21, -4.0, v1, v2\n\tbuffer_load_dwordx4 v[40:43], v84, s[48:51], s79 offen\n')
+    # an MFMA result consumed as the next MFMA's SrcB is a hazard too
+    assert any('(A)' in f for f in _audit(tmp_path, mf + '\tv_mfma_f32_16x16x4_f32 a[8:11], v1, v38, a[8:11]\n'))
+
+
+def test_isa_audit_is_part_of_the_build_and_the_shipped_assembly_is_clean():
+    """csrc/Makefile audits every file with inline-asm MFMAs before it builds the object; the assembly the last build audited has no finding"""
+    csrc = os.path.join(ROOT, 'imgcomp_cvpr_amd', 'csrc')
+    mk = open(os.path.join(csrc, 'Makefile')).read()
+    asm_files = sorted(f[:-4] for f in os.listdir(csrc) if f.endswith('.hip') and 'asm volatile("v_mfma' in open(os.path.join(csrc, f)).read())
+    assert asm_files == ['conv3x3_wino4', 'conv3x3_wino_stack', 'conv3x3_wino_tn', 'conv3x3_wino_tp']
+    for f in asm_files:
+        assert 'AUDIT_{} := 1'.format(f) in mk, f
+    assert 'isa_audit.py $*.audit.s' in mk and mk.index('isa_audit.py $*.audit.s') < mk.index('-c $< -o $@')
+    for f in ('conv3x3_wino4', 'conv3x3_wino_tn'):              # built by build(): the audited assembly is on disk
+        s = os.path.join(csrc, f + '.audit.s')
+        if not os.path.exists(s):
+            pytest.skip('library not built in this checkout')
+        r = subprocess.run([sys.executable, os.path.join(csrc, 'isa_audit.py'), s], stdout=subprocess.PIPE, universal_newlines=True)
+        assert r.returncode == 0 and ' 0 finding(s)' in r.stdout, r.stdout[-2000:]

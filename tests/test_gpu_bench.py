@@ -75,3 +75,42 @@ def test_bench_single_rank_contract(cuda):
     tr = out['train']
     assert 'error' not in tr, tr
     assert tr['value'] > 0 and tr['checks']['ms_ssim_in_unit_interval'] and tr['checks']['d_loss_is_K_times_one_minus_ms_ssim']
+
+
+@pytest.mark.parametrize('n_flight,rounds', [(4, 16), (8, 26)])
+def test_in_flight_schedule_is_bit_identical_to_serial(cuda, n_flight, rounds):
+    """The schedule BENCH's `value` is measured on (bench.InFlight, default flags: n Kodak-sized pipelines on n streams, F(4x4) 3x3
+    layers with two work-groups of DIFFERENT grids per CU, h2 / h12 in their <256,128> / <128,256,SHUF> forms, context model and edge
+    kernels co-resident) gives, for every image and every step, exactly the z / symbols / bit costs / bpp / x_out the SAME pipeline
+    gives alone on one stream with the same plan flags (val.py:157-158: one image per sess.run is what is being reproduced).
+    Round 4's failure (wrong lanes under shared SIMDs; root cause: profiles/r05_w4_rootcause.md) lived exactly here and no test looked.
+    Comparisons are enqueued on the pipelines' own streams (mismatch counters on the device), so the images stay in flight:
+    n_flight x rounds steps = 64 / 208 steps, each with 64 launches of the 128 -> 128 kernel and one of each 5x5-as-phases form."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from imgcomp_cvpr_amd import _lib
+    first = bench.Pipeline(cuda, 'low', 'serial', seed=0).set_input(1, 512, 768)
+    sched = bench.InFlight(torch, first, cuda, n_flight, 'low', 0)
+    # the plan really is the one under test: F(4x4) for the Kodak map with n launches in flight
+    assert int(_lib.lib.ic_conv3x3_c128_pick_form(1, 128, 192, sched.pipes[0].ae.plan_flags)) == 2
+    refs = []
+    for pl, st in zip(sched.pipes, sched.streams):
+        torch.cuda.synchronize()
+        with torch.cuda.stream(st):                      # alone on the chip: nothing else is enqueued anywhere
+            bpp, x_out = pl.step()
+        torch.cuda.synchronize()
+        enc, bc = pl.last
+        refs.append([t.clone() for t in (enc.z, enc.symbols, enc.qhard, bc, bpp.reshape(-1), x_out)])
+    assert not torch.equal(refs[0][5], refs[1][5])       # different images per pipeline
+    mism = [torch.zeros((), dtype=torch.int64, device=cuda) for _ in sched.pipes]
+    for _ in range(rounds):
+        for k in range(n_flight):
+            bpp, x_out = sched.step()
+            pl = sched.pipes[k]
+            with torch.cuda.stream(sched.streams[k]):
+                enc, bc = pl.last
+                for got, want in zip((enc.z, enc.symbols, enc.qhard, bc, bpp.reshape(-1), x_out), refs[k]):
+                    mism[k] += (got != want).sum()
+    torch.cuda.synchronize()
+    bad = [int(m) for m in mism]
+    assert bad == [0] * n_flight, 'values that differ from the serial run, per image over {} steps each: {}'.format(rounds, bad)

@@ -352,32 +352,80 @@ def test_wino4_batched_packer_equals_the_single_one(cuda):
             assert torch.equal(batch[l], one), 'layer {} backward {}'.format(l, backward)
 
 
-def test_conv3x3_c128_winograd_f4_full_load_is_deterministic(cuda):
-    """the failure this kernel had in development showed only with two work-groups per CU and several rounds of them (wrong values
-    in lanes 12..15 of a 16-lane row; gone without the SLP vectoriser's packed fp32 ops, csrc/Makefile): 1152 work-groups, launches
-    back to back, every launch bit-identical to the first and within the bound of the float64 conv."""
+W4_FULL_LOAD_CASES = [
+    # (label, N, H, W): which instantiation of wino4_3x3_kernel the launch runs (WT = write-through stores: <= 512 work-groups)
+    ('c128 1x16 segments, several rounds', 6, 128, 192),       # <WT=0, RES, 128, 128, SHUF=0, SEG2=0>: 1152 work-groups
+    ('c128 2x8 segments (training crops)', 72, 32, 32),        # <.., SEG2=1>: 576 work-groups
+    ('c128 one round, write-through', 2, 128, 192),            # <WT=1, ..>: 384 work-groups, two per CU on half the chip
+]
+
+
+@pytest.mark.parametrize('label,N,H,W', W4_FULL_LOAD_CASES)
+@pytest.mark.parametrize('n_res', [0, 2])
+def test_conv3x3_c128_winograd_f4_full_load_is_deterministic(cuda, label, N, H, W, n_res):
+    """Two waves per SIMD is where round 4's failure showed (wrong values in lanes 12..15 of a 16-lane row).  Root cause, round 5
+    (profiles/r05_w4_rootcause.md): the register allocator's spills / copies of VGPR-resident accumulators next to inline-asm
+    MFMAs, without the matrix-pipe wait states -- ruled out at build time by csrc/isa_audit.py.  This is the run-time half: every
+    instantiation of the 128 -> 128 kernel (segment shapes, store modes, RES = 1 / 2 epilogues) at two work-groups per CU, 12 launches
+    back to back bit-identical to the first, the first within the bound of the float64 conv."""
     L = _lib()
-    N, H, W = 6, 128, 192
     g = torch.Generator().manual_seed(3)
     x = torch.relu(torch.randn((N, 128, H, W), generator=g)) * 1.5
     w = torch.randn((3, 3, 128, 128), generator=g) * 0.03
     sc, sh = torch.rand(128, generator=g) * 0.6 + 0.5, torch.randn(128, generator=g) * 0.1
+    res = [torch.randn((N, 128, H, W), generator=g) for _ in range(n_res)]
     xd, wd, scd, shd = x.to(cuda), w.to(cuda), sc.to(cuda), sh.to(cuda)
+    resd = [r.to(cuda) for r in res]
     wp = torch.empty(L.lib.ic_wino4_3x3_c128_packed_floats(), device=cuda)
     L.check(L.lib.ic_pack_wino4_3x3_c128_f32(L.ptr(wd), L.ptr(wp), 0, L.current_stream()))
+    assert int(L.lib.ic_wino4_3x3_c128_workgroups(N, H, W)) >= 384
     ys = []
     for _ in range(12):
         y = torch.empty((N, 128, H, W), device=cuda)
-        L.check(L.lib.ic_wino4_3x3_c128_bn_act_f32(L.ptr(xd), L.ptr(wp), L.ptr(scd), L.ptr(shd), None, None, L.ptr(y), N, H, W, 1, 0,
-                                                   L.current_stream()))
+        L.check(L.lib.ic_wino4_3x3_c128_bn_act_f32(L.ptr(xd), L.ptr(wp), L.ptr(scd), L.ptr(shd), L.ptr(resd[0]) if n_res else None,
+                                                   L.ptr(resd[1]) if n_res > 1 else None, L.ptr(y), N, H, W, 1, 0, L.current_stream()))
         ys.append(y)
     torch.cuda.synchronize()
     for k in range(1, 12):
-        assert torch.equal(ys[0], ys[k]), 'launch {} differs from launch 0 in {} values'.format(k, int((ys[0] != ys[k]).sum()))
+        assert torch.equal(ys[0], ys[k]), '{}: launch {} differs from launch 0 in {} values'.format(label, k, int((ys[0] != ys[k]).sum()))
     torch.set_num_threads(16)
-    ref = torch.relu(torch.nn.functional.conv2d(torch.nn.functional.pad(x[:2].double(), (1, 1, 1, 1)), w.double().permute(3, 2, 0, 1))
+    n_ref = min(N, 2)
+    ref = torch.relu(torch.nn.functional.conv2d(torch.nn.functional.pad(x[:n_ref].double(), (1, 1, 1, 1)), w.double().permute(3, 2, 0, 1))
                      * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
-    assert_close(ys[0][:2], ref, 'winograd F(4x4) full load', W4_RTOL)
+    for r in res:
+        ref = ref + r[:n_ref].double()
+    assert_close(ys[0][:n_ref], ref, 'winograd F(4x4) full load', W4_RTOL)
+
+
+@pytest.mark.parametrize('transposed', [0, 1])
+@pytest.mark.parametrize('N,H,W', [(4, 128, 192), (48, 32, 32)])
+def test_conv5s2_as_winograd_full_load_is_deterministic(cuda, transposed, N, H, W):
+    """the same for the <256,128> (h2 over its input's phases) and <128,256,SHUF> (h12 to its output's phases) instantiations, 1 x 16
+    and 2 x 8 segments, at two work-groups per CU: 12 launches bit-identical (the values themselves:
+    test_conv5s2_layers_as_winograd_over_phases)."""
+    L = _lib()
+    g = torch.Generator().manual_seed(5)
+    st = L.current_stream()
+    cin = 128 if transposed else 256
+    x = (torch.relu(torch.randn((N, cin, H, W), generator=g)) * 1.2).to(cuda)
+    w = (torch.randn((5, 5, 64, 128), generator=g) * 0.03).to(cuda)
+    cout = 64 if transposed else 128
+    sc, sh = (torch.rand(cout, generator=g) * 0.6 + 0.5).to(cuda), (torch.randn(cout, generator=g) * 0.1).to(cuda)
+    wp = torch.empty(L.lib.ic_wino4_conv5s2_packed_floats(), device=cuda)
+    L.check(L.lib.ic_pack_wino4_conv5s2_f32(L.ptr(w), L.ptr(wp), transposed, st))
+    assert int(L.lib.ic_wino4_conv5s2_workgroups(N, H, W, transposed)) >= 384
+    ys = []
+    for _ in range(12):
+        y = torch.empty((N, 64, 2 * H, 2 * W) if transposed else (N, 128, H, W), device=cuda)
+        if transposed:
+            L.check(L.lib.ic_wino4_deconv5s2_c128_c64_bn_act_f32(L.ptr(x), L.ptr(wp), L.ptr(sc), L.ptr(sh), L.ptr(y), N, H, W, 1, 0, st))
+        else:
+            L.check(L.lib.ic_wino4_conv5s2_c64_c128_bn_act_f32(L.ptr(x), L.ptr(wp), L.ptr(sc), L.ptr(sh), L.ptr(y), N, H, W, 1, 0, st))
+        ys.append(y)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ys[0]).all())
+    for k in range(1, 12):
+        assert torch.equal(ys[0], ys[k]), 'launch {} differs from launch 0 in {} values'.format(k, int((ys[0] != ys[k]).sum()))
 
 
 def test_conv3x3_c128_auto_selection(cuda):
