@@ -550,6 +550,12 @@ def main():
             'roofline': roofline, 'roofline_context_model': roofline_pc, 'cpu_baseline': cpu,
         }
         out.update(extra)
+        # the driver's record keeps the contract keys, `config`, `roofline` and `cpu_baseline` of this line: the like-for-like figure
+        # with the reference's one-sess.run-per-image loop (val.py:157-158) rides in `config` (numbers only) so that it survives too
+        one = extra.get('one_image_at_a_time')
+        out['config']['images_in_flight'] = n_flight
+        out['config']['one_image_at_a_time_mpix_s'] = one['value'] if one else (round(value, 3) if n_flight == 1 else None)
+        out['config']['one_image_at_a_time_ms_per_step'] = one['ms_per_step'] if one else (round(elapsed / a.steps * 1e3, 4) if n_flight == 1 else None)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()                 # rank 0 is still timing the stage split / dominant kernel: leave together

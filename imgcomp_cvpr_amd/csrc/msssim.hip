@@ -57,7 +57,7 @@ static MsPlan ms_layout(int H, int W) {
         v.H = h; v.W = w;
         const int size = h < w ? (h < 11 ? h : 11) : (w < 11 ? w : 11);
         v.K = 2 * (size / 2) + 1;
-        const int total = v.K - h > 0 ? v.K - h : 0;           // ms_ssim.py:19-22: computed from the HEIGHT, applied to both axes
+        const int total = v.K - w > 0 ? v.K - w : 0;           // ms_ssim.py:19-22 on the NHWC tensor of :160-162: computed from the WIDTH, applied to both axes
         v.pb = total;
         const int pa = total / 2;
         v.oh = h + v.pb + pa - v.K + 1;

@@ -55,7 +55,7 @@ def _separable_valid(img, k):
 
 def _blur(img, sigma, size):
     k = _kernel1d(sigma, size)
-    total_pad = max(len(k) - img.shape[2], 0)
+    total_pad = max(len(k) - img.shape[3], 0)       # the reference reads shape[2] of its NHWC tensor (ms_ssim.py:19, :160-162): the WIDTH
     before, after = total_pad + 1 // 2, total_pad // 2
     if before or after:
         img = F.pad(img, (before, after, before, after), mode='reflect')

@@ -618,23 +618,12 @@ class TrainGraph(object):
         x_out = self.plugin_decode(enc.qbar)
         pad_value = self._pad_value() if self.pc_config.use_centers_for_padding else 0.0
         hd = self._hip_distortion(x) if (self.HIP_LOSS and cfg.distortion_to_minimize == 'ms_ssim') else None
-        if hd is not None or (self.GRAPH_LOSS and self.OVERLAP_LOSS):
-            # The distortion and its gradient with respect to x_out come from ONE call -- csrc/msssim.hip (16 launches, ~0.1 ms)
-            # or, with GRAPH_LOSS, the replayed torch graph on a side stream -- so the backward is staged by hand: the rate
-            # branch first (its bucket's all-reduce goes out first), then clip / de-normalise + decoder + encoder with the
-            # distortion's gradient fed in.  Same Functions, same kernels, same sums as the single-backward form below.
-            main = torch.cuda.current_stream(self.dev)
-            if hd is not None:
-                d = hd.launch(x, x_out.detach())
-            else:
-                gd = self._graphed_distortion(x)
-                if getattr(self, '_loss_stream', None) is None:
-                    # its own hardware queue: streams of equal priority may share one, and a shared queue runs its streams in turn
-                    self._loss_stream = torch.cuda.Stream(device=self.dev, priority=-1)
-                side = self._loss_stream
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    d = gd.launch(x, x_out.detach())
+        if hd is not None:
+            # The distortion and its gradient with respect to x_out come from ONE call -- csrc/msssim.hip (16 launches, ~0.1 ms) --
+            # so the backward is staged by hand: the rate branch first (its bucket's all-reduce goes out first), then clip /
+            # de-normalise + decoder + encoder with the distortion's gradient fed in.  Same Functions, same kernels, same sums
+            # as the single-backward form below.
+            d = hd.launch(x, x_out.detach())
             bc = self.plugin_bitcost(enc.qbar.detach(), enc.symbols, pad_value)
             zero = torch.zeros((), device=self.dev)
             _, H_real, pc_comps, _ = get_loss(cfg, None, None, zero, bc, enc.heatmap)
@@ -644,8 +633,6 @@ class TrainGraph(object):
             d_bc = grads[0] if grads[0] is not None else torch.zeros_like(bc)
             d_hm = grads[1] if len(grads) > 1 else None
             torch.autograd.backward([bc], [d_bc])                       # context-model backward (its bucket goes out first)
-            if hd is None:
-                main.wait_stream(side)
             g_qbar, = torch.autograd.grad(x_out, [enc.qbar], d.grad)    # clip / de-normalise + decoder backward
             if d_hm is not None:
                 torch.autograd.backward([enc.qbar, enc.heatmap], [g_qbar, d_hm])
@@ -667,19 +654,9 @@ class TrainGraph(object):
                      'z': enc.z, 'qbar': enc.qbar.detach()}
         return out
 
-    # ---- distortion and its gradient as one replayed HIP graph ----
-    # GRAPH_LOSS: replay the distortion from a captured HIP graph instead of dispatching its ~300 torch kernels eagerly.
-    # OFF since round 4: inside the training loop the replayed graph starts reading STALE intermediates (the previous replay's)
-    # after 5-10 steps -- ms_ssim 1.157 > 1 in profiles/r03_train_line.json was that.  Pinned down with tools/train_hazard.py
-    # and tools/train_hazard_trace.py: the graph's inputs are right (device-side copies taken behind every replay), its outputs
-    # are wrong from step 5 (side stream) / step 10 (main stream) on, deterministically; replayed in isolation afterwards, fully
-    # synchronised, it is still wrong for new inputs and right when the same inputs are replayed twice, i.e. some node consumes a
-    # buffer of the replay before; a device-wide synchronize behind every replay hides it; the same capture replayed 40 times
-    # outside the training loop (tools/distortion_graph_probe.py, host far ahead, consumers on the same / another stream / the
-    # autograd thread / a library kernel) never shows it.  A fault of graph replay in this ROCm build that the loop's launch
-    # pattern triggers, not of the kernels: eager evaluation of the same inputs is right every time.
-    GRAPH_LOSS = False
-    OVERLAP_LOSS = True      # (with GRAPH_LOSS) the graphed distortion on a side stream beside the context model's branch
+    # (Rounds 2-3 replayed the torch distortion from a captured HIP graph; inside the training loop the replay read stale
+    # intermediates after 5-10 steps -- a fault of graph replay in this ROCm build, docs/history/DESIGN_rounds_1_4.md -- and
+    # csrc/msssim.hip made it unnecessary.  Removed in round 5.)
     # HIP_LOSS: the MS-SSIM distortion and its gradient from csrc/msssim.hip (one launch per scale and direction) instead of the
     # ~300 torch kernels of ms_ssim.py -- no graph, no static buffers, any shape with five scales.  False: torch, eagerly.
     HIP_LOSS = True
@@ -701,25 +678,14 @@ class TrainGraph(object):
                 cache[key] = None
         return cache[key]
 
-    def _graphed_distortion(self, x):
-        key = (tuple(x.shape), self.ae_config.distortion_to_minimize)
-        cache = self.__dict__.setdefault('_graphed_distortions', {})
-        if key not in cache:
-            cache[key] = _GraphedDistortion(self.ae_config, x.shape, self.dev)
-        return cache[key]
-
     def _distortions(self, x, x_out):
-        """Distortions(cfg, x, x_out, is_training=True).  The MS-SSIM loss is ~300 small torch kernels forward + backward; eagerly
-        dispatched they take the host 5-8 ms during which the GPU idles (rocprofv3 trace of the step: 15 % busy in that section).
-        Shapes are static in training, so forward and backward of the distortion are captured ONCE per input shape into a HIP
-        graph and replayed: same kernels, same order, same results, no host time."""
+        """Distortions(cfg, x, x_out, is_training=True): MS-SSIM and its gradient from csrc/msssim.hip where the shape has five scales,
+        else the torch restatement (ms_ssim.py), eagerly."""
         if self.HIP_LOSS and self.ae_config.distortion_to_minimize == 'ms_ssim':
             hd = self._hip_distortion(x)
             if hd is not None:
                 return hd(x, x_out)
-        if not self.GRAPH_LOSS:
-            return Distortions(self.ae_config, x, x_out, is_training=True)
-        return self._graphed_distortion(x)(x, x_out)
+        return Distortions(self.ae_config, x, x_out, is_training=True)
 
     # ---- centres[0] on the host (the context model's pad value is a by-value argument of the C ABI) ----
     def refresh_pad_value(self):
@@ -878,57 +844,6 @@ class Distortions(object):
         return 10.0 * torch.log10(255.0 * 255.0 / Distortions.get_mse_per_img(inp, otp, cast_to_int))
 
 
-class _GraphedDistortion(object):
-    """Distortions(config, x, x_out, True) and d(d_loss_scaled)/d(x_out), captured once into a HIP graph (static buffers)."""
-
-    def __init__(self, config, shape, device):
-        self.config = config
-        self.x = torch.zeros(tuple(shape), dtype=torch.float32, device=device)
-        self.xo = torch.full(tuple(shape), 1.0, dtype=torch.float32, device=device)
-        cur = torch.cuda.current_stream(device)
-        side = torch.cuda.Stream(device=device)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):                    # warm-up outside the capture: band matrices, GEMM workspaces, autotuning
-            for _ in range(2):
-                self._run()
-        cur.wait_stream(side)
-        torch.cuda.synchronize(device)
-        self.graph = torch.cuda.CUDAGraph()
-        # thread_local: other host threads (the RCCL watchdog of a data-parallel run) may keep calling the runtime during capture
-        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
-            self.outs = self._run()
-
-    def _run(self):
-        xo = self.xo.detach().requires_grad_(True)
-        d = Distortions(self.config, self.x, xo, is_training=True)
-        grad, = torch.autograd.grad(d.d_loss_scaled, xo)
-        return {'d_loss_scaled': d.d_loss_scaled.detach(), 'mse': d.mse.detach(), 'psnr': d.psnr.detach(),
-                'ms_ssim': d.ms_ssim.detach() if d.ms_ssim is not None else None, 'grad': grad}
-
-    def launch(self, x, x_out):
-        """copy the inputs in and replay on the CURRENT stream, no autograd: -> values with .d_loss_scaled, .mse, .psnr, .ms_ssim
-        and .grad = d(d_loss_scaled)/d(x_out); all of them views of static buffers, valid until the next replay"""
-        self.x.copy_(x)
-        self.xo.copy_(x_out)
-        self.graph.replay()
-        if _TRACE is not None:
-            _TRACE.append({'x': self.x.clone(), 'xo': self.xo.clone(), 'src_xo': x_out.clone(),
-                           'outs': {k: v.clone() for k, v in self.outs.items() if v is not None}})
-        self.replays = getattr(self, 'replays', 0) + 1
-        o = self.outs
-        d = _DistortionValues()
-        d.d_loss_scaled, d.mse, d.psnr, d.ms_ssim, d.grad = o['d_loss_scaled'], o['mse'], o['psnr'], o['ms_ssim'], o['grad']
-        return d
-
-    def __call__(self, x, x_out):
-        d = _DistortionValues()
-        d.d_loss_scaled = _GraphedDistortionFn.apply(self, x, x_out)
-        o = self.outs
-        d.mse, d.psnr = o['mse'].clone(), o['psnr'].clone()
-        d.ms_ssim = o['ms_ssim'].clone() if o['ms_ssim'] is not None else None
-        return d
-
-
 class _HipMsSsimDistortion(object):
     """Distortions(config, x, x_out, is_training=True) for distortion_to_minimize = ms_ssim (train.py:352-394) and
     d(d_loss_scaled) / d(x_out), from csrc/msssim.hip: the blur matrices of the shape are made once on the host
@@ -975,39 +890,20 @@ class _HipDistortionFn(torch.autograd.Function):
     def forward(ctx, hd, x, x_out):
         v = hd.launch(x, x_out, want_grad=True)
         ctx.save_for_backward(v.grad)
-        ctx.mark_non_differentiable(v.ms_ssim)
-        return v.d_loss_scaled.clone(), v.ms_ssim.clone()
+        loss, ms = v.d_loss_scaled.clone(), v.ms_ssim.clone()
+        ctx.mark_non_differentiable(ms)              # the RETURNED tensor: ms_ssim is a logged value, d_loss_scaled carries the gradient
+        return loss, ms
 
     @staticmethod
     def backward(ctx, go, _unused):
         grad, = ctx.saved_tensors
+        if go is None:                               # only ms_ssim was used downstream: nothing flows to x_out
+            return None, None, None
         return None, None, grad * go
-
-
-_TRACE = None      # tools/train_hazard_trace.py: a list collects device-side copies of every replay's inputs and outputs
 
 
 class _DistortionValues(object):
     pass
-
-
-class _GraphedDistortionFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, gd, x, x_out):
-        gd.x.copy_(x)
-        gd.xo.copy_(x_out)
-        gd.graph.replay()
-        gd.replays = getattr(gd, 'replays', 0) + 1
-        ctx.gd, ctx.replay = gd, gd.replays
-        return gd.outs['d_loss_scaled'].clone()
-
-    @staticmethod
-    def backward(ctx, go):
-        # the static gradient buffer is valid until the next replay; go is the scalar d(total)/d(d_loss_scaled) (= 1)
-        if ctx.replay != ctx.gd.replays:
-            raise RuntimeError('the graphed distortion was evaluated again before this backward: its gradient buffer has been '
-                               'overwritten (one forward_backward at a time per TrainGraph, or set TrainGraph.GRAPH_LOSS = False)')
-        return None, None, ctx.gd.outs['grad'] * go
 
 
 def get_loss(config, ae, pc, d_loss_scaled, bc, heatmap):
@@ -1226,15 +1122,21 @@ class Trainer(object):
         (0.999 ** t is a normal float32 until t ~ 87,000; 0.9 ** t goes denormal near t = 830 and reaches zero near 980); beyond
         what either can resolve the global step counts the updates."""
         def read(name, legacy):
-            v = ckpt.get(name, ckpt.get(legacy))
-            return float(np.asarray(v).reshape(-1)[0]) if v is not None else None
+            # rounds 1-3 of this repo wrote `<optimiser>/beta1_power` holding beta ** t (no TF checkpoint has that name): no -1 there
+            if name in ckpt:
+                return float(np.asarray(ckpt[name]).reshape(-1)[0]), 1
+            if legacy in ckpt:
+                return float(np.asarray(ckpt[legacy]).reshape(-1)[0]), 0
+            return None, 0
         b1n, b2n = BETA_POWER_NAMES[tag]
-        for val, base in ((read(b2n, tag + '/beta2_power'), opt.b2), (read(b1n, tag + '/beta1_power'), opt.b1)):
+        for (val, minus), base in ((read(b2n, tag + '/beta2_power'), opt.b2), (read(b1n, tag + '/beta1_power'), opt.b1)):
             # a NORMAL float32 carries beta ** (t + 1) to 6e-8 relative, i.e. t to 6e-8 / |log beta| << 1: exact
             if val is not None and 1e-30 < val < 1.0:
-                t = int(round(math.log(val) / math.log(base))) - 1
+                t = int(round(math.log(val) / math.log(base))) - minus
                 if t >= 0:
                     return t
+            elif val == 1.0 and not minus:
+                return 0                                   # legacy checkpoint at step 0: beta ** 0
         return self.global_step
 
     def restore_training_state(self, ckpt):

@@ -39,7 +39,7 @@ def _sep_valid(img, k1d):
 
 def _gaussian_blur(img, sigma, size):
     k = _gauss_kernel(sigma, size)
-    total_pad = max(k.shape[0] - img.shape[2], 0)
+    total_pad = max(k.shape[0] - img.shape[3], 0)          # ms_ssim.py:19 reads shape[2] of the NHWC tensor of :160-162 = the WIDTH (NCHW here: [3])
     p1, p2 = total_pad + 1 // 2, total_pad // 2          # sic: `total_pad + 1 // 2` (ms_ssim.py:20)
     if p1 or p2:
         img = F.pad(img, (p1, p2, p1, p2), mode='reflect')

@@ -666,6 +666,10 @@ def test_adam_step_count_from_tf_beta_powers():
         assert tr._adam_steps_from_checkpoint(ck, 'Adam_AE', Opt) == t, t
     assert tr._adam_steps_from_checkpoint({'beta1_power_1': np.array(0.9 ** 4, np.float32)}, 'Adam_PC', Opt) == 3
     assert tr._adam_steps_from_checkpoint({}, 'Adam_AE', Opt) == 777                      # no beta powers: the global step
+    # checkpoints of rounds 1-3 of this repo: `<optimiser>/beta?_power` = beta ** t (not t + 1)
+    for t in (0, 1, 12, 3000):
+        ck = {'Adam_PC/beta1_power': np.array(0.9 ** t, np.float32), 'Adam_PC/beta2_power': np.array(0.999 ** t, np.float32)}
+        assert tr._adam_steps_from_checkpoint(ck, 'Adam_PC', Opt) == t, t
 
 
 # ---- csrc/isa_audit.py: the build gate for the kernels whose MFMAs are inline asm (profiles/r05_w4_rootcause.md) ----

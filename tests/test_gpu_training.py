@@ -256,12 +256,15 @@ def test_ms_ssim_loss_module(cuda):
     assert rel_err(gb.grad, tb.grad) < 1e-3
 
 
-@pytest.mark.parametrize('shape', [(2, 3, 128, 128), (3, 3, 64, 64), (1, 3, 160, 160), (2, 3, 72, 136), (1, 3, 33, 47), (1, 2, 17, 19)])
+@pytest.mark.parametrize('shape', [(2, 3, 128, 128), (3, 3, 64, 64), (1, 3, 160, 160), (2, 3, 72, 136), (1, 3, 33, 47), (1, 2, 17, 19), (1, 3, 320, 160), (2, 3, 40, 20)])
 def test_hip_ms_ssim_distortion_value_and_gradient(cuda, shape):
     """csrc/msssim.hip (ic_msssim_loss_grad_f32) against the oracle's float64 restatement of code/ms_ssim.py under autograd:
     K (1 - MS-SSIM) and its gradient with respect to the reconstruction, on the training shapes (128 and the config's 160 crops),
     the small-scale REFLECT pads (64: two scales narrower than the window), non-square, odd sizes (the (0,1) REFLECT pad of
-    the 2x2 box) and the smallest image with five scales.  Two calls are bit-identical (fixed-order float64 means)."""
+    the 2x2 box), the smallest image with five scales, and tall crops whose coarsest scale is narrower than the window (320 x 160,
+    40 x 20: the reference derives the REFLECT pad from the WIDTH -- shape[2] of its NHWC tensor, ms_ssim.py:19 / :160-162 -- and
+    applies it to both axes; the transposed shapes have no valid output there, in the reference as here).
+    Two calls are bit-identical (fixed-order float64 means)."""
     from imgcomp_cvpr_amd import training, config_parser as cp, weights as W
     from oracle import train_oracle as T
     ae, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', 'med'))
@@ -291,6 +294,7 @@ def test_hip_ms_ssim_distortion_value_and_gradient(cuda, shape):
 
 def lib_unsupported_below_five_scales():
     from imgcomp_cvpr_amd import _lib as L
+    assert L.lib.ic_msssim_plan_bytes(320, 160) > 0 and L.lib.ic_msssim_plan_bytes(160, 320) == 0      # pad from the width
     return L.lib.ic_msssim_plan_bytes(16, 16) == 0 and L.lib.ic_msssim_workspace_bytes(1, 3, 16, 64) == 0 and L.lib.ic_msssim_plan_bytes(17, 17) > 0
 
 
