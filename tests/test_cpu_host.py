@@ -727,3 +727,138 @@ def test_isa_audit_is_part_of_the_build_and_the_shipped_assembly_is_clean():
             pytest.skip('library not built in this checkout')
         r = subprocess.run([sys.executable, os.path.join(csrc, 'isa_audit.py'), s], stdout=subprocess.PIPE, universal_newlines=True)
         assert r.returncode == 0 and ' 0 finding(s)' in r.stdout, r.stdout[-2000:]
+
+
+# ---- tools/pin_reference.py: the one command for the day a TF-written checkpoint arrives (N1) ----
+def _hand_assembled_bundle(prefix, tensors, entries_per_block=37):
+    """A TF-1 tensor bundle laid out byte by byte from the FORMAT DESCRIPTION (LevelDB table_format.md; tensor_bundle.proto),
+    sharing no code with imgcomp_cvpr_amd.tf_checkpoint's writer, and deliberately different from it where the format allows:
+    every entry its own restart point (no prefix compression), fixed entries per data block, zero-valued proto fields omitted
+    as protobuf serialisers do (shard_id 0, offset 0, little-endian), the VersionDef in the header as BundleWriter writes it."""
+    import struct
+
+    def varint(v):
+        out = bytearray()
+        while True:
+            b = v & 0x7f
+            v >>= 7
+            out.append(b | (0x80 if v else 0))
+            if not v:
+                return bytes(out)
+
+    def crc32c_bitwise(data):                                   # reflected Castagnoli polynomial, bit by bit
+        c = 0xFFFFFFFF
+        for byte in data:
+            c ^= byte
+            for _ in range(8):
+                c = (c >> 1) ^ (0x82F63B78 & -(c & 1))
+        return c ^ 0xFFFFFFFF
+
+    def masked(c):
+        return (((c >> 15) | (c << 17)) + 0xa282ead8) & 0xFFFFFFFF
+
+    def crc_of(raw):
+        if len(raw) <= 16384:
+            return crc32c_bitwise(raw)
+        from imgcomp_cvpr_amd import tf_checkpoint as T          # (large tensors: the library's routine, pinned by the published
+        return T.crc32c(raw)                                     #  check values in test_tf_checkpoint_bundle_round_trip)
+
+    def block(entries):
+        buf, restarts = bytearray(), []
+        for k, v in entries:
+            restarts.append(len(buf))
+            buf += varint(0) + varint(len(k)) + varint(len(v)) + k + v
+        for r in restarts:
+            buf += struct.pack('<I', r)
+        buf += struct.pack('<I', len(restarts))
+        return bytes(buf)
+
+    items = [(b'', b'\x08\x01' + b'\x1a\x02\x08\x01')]            # BundleHeaderProto{num_shards: 1, version{producer: 1}}
+    offset = 0
+    with open(prefix + '.data-00000-of-00001', 'wb') as f:
+        for name in sorted(tensors, key=lambda n: n.encode()):
+            a = np.ascontiguousarray(tensors[name]) if np.ndim(tensors[name]) else np.asarray(tensors[name])
+            raw = a.astype('<' + a.dtype.str[1:]).tobytes()
+            f.write(raw)
+            dt = {np.dtype(np.float32): 1, np.dtype(np.int64): 9}[a.dtype]
+            shape = b''.join(b'\x12' + varint(len(b'\x08' + varint(d))) + b'\x08' + varint(d) for d in a.shape)
+            e = b'\x08' + varint(dt) + b'\x12' + varint(len(shape)) + shape
+            if offset:
+                e += b'\x20' + varint(offset)
+            e += b'\x28' + varint(len(raw)) + b'\x35' + struct.pack('<I', masked(crc_of(raw)))
+            items.append((name.encode(), e))
+            offset += len(raw)
+    with open(prefix + '.index', 'wb') as f:
+        def emit(blk):
+            off = f.tell()
+            f.write(blk + b'\x00' + struct.pack('<I', masked(crc32c_bitwise(blk + b'\x00'))))
+            return varint(off) + varint(len(blk))
+        index = []
+        for i in range(0, len(items), entries_per_block):
+            chunk = items[i:i + entries_per_block]
+            index.append((chunk[-1][0], emit(block(chunk))))
+        meta = emit(block([]))
+        idx = emit(block(index))
+        f.write((meta + idx).ljust(40, b'\x00') + struct.pack('<Q', 0xdb4775248b80fb57))
+
+
+def test_pin_reference_inventory_on_written_and_hand_assembled_bundles(tmp_path, configs, syn_weights):
+    """tools/pin_reference.py steps 1-3 (no GPU): the log-dir / checkpoint discovery, the Appendix-B inventory against the bundle and
+    var_names.pkl, the CRC-verified read -- on a bundle written by tf_checkpoint.write_bundle AND on one assembled by hand from the
+    format description (reader and writer cannot share a bug); a missing, mis-shaped or unknown variable is named precisely."""
+    import pickle
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import pin_reference as P
+    from imgcomp_cvpr_amd import tf_checkpoint as T
+    state = {'global_step': np.array(7, np.int64), 'beta1_power': np.array(0.9 ** 8, np.float32),
+             'autoencoder/encoder/centers/Adam_AE': np.zeros(6, np.float32), 'autoencoder/encoder/centers/Adam_AE_1': np.zeros(6, np.float32)}
+    full = dict(syn_weights, **state)
+    job = '0515_1103 ae_configs@cvpr@low pc_configs@cvpr@res_shallow'
+
+    def lay_out(root, writer, tensors, names=None):
+        ck = os.path.join(str(root), job, 'ckpts')
+        os.makedirs(ck, exist_ok=True)
+        writer(os.path.join(ck, 'ckpt-7'), tensors)
+        with open(os.path.join(ck, 'var_names.pkl'), 'wb') as f:
+            pickle.dump([n + ':0' for n in (names if names is not None else sorted(tensors))], f)
+        return str(root)
+
+    # 1. this package's writer
+    r1 = lay_out(tmp_path / 'a', T.write_bundle, full)
+    rep = P.pin(r1, 'unused', inventory_only=True, verbose=False)['inventory']
+    assert rep['model_variables'] == len(syn_weights) and rep['training_state_variables'] == 4 and rep['other_variables'] == []
+    assert rep['parameters'] == sum(int(np.prod(np.shape(v))) for v in syn_weights.values())
+    # 2. laid out by hand
+    r2 = lay_out(tmp_path / 'b', _hand_assembled_bundle, full)
+    assert P.pin(r2, 'unused', inventory_only=True, verbose=False)['inventory'] == rep
+    back = T.read_bundle(os.path.join(r2, job, 'ckpts', 'ckpt-7'), verify=True)
+    assert list(back) == sorted(full, key=lambda n: n.encode())
+    for k, v in full.items():
+        assert back[k].dtype == np.asarray(v).dtype and back[k].shape == np.shape(v) and np.array_equal(back[k], v), k
+    assert open(os.path.join(r1, job, 'ckpts', 'ckpt-7.index'), 'rb').read() != open(os.path.join(r2, job, 'ckpts', 'ckpt-7.index'), 'rb').read()
+    w = T.load_weights(os.path.join(r2, job))
+    assert set(w) == set(syn_weights)
+    # 3. precise failures
+    gone = {k: v for k, v in full.items() if k != 'autoencoder/encoder/h2/BatchNorm/gamma'}
+    with pytest.raises(P.PinError, match=r'missing variable autoencoder/encoder/h2/BatchNorm/gamma \(expected float32 \[128\]\)'):
+        P.pin(lay_out(tmp_path / 'c', _hand_assembled_bundle, gone), 'unused', inventory_only=True, verbose=False)
+    bent = dict(full)
+    bent['autoencoder/decoder/h12/weights'] = np.zeros((5, 5, 128, 64), np.float32)         # in/out swapped
+    with pytest.raises(P.PinError, match=r'variable autoencoder/decoder/h12/weights has shape \[5, 5, 128, 64\], expected \[5, 5, 64, 128\]'):
+        P.pin(lay_out(tmp_path / 'd', T.write_bundle, bent), 'unused', inventory_only=True, verbose=False)
+    extra = dict(full)
+    extra['autoencoder/encoder/h3/weights'] = np.zeros((3, 3, 8, 8), np.float32)
+    with pytest.raises(P.PinError, match='do not have: autoencoder/encoder/h3/weights'):
+        P.pin(lay_out(tmp_path / 'e', T.write_bundle, extra), 'unused', inventory_only=True, verbose=False)
+    with pytest.raises(P.PinError, match='var_names.pkl does not list probclass3d/logits/conv3d_conv0_mask/biases'):
+        P.pin(lay_out(tmp_path / 'f', T.write_bundle, full, [n for n in sorted(full) if n != 'probclass3d/logits/conv3d_conv0_mask/biases']),
+              'unused', inventory_only=True, verbose=False)
+    flipped = lay_out(tmp_path / 'g', _hand_assembled_bundle, full)
+    dp = os.path.join(flipped, job, 'ckpts', 'ckpt-7.data-00000-of-00001')
+    raw = bytearray(open(dp, 'rb').read())
+    raw[len(raw) // 2] ^= 4
+    open(dp, 'wb').write(bytes(raw))
+    with pytest.raises(P.PinError, match='checksum mismatch'):
+        P.pin(flipped, 'unused', inventory_only=True, verbose=False)
+    with pytest.raises(P.PinError, match='expected exactly one log dir'):
+        P.pin(str(tmp_path / 'nowhere'), 'unused', inventory_only=True, verbose=False)

@@ -219,3 +219,145 @@ def test_cfg3_training_step_full_size(cuda):
         if e > tol:
             bad.append('{}: {:.3e} > {:.1e}'.format(n, e, tol))
     assert not bad, 'cfg3 gradients outside their bounds (relative to the tensor scale): ' + '; '.join(bad)
+
+
+def test_cfg1_256_png_through_val(cuda, tmp_path, configs, syn_weights):
+    """BASELINE configs[0] at its exact size: ONE 256 x 256 PNG, ae_configs/cvpr/low + pc_configs/cvpr/res_shallow, through the val.py
+    entry point (val.py:81-94, :157-158).  The measures.csv row equals the oracle's validate_forward of the same pixels: bpp to
+    1e-4, the reconstruction it saves equals the oracle's truncated uint8 output except where the oracle's float64 value sits on an
+    integer boundary, and MS-SSIM / PSNR equal the numpy twins of the reference's host metrics evaluated on that saved image."""
+    from PIL import Image
+    from imgcomp_cvpr_amd import val, metrics, weights as W
+    from oracle import oracle as O
+    ae_cfg, _ = configs
+    imgs = tmp_path / 'one256'
+    imgs.mkdir()
+    x = W.synthetic_image((1, 3, 256, 256), 'natural', seed=17)
+    Image.fromarray(x[0].transpose(1, 2, 0)).save(str(imgs / 'img00.png'))
+    root = tmp_path / 'logs'
+    (root / '0515_1103 ae_configs@cvpr@low pc_configs@cvpr@res_shallow').mkdir(parents=True)
+    val.main([str(root), '0515_1103', str(imgs), '--weights', 'synthetic', '--save_ours', '--in_flight', '1'])
+    out = root / '0515_1103 one256'
+    rows = (out / 'measures.csv').read_text().strip().split('\n')
+    assert rows[0] == 'img_name,bpp,ms-ssim,psnr' and len(rows) == 2
+    name, bpp, msssim, psnr = rows[1].split(',')
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        ref = O.validate_forward(x, syn_weights, ae_cfg.as_dict(), torch.float64)
+    assert tuple(ref['enc'].symbols.shape) == (1, 32, 32, 32)                     # cfg1: 32,768 symbols
+    assert abs(float(bpp) - float(ref['bpp'])) < 1e-4, (bpp, float(ref['bpp']))
+    saved = np.asarray(Image.open(str(out / 'imgs' / 'img00.png'))).transpose(2, 0, 1)[None]
+    want = ref['x_out_uint8'].numpy()
+    diff = saved.astype(np.int32) - want.astype(np.int32)
+    frac = ref['x_out'].numpy() - np.floor(ref['x_out'].numpy())
+    off = diff != 0
+    assert np.abs(diff).max() <= 1 and off.mean() < 1e-4, (int(np.abs(diff).max()), float(off.mean()))
+    assert np.all(np.minimum(frac[off], 1 - frac[off]) < 1e-3)                    # only values within 1e-3 of an integer may differ
+    assert abs(float(msssim) - metrics.msssim_nchw_uint8(x, saved)) < 1e-5
+    assert abs(float(psnr) - metrics.psnr_uint8(x, saved)) < 1e-3
+    assert abs(metrics.psnr_uint8(x, saved) - O.psnr_uint8(x, saved)) < 1e-9
+
+
+def test_cfg5_tiles_sharded_world2(cuda, tmp_path):
+    """BASELINE configs[4] as it words it -- "4K tiles, batch sharded across the GPUs": a 3840 x 2160 frame cut into four 1920 x 1080
+    tiles (independent images: SURVEY 8(e), the encoder's receptive field forbids halo-free stitching and the reference has no
+    tiling), ae_configs/cvpr/hi + res_shallow, evaluated by val.py on one rank and on two ranks (imgcomp_cvpr_amd.sharding:
+    round-robin tiles, no data-path collective, one gather of the per-tile scalars; the box has one GPU, so both ranks use cuda:0
+    over gloo).  The gathered measures.csv is identical."""
+    import os
+    import subprocess
+    import sys
+    from PIL import Image
+    from imgcomp_cvpr_amd import val, weights as W
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    frame = W.synthetic_image((1, 3, 2160, 3840), 'natural', seed=3)[0]
+    imgs = tmp_path / 'tiles4k'
+    imgs.mkdir()
+    for ty in range(2):
+        for tx in range(2):
+            t = frame[:, ty * 1080:(ty + 1) * 1080, tx * 1920:(tx + 1) * 1920].transpose(1, 2, 0)
+            Image.fromarray(np.ascontiguousarray(t)).save(str(imgs / 'tile_{}_{}.png'.format(ty, tx)), compress_level=1)
+    root = tmp_path / 'logs'
+    (root / '0601_0000 ae_configs@cvpr@hi pc_configs@cvpr@res_shallow').mkdir(parents=True)
+    val.main([str(root), '0601_0000', str(imgs), '--weights', 'synthetic', '--reset', '--in_flight', '1'])
+    out = root / '0601_0000 tiles4k' / 'measures.csv'
+    one = out.read_text()
+    rows = one.strip().split('\n')
+    assert len(rows) == 5 and [r.split(',')[0] for r in rows[1:]] == ['tile_0_0.png', 'tile_0_1.png', 'tile_1_0.png', 'tile_1_1.png']
+    assert all(0.01 < float(r.split(',')[1]) < 8 for r in rows[1:])
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29583', '-m', 'imgcomp_cvpr_amd.val', str(root), '0601_0000', str(imgs), '--weights', 'synthetic',
+           '--reset', '--backend', 'gloo', '--device', 'cuda:0', '--in_flight', '1']
+    p = subprocess.run(cmd, cwd=root_dir, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, universal_newlines=True)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert out.read_text() == one
+
+
+def test_pin_reference_end_to_end_on_a_written_bundle(cuda, tmp_path, configs, syn_weights):
+    """tools/pin_reference.py, all six steps, on assets made here: the synthetic weights as a TF-1 bundle in the reference's ckpts layout
+    (README.md:14-15) and three PNGs.  The per-image rows equal val.py's, the symbol CRCs are those of ae.encode, the run fails when
+    the expected means are not met to three decimals and passes when they are."""
+    import os
+    import pickle
+    import sys
+    import zlib
+    from PIL import Image
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root_dir, 'tools'))
+    import pin_reference as P
+    from imgcomp_cvpr_amd import tf_checkpoint as T, val, weights as W, autoencoder
+    job = '0515_1103 ae_configs@cvpr@low pc_configs@cvpr@res_shallow'
+    ck = tmp_path / 'ckpts_root' / job / 'ckpts'
+    ck.mkdir(parents=True)
+    T.write_bundle(str(ck / 'ckpt-1000'), syn_weights)
+    with open(str(ck / 'var_names.pkl'), 'wb') as f:
+        pickle.dump([n + ':0' for n in sorted(syn_weights)], f)
+    imgs = tmp_path / 'kodak3'
+    imgs.mkdir()
+    xs = []
+    for i, (h, w) in enumerate(((128, 192), (192, 128), (96, 96))):
+        x = W.synthetic_image((1, 3, h, w), 'natural', seed=70 + i)
+        xs.append(x)
+        Image.fromarray(x[0].transpose(1, 2, 0)).save(str(imgs / 'kodim{:02d}.png'.format(i + 1)))
+    out = str(tmp_path / 'golden' / 'kodak_test.npz')
+    res = P.pin(str(tmp_path / 'ckpts_root'), str(imgs), expect_bpp=None, expect_msssim=None, out=None, verbose=False)
+    # README-style expectations, three decimals
+    with pytest.raises(P.PinError, match='NOT reproduced: mean bpp'):
+        P.pin(str(tmp_path / 'ckpts_root'), str(imgs), expect_bpp=res['mean_bpp'] + 0.002, expect_msssim=res['mean_msssim'], verbose=False)
+    again = P.pin(str(tmp_path / 'ckpts_root'), str(imgs), expect_bpp=round(res['mean_bpp'], 3), expect_msssim=round(res['mean_msssim'], 3),
+                  out=out, verbose=False)
+    assert again['rows'] == res['rows'] and again['symbol_crc32'] == res['symbol_crc32']
+    z = np.load(out)
+    assert list(z['names']) == ['kodim01.png', 'kodim02.png', 'kodim03.png'] and z['symbol_crc32'].dtype == np.uint32
+    # the same rows as the val.py entry point on the same directory (host metrics)
+    val.main([str(tmp_path / 'ckpts_root'), '0515_1103', str(imgs), '--reset', '--host_metrics'])
+    rows = (tmp_path / 'ckpts_root' / '0515_1103 kodak3' / 'measures.csv').read_text().strip().split('\n')[1:]
+    for r, (name, bpp, ms, ps) in zip(rows, res['rows']):
+        n2, b2, m2, p2 = r.split(',')
+        assert n2 == name and abs(float(b2) - bpp) < 1e-6 and abs(float(m2) - ms) < 1e-9 and abs(float(p2) - ps) < 1e-9
+    ae_cfg, _ = configs
+    ae = autoencoder.get_network_cls(ae_cfg)(ae_cfg).load_weights(syn_weights, cuda)
+    for x, crc in zip(xs, res['symbol_crc32']):
+        sym = ae.encode(dev(x, cuda), False).symbols.cpu().numpy().astype(np.int64)
+        assert zlib.crc32(np.ascontiguousarray(sym).tobytes()) & 0xffffffff == crc
+
+
+def test_pinned_kodak_fixture(cuda):
+    """Replays tests/golden/kodak_0515_1103.npz (written by tools/pin_reference.py from the reference's published checkpoint and the
+    Kodak set) -- the TF-1.4 pin of SURVEY 8(c).  Needs the assets: IMGCOMP_CKPTS_ROOT (extracted ckpts.tar.gz) and IMGCOMP_KODAK
+    (directory of the 24 PNGs); neither exists in the build container or on the GPU boxes, where this skips."""
+    import os
+    import sys
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fixture = os.path.join(root_dir, 'tests', 'golden', 'kodak_0515_1103.npz')
+    ck, kodak = os.environ.get('IMGCOMP_CKPTS_ROOT'), os.environ.get('IMGCOMP_KODAK')
+    if not (ck and kodak and os.path.isfile(fixture)):
+        pytest.skip('needs the 0515_1103 checkpoint, the Kodak images and the fixture pin_reference.py writes from them')
+    sys.path.insert(0, os.path.join(root_dir, 'tools'))
+    import pin_reference as P
+    z = np.load(fixture)
+    res = P.pin(ck, kodak, out=None, verbose=False)                      # asserts 0.370 / 0.975 to three decimals itself
+    assert [r[0] for r in res['rows']] == list(z['names'])
+    assert res['symbol_crc32'] == [int(c) for c in z['symbol_crc32']]    # bit-exact symbols
+    assert np.allclose([r[1] for r in res['rows']], z['bpp'], atol=1e-4)
