@@ -66,15 +66,21 @@ def conv3_scopes(W, ae_cfg, which):
 class Pipeline(object):
     """encode -> (bitcost on the side stream || decode) of one batch, the val.py wiring."""
 
-    def __init__(self, dev, ae_config='low', share='cu_range', seed=0, idle_layers=None):
+    def __init__(self, dev, ae_config='low', share='cu_range', seed=0, idle_layers=None, share_weights_with=None):
         import torch
         from imgcomp_cvpr_amd import autoencoder, probclass, config_parser as cp, weights as W, streams
         self.torch, self.dev, self.W = torch, dev, W
         self.ae_cfg, _ = cp.parse(cp.builtin_config_path('ae_configs', 'cvpr', ae_config))
         self.pc_cfg, _ = cp.parse(cp.builtin_config_path('pc_configs', 'cvpr', 'res_shallow'))
-        self.wts = W.synthetic_weights(self.ae_cfg, self.pc_cfg)
-        self.ae = autoencoder.get_network_cls(self.ae_cfg)(self.ae_cfg).load_weights(self.wts, dev)
-        self.pc = probclass.get_network_cls(self.pc_cfg)(self.pc_cfg, num_centers=self.ae_cfg.num_centers).load_weights(self.wts, dev)
+        if share_weights_with is not None:
+            # ONE model evaluates the images of a set (val.py:74-89 builds the graph once): the pipelines of the images in flight read
+            # the same device weights and packed filters (val.Fetcher(share_with=...) does the same), own workspaces and outputs each
+            o = share_weights_with
+            self.wts, self.ae, self.pc = o.wts, o.ae.sharing_weights(), o.pc.sharing_weights()
+        else:
+            self.wts = W.synthetic_weights(self.ae_cfg, self.pc_cfg)
+            self.ae = autoencoder.get_network_cls(self.ae_cfg)(self.ae_cfg).load_weights(self.wts, dev)
+            self.pc = probclass.get_network_cls(self.pc_cfg)(self.pc_cfg, num_centers=self.ae_cfg.num_centers).load_weights(self.wts, dev)
         self.pad_value = float(self.wts['autoencoder/encoder/centers'][0])
         self.serial = share in ('serial', 'auto')    # bitcost, then decode, on one stream
         self.branch = streams.BranchStreams(dev, share=share, idle_layers=idle_layers)
@@ -136,7 +142,11 @@ class InFlight(object):
     def __init__(self, torch, first, dev, n, ae_config, seed0, graphs=False):
         self.torch, self.n, self.i = torch, n, 0
         from imgcomp_cvpr_amd import _lib
-        self.pipes = [Pipeline(dev, ae_config, 'serial', seed=seed0 + 1000 * k).set_input(first.N, first.H, first.Wd) for k in range(n)]
+        shared = os.environ.get('IMGCOMP_BENCH_OWN_WEIGHTS', '0') != '1'       # A/B switch: 1 = every pipeline uploads its own copy (rounds 3-4)
+        self.pipes = []
+        for k in range(n):
+            self.pipes.append(Pipeline(dev, ae_config, 'serial', seed=seed0 + 1000 * k,
+                                       share_weights_with=self.pipes[0] if (shared and k) else None).set_input(first.N, first.H, first.Wd))
         for pl in self.pipes:
             # the plan hint: n independent calls of this shape are in flight (IC_CONV3_IN_FLIGHT, include/imgcomp_hip.h)
             pl.ae.plan_flags = first.ae.plan_flags | _lib.CONV3_IN_FLIGHT(n)
@@ -155,6 +165,60 @@ class InFlight(object):
         self.i += 1
         with self.torch.cuda.stream(self.streams[k]):
             return self.pipes[k].step()
+
+
+def res_stack_runner(torch, lib, _lib, W, ae, ae_cfg, pipe, enc, which, flags, st):
+    """the 32-layer residual stack of the encoder / decoder with its own 32 filters through the library's own launch sequence
+    (ic_ae_res_stack_f32 = the res_stack of network.hip that encode / decode run) on the stack's REAL input: the first buffer of the
+    autoencoder's workspace still holds it after a call (kept for the global skip) -- h2's output after encode, from_bn's after
+    decode.  (Random data would not do: the chip clocks to its power budget, and power follows the data.)  -> (go(stream=None), layers)"""
+    N, H, Wd, dev = pipe.N, pipe.H, pipe.Wd, pipe.dev
+    h4, w4 = H // 4, Wd // 4
+    n4 = N * 128 * h4 * w4
+    rs_need = lib.ic_ae_res_stack_workspace_bytes(N, h4, w4)
+    if which == 'enc':
+        ae.encode(pipe.x, False)
+    else:
+        ae.decode(enc.qhard, False)
+    xin = ae._ws.view(torch.float32)[:n4].clone()
+    yo = torch.empty((N, 128, h4, w4), device=dev)
+    ws_ = torch.empty(rs_need, dtype=torch.uint8, device=dev)
+    tens = []
+    for sname in conv3_scopes(W, ae_cfg, which):
+        tens += list(ae._plan[sname])
+    tab = _lib.ptr_table(tens)
+    B = int(ae_cfg.arch_param_B)
+
+    def go(sth=None):
+        _lib.check(lib.ic_ae_res_stack_f32(_lib.ptr(xin), tab, B, _lib.ptr(yo), N, h4, w4, _lib.ptr(ws_), rs_need, flags,
+                                           st if sth is None else sth))
+    go.keep = (xin, yo, ws_, tens, tab)
+    go.out = yo
+    return go, len(tens) // 3
+
+
+def timed_concurrent_stacks(torch, lib, _lib, dev, ev, st, gos, reps, warm=2):
+    """gos[i] runs on its own stream; HIP events on the main stream bracket all of them -> ms per stack"""
+    main = torch.cuda.current_stream(dev)
+    strs = [torch.cuda.Stream(device=dev) for _ in gos]
+    handles = [ctypes.c_void_p(s_.cuda_stream) for s_ in strs]
+
+    def burst(n):
+        for s_ in strs:
+            s_.wait_stream(main)
+        for _ in range(n):
+            for g_, h_ in zip(gos, handles):
+                g_(h_)
+        for s_ in strs:
+            main.wait_stream(s_)
+    burst(warm)
+    torch.cuda.synchronize(dev)
+    _lib.check(lib.ic_event_record(ev[0], st))
+    burst(reps)
+    _lib.check(lib.ic_event_record(ev[1], st))
+    ms = ctypes.c_float()
+    _lib.check(lib.ic_event_elapsed_ms(ev[0], ev[1], ctypes.byref(ms)))
+    return ms.value / (reps * len(gos))
 
 
 def main():
@@ -299,51 +363,10 @@ def main():
         step_flags = a.plan_flags | (_lib.CONV3_IN_FLIGHT(n_flight) if n_flight > 1 else 0)
 
         def res_stack(which, flags):
-            # the stack's REAL input: the first buffer of the autoencoder's workspace still holds it after a call (kept for the
-            # global skip) -- h2's output after encode, from_bn's after decode.  (Random data would not do: the chip clocks to
-            # its power budget, and power follows the data.)
-            if which == 'enc':
-                ae.encode(pipe.x, False)
-            else:
-                ae.decode(enc.qhard, False)
-            xin = ae._ws.view(torch.float32)[:n4].clone()
-            yo = torch.empty((N, 128, h4, w4), device=dev)
-            ws_ = torch.empty(rs_need, dtype=torch.uint8, device=dev)
-            tens = []
-            for sname in conv3_scopes(W, ae_cfg, which):
-                tens += list(ae._plan[sname])
-            tab = _lib.ptr_table(tens)
-            B = int(ae_cfg.arch_param_B)
-
-            def go(sth=None):
-                _lib.check(lib.ic_ae_res_stack_f32(_lib.ptr(xin), tab, B, _lib.ptr(yo), N, h4, w4, _lib.ptr(ws_), rs_need, flags,
-                                                   st if sth is None else sth))
-            go.keep = (xin, yo, ws_, tens, tab)
-            go.out = yo
-            return go, len(tens) // 3
+            return res_stack_runner(torch, lib, _lib, W, ae, ae_cfg, pipe, enc, which, flags, st)
 
         def timed_concurrent(gos, reps, warm=2):
-            """gos[i] runs on its own stream; events on the main stream bracket all of them"""
-            main = torch.cuda.current_stream(dev)
-            strs = [torch.cuda.Stream(device=dev) for _ in gos]
-            handles = [ctypes.c_void_p(s_.cuda_stream) for s_ in strs]
-
-            def burst(n):
-                for s_ in strs:
-                    s_.wait_stream(main)
-                for _ in range(n):
-                    for g_, h_ in zip(gos, handles):
-                        g_(h_)
-                for s_ in strs:
-                    main.wait_stream(s_)
-            burst(warm)
-            torch.cuda.synchronize(dev)
-            _lib.check(lib.ic_event_record(ev[0], st))
-            burst(reps)
-            _lib.check(lib.ic_event_record(ev[1], st))
-            ms = ctypes.c_float()
-            _lib.check(lib.ic_event_elapsed_ms(ev[0], ev[1], ctypes.byref(ms)))
-            return ms.value / (reps * len(gos))
+            return timed_concurrent_stacks(torch, lib, _lib, dev, ev, st, gos, reps, warm)
 
         def layer_entry(which, flags):
             go, nl = res_stack(which, flags)
@@ -429,6 +452,33 @@ def main():
                             'completes one launch of the stack: HIP events around {} stacks in flight, one per stream, as in the step; '
                             '`encoder.alone` = the same launch with nothing beside it (its duration in a kernel trace, on plan.cus of 256 CUs)'.format(n_flight),
                     'from_profiles': from_profiles, 'encoder': enc_l, 'decoder': dec_l}
+        # The in-flight figure cannot be read from a kernel trace (the tracer serialises the streams); tools/w4_inflight_stamps.py
+        # measures the same schedule with in-kernel stamps on a -DW4_LAUNCH_STAMPS build and commits profiles/rNN_inflight_stamps.json.
+        # `frac` of this line is checked against it: within 5 % of the file's figure for the SAME scenario (n stacks in flight, the
+        # scenario the HIP events above bracket), else the file's figure replaces it and the live one moves to `frac_live_events`.
+        stamps = load_stamps(ROOT)
+        if stamps and stamps.get('input_shape') == [N, 3, H, Wd] and stamps.get('images_in_flight') == n_flight and form3 == 2 \
+                and 'dominant' in stamps.get('stacks', {}) and 'dominant' in stamps.get('step', {}):
+            sk, sp = stamps['stacks'], stamps['step']
+            ratio = roofline['frac'] / sk['dominant']['frac'] if sk['dominant']['frac'] else None
+            roofline['from_stamps'] = {
+                'file': stamps['file'],
+                'stacks_in_flight': {'us_per_launch': sk['dominant']['us_per_launch_under_concurrency'], 'frac': sk['dominant']['frac'],
+                                     'hip_events_us_per_launch_same_run': sk.get('hip_events_us_per_launch'),
+                                     'events_over_stamps_same_run': sk.get('events_over_stamps')},
+                'in_step': {'us_per_launch': sp['dominant']['us_per_launch_under_concurrency'], 'frac': sp['dominant']['frac'],
+                            'launch_duration_us_mean': sp['kernels'][sp['dominant']['kernel']]['launch_duration_us']['mean'],
+                            'concurrency': sp['kernels'][sp['dominant']['kernel']]['concurrency'],
+                            'chip_mfma_issue_share': sp.get('chip_mfma_issue_share'), 'shader_clock_ghz': sp.get('shader_clock_ghz_under_load')},
+                'this_run_frac_over_file_frac': round(ratio, 4) if ratio else None,
+                'note': 'in-kernel s_memrealtime stamps, no tracer: us_per_launch = union of the launches\' [first wave start, last store '
+                        'acknowledged] intervals / launches; `stacks_in_flight` is the scenario `frac` is measured on, `in_step` the timed '
+                        'region of this benchmark itself (other kernels share the chip there)'}
+            if ratio is not None and abs(ratio - 1.0) > 0.05:
+                roofline['frac_live_events'], roofline['achieved_live_events'] = roofline['frac'], roofline['achieved']
+                roofline['frac'] = sk['dominant']['frac']
+                roofline['achieved'] = sk['dominant']['achieved_tflops']
+                roofline['from_stamps']['replaced_frac'] = True
         sym = N * int(ae_cfg.num_chan_bn) * (H // 8) * (Wd // 8)
         roofline_pc = {'kernel': 'context model, 4 masked conv3d layers + cross-entropy (ic_pc_bitcost_f32), standalone',
                        'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': PEAK_F32_MFMA_TFLOPS,
@@ -661,6 +711,21 @@ def load_counters(root):
     """the newest profiles/rNN_counters.json (tools/profile_digest.py), or None"""
     import glob
     files = sorted(glob.glob(os.path.join(root, 'profiles', 'r[0-9][0-9]_counters.json')))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            c = json.load(f)
+        c['file'] = os.path.relpath(files[-1], root)
+        return c
+    except (IOError, OSError, ValueError):
+        return None
+
+
+def load_stamps(root):
+    """the newest profiles/rNN_inflight_stamps.json (tools/w4_inflight_stamps.py: in-kernel launch stamps, no tracer), or None"""
+    import glob
+    files = sorted(glob.glob(os.path.join(root, 'profiles', 'r[0-9][0-9]_inflight_stamps.json')))
     if not files:
         return None
     try:

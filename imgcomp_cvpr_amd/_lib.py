@@ -140,6 +140,7 @@ PROTOTYPES = {
     'ic_bn_workspace_bytes': (c_size_t, [c_int]),
     'ic_bn_stats_f32': (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p, c_void_p]),
     'ic_bn_train_stats_f32': (c_int, [c_void_p] * 5 + [c_float] * 2 + [c_void_p] * 4 + [c_int] * 3 + [c_void_p, c_void_p]),
+    'ic_bn_train_forward_f32': (c_int, [c_void_p] * 5 + [c_float] * 2 + [c_void_p] * 7 + [c_int] * 4 + [c_void_p, c_void_p]),
     'ic_bn_moments_f32': (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p, c_void_p]),
     'ic_bn_train_fold_moments_f32': (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float] +
                                      [c_void_p] * 4 + [c_int, c_void_p]),

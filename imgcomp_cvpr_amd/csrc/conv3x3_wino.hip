@@ -1049,18 +1049,17 @@ extern "C" int ic_conv3x3_c128_pick_algo(int N, int H, int W, int flags) {
 }
 
 // The form ic_conv3x3_c128_auto_f32 runs: 0 direct, 1 Winograd F(2x2,3x3) (decomposition: ic_wino3x3_c128_plan), 2 Winograd F(4x4,3x3).
-// F(4x4) executes 0.5625 of F(2x2)'s multiplies; it is chosen where TWO of its work-groups per CU are resident (each SIMD then has a
-// second wave to issue from while one waits for its 2.36 MB of filter fragments -- 2.25 x F(2x2)'s, and cold in L2 at every layer
-// of a network: 64 layers x 2.36 MB):
-//   * a launch of >= 512 work-groups (N >= 3 Kodak maps, a 4K map: 426 against 622 us; 8 Kodak maps 175 against 242 us), or
-//   * several independent launches in flight (IC_CONV3_IN_FLIGHT: the images of an evaluation set) with >= 384 work-groups together;
+// F(4x4) executes 0.5625 of F(2x2)'s multiplies and streams 2.25 x its filter fragments (2.36 MB per layer, cold in L2 at every layer
+// of a network: 64 layers x 2.36 MB).  It is chosen
+//   * for a launch of >= 160 work-groups (a Kodak map: 192), alone or not -- round 5, after the filter ring went from 6 to 9 quads
+//     and a lone launch began to pull the NEXT layer's fragments into L2 (conv3x3_wino4.hip).  One image at a time through the whole
+//     network (bench.py --in_flight 1, automatic F(2x2) plan against F(4x4) forced, Mpix/s):
+//         384x512 (96 work-groups) 111.5 / 91.1    512x512 (128) 143.6 / 119.4    448x768 (168) 145.3 / 150.2    512x768 (192) 162.8 / 169.3
+//         640x768 (240) 174.0 / 201.9    768x768 (288) 152.7 / 162.4    768x1024 (384) 170.6 / 213.0
+//     (round 4, 6-quad ring, no prefetch: 512x768 162.5 / 140.7 -- the threshold stood at 512 work-groups, two per CU, then);
+//   * with several independent launches in flight (IC_CONV3_IN_FLIGHT: the images of an evaluation set) from 384 work-groups together;
 //   * and only where the map fills its 16-tile segments (1 x 16 tiles, or 2 x 8 on narrow maps: whichever needs fewer): 30 maps of
 //     40 x 40 (62 % full) 68 against 95 us; below 55 % the F(2x2) plan stays.
-// One Kodak map alone (192 work-groups, one per CU) is 29.4 against 32.8 us in a loop over ONE layer (tools/w4sweep.py) but loses in
-// the network, where every layer brings new filters: 2.85 against 2.47 ms per image one at a time (bench.py, round 4).  That the cold
-// fragments are the reason was checked by having every launch touch the NEXT layer's fragments once per XCD (a prototype in the
-// kernel's prologue): one image at a time with F(4x4) forced 140.7 -> 164.1 Mpix/s -- level with the F(2x2) plan's 162.5, so the plan
-// stays as it is --, and 261.8 -> 257.3 with images in flight, where other launches hide the misses already.  Not kept.
 extern "C" int ic_conv3x3_c128_pick_form(int N, int H, int W, int flags) {
     if (ic_conv3x3_c128_pick_algo(N, H, W, flags) == 0) return 0;
     const int form = flags & IC_CONV3_FORM_MASK;
@@ -1071,19 +1070,28 @@ extern "C" int ic_conv3x3_c128_pick_form(int N, int H, int W, int flags) {
     const long long tiles = (long long)N * ic_cdiv(H, 4) * ic_cdiv(W, 4);
     if (tiles * 100 < wgs * 8 * 55) return 1;                                     // segments less than 55 % full (16 tiles x 2 halves per segment)
     const int in_flight = (flags >> 19) & 0xf;
-    return (wgs >= 512 || (in_flight >= 2 && wgs * in_flight >= 384)) ? 2 : 1;
+    return (wgs >= 160 || (in_flight >= 2 && wgs * in_flight >= 384)) ? 2 : 1;
 }
 
-extern "C" int ic_conv3x3_c128_auto_f32(const float* x, const float* w_both, const float* scale, const float* shift,
-                                        const float* res1, const float* res2, float* y, int N, int H, int W, int relu,
-                                        int flags, ic_stream_t stream) {
+int icx_conv3x3_c128_auto_next(const float* x, const float* w_both, const float* scale, const float* shift,
+                               const float* res1, const float* res2, float* y, int N, int H, int W, int relu,
+                               int flags, const float* w_both_next, hipStream_t stream) {
     IC_CHECK_ARG(x && w_both && scale && shift && y && N > 0 && H > 0 && W > 0);
     const int form = ic_conv3x3_c128_pick_form(N, H, W, flags);
-    if (form == 2)
-        return ic_wino4_3x3_c128_bn_act_f32(x, w_both + ic_conv3x3_c128_packed_floats() + WN_PACKED_FLOATS, scale, shift, res1, res2, y,
-                                            N, H, W, relu, flags, stream);
+    if (form == 2) {
+        const size_t f4 = ic_conv3x3_c128_packed_floats() + WN_PACKED_FLOATS;      // the F(4x4) fragments inside a `both` blob
+        // prefetch of the next layer's fragments: one call at a time only (conv3x3_wino4.hip has the measurements)
+        const bool alone = ((flags >> 19) & 0xf) < 2;
+        return icx_wino4_3x3_c128_next(x, w_both + f4, scale, shift, res1, res2, y, N, H, W, relu, flags,
+                                       (w_both_next && alone) ? w_both_next + f4 : nullptr, stream);
+    }
     if (form == 1)
         return ic_wino3x3_c128_bn_act_f32(x, w_both + ic_conv3x3_c128_packed_floats(), scale, shift, res1, res2, y, N, H, W,
                                           relu, flags & ~IC_CONV3_WINO4_BITS, stream);
     return ic_conv3x3_c128_bn_act_f32(x, w_both, scale, shift, res1, res2, y, N, H, W, relu, flags, stream);
+}
+extern "C" int ic_conv3x3_c128_auto_f32(const float* x, const float* w_both, const float* scale, const float* shift,
+                                        const float* res1, const float* res2, float* y, int N, int H, int W, int relu,
+                                        int flags, ic_stream_t stream) {
+    return icx_conv3x3_c128_auto_next(x, w_both, scale, shift, res1, res2, y, N, H, W, relu, flags, nullptr, (hipStream_t)stream);
 }

@@ -59,7 +59,7 @@
 #define W4_ACC_A 32                                 // accumulators (of 36) kept in AGPRs
 // tuning knobs (defaults = the measured best, round 4: 4 waves, rings 6 / 3, turn at quad 6, transform 3 quads after its request)
 #ifndef W4_RA
-#define W4_RA 6                                     // filter-fragment ring, in quads (36 % W4_RA == 0)
+#define W4_RA 9                                     // filter-fragment ring, in quads (36 % W4_RA == 0); round 5: 6 -> 9 (below)
 #endif
 #ifndef W4_RB
 #define W4_RB 3                                     // B-operand ring, in quads (36 % W4_RB == 0)
@@ -213,8 +213,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void wino4_3x3_kernel(const WnArgs a) {
     constexpr int KS = CIN / 4, IT = KS / 4, PARTS = COUT / 64;   // k-steps, iterations of 4 k-steps, work-groups per segment
     __shared__ f32x4 ring[2 * 4 * W4_QUADS * 64];                 // [half][k-step of the iteration][position quad][lane]: 72 KB
+    __shared__ float pf_sink[64];                                 // where the prefetch below lands (never read)
 #ifdef W4_STAMPS
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef W4_LAUNCH_STAMPS
+    const unsigned long long ls_c0 = __builtin_amdgcn_s_memtime(), ls_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, n16 = lane & 15, kq = lane >> 4;
@@ -413,6 +417,25 @@ void wino4_3x3_kernel(const WnArgs a) {
     load_patch(pw);
 #pragma unroll
     for (int Q = 0; Q < W4_RA - 1; ++Q) load_filter(Q, Q);
+    // The NEXT layer's fragments into this XCD's L2 while this layer computes (one call at a time only: a lone launch starts every
+    // layer on 2.36 MB of fragments no L2 has seen -- 64 layers x 2.36 MB -- and its one wave per SIMD waits for them; with several
+    // images in flight the other launches cover the misses and the extra traffic costs more than it brings: 261.8 -> 257.3 Mpix/s,
+    // round 4).  Work-groups are dealt round-robin to the XCDs: work-group j of an XCD's n touches one dword of every 128-byte line
+    // of its 1 / n of the blob -- 3 loads per lane on a Kodak map.  LDS-DMA into a sink: no register is held for data nobody reads,
+    // and the hidden loads can only make the compiler's vmcnt waits stricter (loads return in order), never weaker.
+    if (a.wp_next) {
+        constexpr unsigned LINES = 36u * CIN * COUT * 4u / 128u;
+        const unsigned n_x = (gridDim.x + 7u) >> 3, j_x = blockIdx.x >> 3;
+        const unsigned per = (LINES + n_x - 1) / n_x, l0 = j_x * per;
+        const __amdgpu_buffer_rsrc_t nr = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp_next, 0, 36 * CIN * COUT * 4, 0x00020000);
+        const unsigned sink = (unsigned)(size_t)pf_sink;          // LDS byte address (wave-uniform)
+        for (unsigned l = threadIdx.x; l < per; l += 256) {
+            const unsigned off = (l0 + l) < LINES ? (l0 + l) * 128u : WN_OOB;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(off), "s"(nr), "s"(sink) : "memory");
+        }
+    }
     transform_put(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -421,13 +444,13 @@ void wino4_3x3_kernel(const WnArgs a) {
     const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
 #endif
     // One iteration = 4 k-steps = 36 quads of 4 MFMAs.  Per quad, IN THIS ORDER: its 4 MFMAs, then the request of the filter
-    // fragments W4_RA - 1 quads ahead into the ring slot the PREVIOUS quad consumed, then the B operands two quads ahead into the
+    // fragments W4_RA - 1 quads ahead into the ring slot the PREVIOUS quad consumed, then the B operands W4_RB - 1 quads ahead into the
     // slot the previous quad consumed: a register is overwritten by a load issued at least 4 MFMAs after its last reader.
     // `last`: the eighth iteration has no next k-steps to prepare; the epilogue's first operands are requested in its place.
     auto iteration = [&](const int j, const int u2, const bool last) __attribute__((always_inline)) {      // reads ring half u2
         f32x4 bq[W4_RB];
-        bq[0] = ring[((u2 * 4 + 0) * W4_QUADS + 0) * 64 + lane];
-        bq[1] = ring[((u2 * 4 + 0) * W4_QUADS + 1) * 64 + lane];
+#pragma unroll
+        for (int q0 = 0; q0 < W4_RB - 1; ++q0) bq[q0] = ring[((u2 * 4 + 0) * W4_QUADS + q0) * 64 + lane];
 #pragma unroll
         for (int lq = 0; lq < 36; ++lq) {                         // quad of the iteration: k-step lq / 9, positions 4 (lq % 9) ..
             const int q = lq % W4_QUADS;
@@ -444,8 +467,8 @@ void wino4_3x3_kernel(const WnArgs a) {
                 }
             }
             if (!last || lq + W4_RA - 1 < 36) load_filter((lq + W4_RA - 1) % W4_RA, Q + W4_RA - 1);      // 36 % W4_RA == 0: the slot depends on lq only
-            if (lq + 2 < 36)
-                bq[(lq + 2) % W4_RB] = ring[((u2 * 4 + (lq + 2) / W4_QUADS) * W4_QUADS + (lq + 2) % W4_QUADS) * 64 + lane];
+            if (lq + W4_RB - 1 < 36)
+                bq[(lq + W4_RB - 1) % W4_RB] = ring[((u2 * 4 + (lq + W4_RB - 1) / W4_QUADS) * W4_QUADS + (lq + W4_RB - 1) % W4_QUADS) * 64 + lane];
             // the wave's own k-step of the NEXT iteration: requested, then from W4_GAP quads later on transformed and written into
             // the other half (W4_SPREAD: in 13 slices behind MFMAs; else as one block)
             if (lq == W4_TURN && !last) load_patch(4 * (j + 1) + pw);
@@ -591,6 +614,17 @@ void wino4_3x3_kernel(const WnArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     }
     }
+#ifdef W4_LAUNCH_STAMPS
+    // one record per WAVE, plain stores (atomics on one line from 768 waves cost 15 us per launch: tried): a.prof points at the launch's
+    // first record; [0] first instruction, [1] all stores acknowledged -- both on the 100 MHz real-time counter every XCD shares --,
+    // [2] shader clocks entry -> end (with [1] - [0]: the shader clock under this load), [3] MFMAs issued
+    if (a.prof && (threadIdx.x & 63) == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long ls_c1 = __builtin_amdgcn_s_memtime(), ls_r1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* d = a.prof + 4 * ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6));
+        d[0] = ls_r0; d[1] = ls_r1; d[2] = ls_c1 - ls_c0; d[3] = (unsigned long long)(36 * KS);
+    }
+#endif
 #ifdef W4_STAMPS
     if (a.prof && (threadIdx.x & 63) == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -607,6 +641,21 @@ void wino4_3x3_kernel(const WnArgs a) {
 // stamp builds only (never in the shipped library: tests/test_cpu_host.py checks the export list)
 static void* g_w4_dbg = nullptr;
 extern "C" void ic_wino4_debug_set_buffer(void* p) { g_w4_dbg = p; }
+#endif
+#ifdef W4_LAUNCH_STAMPS
+// launch-stamp builds only (tools/w4_inflight_stamps.py): a device buffer of `capacity_waves` records of 4 x u64, zeroed by the caller.
+// Launch i of the process (any stream, any instantiation) takes the next 4 x work-groups records; the host table gets
+// (first record, waves, CIN * 1000 + COUT) per launch.
+#include <atomic>
+static unsigned long long* g_w4_ls = nullptr;
+static long long g_w4_ls_cap = 0, g_w4_ls_max_launches = 0;
+static std::atomic<long long> g_w4_ls_next{0}, g_w4_ls_launch{0};
+static long long* g_w4_ls_table = nullptr;          // host array [max_launches][3]
+extern "C" void ic_wino4_launch_stamps_set(void* dev_records, long long capacity_waves, long long* host_table, long long max_launches) {
+    g_w4_ls = (unsigned long long*)dev_records; g_w4_ls_cap = capacity_waves; g_w4_ls_table = host_table; g_w4_ls_max_launches = max_launches;
+    g_w4_ls_next = 0; g_w4_ls_launch = 0;
+}
+extern "C" long long ic_wino4_launch_stamps_count(void) { return g_w4_ls_launch.load(); }
 #endif
 
 extern "C" int ic_wino4_3x3_c128_supported(int N, int H, int W) {
@@ -628,9 +677,9 @@ extern "C" long long ic_wino4_3x3_c128_workgroups(int N, int H, int W) {
 
 template <int RES, int CIN, int COUT, bool SHUF, bool SEG2>
 static int w4_launch2(const float* x, const float* w_packed, const float* scale, const float* shift, const float* res1, const float* res2,
-                      float* y, int N, int H, int W, int relu, int flags, hipStream_t st) {
+                      float* y, int N, int H, int W, int relu, int flags, hipStream_t st, const float* w_next = nullptr) {
     WnArgs a{};
-    a.x = x; a.wp = w_packed; a.scale = scale; a.shift = shift; a.res1 = res1; a.res2 = res2; a.y = y;
+    a.x = x; a.wp = w_packed; a.wp_next = w_next; a.scale = scale; a.shift = shift; a.res1 = res1; a.res2 = res2; a.y = y;
     a.N = N; a.H = H; a.W = W; a.relu = relu;
     a.grows = SEG2 ? ic_cdiv(ic_cdiv(H, 4), 2) : ic_cdiv(H, 4);
     a.gcols = SEG2 ? ic_cdiv(W, 32) : ic_cdiv(W, 64);
@@ -640,6 +689,16 @@ static int w4_launch2(const float* x, const float* w_packed, const float* scale,
     a.prof = (unsigned long long*)g_w4_dbg;
 #endif
     const long long wgs = (long long)(COUT / 64) * a.ngroups;
+#ifdef W4_LAUNCH_STAMPS
+    if (g_w4_ls) {
+        const long long first = g_w4_ls_next.fetch_add(4 * wgs), l = g_w4_ls_launch.load();
+        if (first + 4 * wgs <= g_w4_ls_cap && l < g_w4_ls_max_launches) {
+            g_w4_ls_launch.fetch_add(1);
+            a.prof = g_w4_ls + 4 * first;
+            g_w4_ls_table[3 * l] = first; g_w4_ls_table[3 * l + 1] = 4 * wgs; g_w4_ls_table[3 * l + 2] = CIN * 1000 + COUT;
+        }
+    }
+#endif
     const dim3 grid((unsigned)wgs), block(256);
     if (wgs <= W4_WT_MAX) hipLaunchKernelGGL((wino4_3x3_kernel<true, RES, CIN, COUT, SHUF, SEG2>), grid, block, 0, st, a);     // a single round: write-through stores
     else hipLaunchKernelGGL((wino4_3x3_kernel<false, RES, CIN, COUT, SHUF, SEG2>), grid, block, 0, st, a);
@@ -648,20 +707,23 @@ static int w4_launch2(const float* x, const float* w_packed, const float* scale,
 }
 template <int RES, int CIN, int COUT, bool SHUF>
 static int w4_launch(const float* x, const float* w_packed, const float* scale, const float* shift, const float* res1, const float* res2,
-                     float* y, int N, int H, int W, int relu, int flags, hipStream_t st) {
-    if (w4_seg2(H, W)) return w4_launch2<RES, CIN, COUT, SHUF, true>(x, w_packed, scale, shift, res1, res2, y, N, H, W, relu, flags, st);
-    return w4_launch2<RES, CIN, COUT, SHUF, false>(x, w_packed, scale, shift, res1, res2, y, N, H, W, relu, flags, st);
+                     float* y, int N, int H, int W, int relu, int flags, hipStream_t st, const float* w_next = nullptr) {
+    if (w4_seg2(H, W)) return w4_launch2<RES, CIN, COUT, SHUF, true>(x, w_packed, scale, shift, res1, res2, y, N, H, W, relu, flags, st, w_next);
+    return w4_launch2<RES, CIN, COUT, SHUF, false>(x, w_packed, scale, shift, res1, res2, y, N, H, W, relu, flags, st, w_next);
 }
 
-extern "C" int ic_wino4_3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
-                                            const float* res1, const float* res2, float* y, int N, int H, int W, int relu,
-                                            int flags, ic_stream_t stream) {
+int icx_wino4_3x3_c128_next(const float* x, const float* w_packed, const float* scale, const float* shift, const float* res1, const float* res2,
+                            float* y, int N, int H, int W, int relu, int flags, const float* w_packed_next, hipStream_t st) {
     IC_CHECK_ARG(x && w_packed && scale && shift && y);
     IC_CHECK_ARG(N > 0 && H > 0 && W > 0);
     if (!ic_wino4_3x3_c128_supported(N, H, W)) return IC_ERR_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
-    if (res2) return w4_launch<2, 128, 128, false>(x, w_packed, scale, shift, res1, res2, y, N, H, W, relu, flags, st);
-    return w4_launch<1, 128, 128, false>(x, w_packed, scale, shift, res1, nullptr, y, N, H, W, relu, flags, st);
+    if (res2) return w4_launch<2, 128, 128, false>(x, w_packed, scale, shift, res1, res2, y, N, H, W, relu, flags, st, w_packed_next);
+    return w4_launch<1, 128, 128, false>(x, w_packed, scale, shift, res1, nullptr, y, N, H, W, relu, flags, st, w_packed_next);
+}
+extern "C" int ic_wino4_3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
+                                            const float* res1, const float* res2, float* y, int N, int H, int W, int relu,
+                                            int flags, ic_stream_t stream) {
+    return icx_wino4_3x3_c128_next(x, w_packed, scale, shift, res1, res2, y, N, H, W, relu, flags, nullptr, (hipStream_t)stream);
 }
 
 // ---- the two large 5x5 / stride-2 layers as F(4x4) 3x3 convolutions over phases (packing modes 2 / 3 above) -------------------------

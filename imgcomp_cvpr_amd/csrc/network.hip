@@ -20,7 +20,7 @@ static inline int layer_flags(int flags, int li) {
 
 // One layer of the stack as the walk below visits it: the per-layer path launches it, the persistent path records it.
 struct StackWalk {
-    bool record; WnStackArgs* sa; int flags; int N, H, W; hipStream_t st; int li;
+    bool record; WnStackArgs* sa; int flags; int N, H, W; hipStream_t st; int li; int nlayers;
     int conv(const float* x, const float* const* l, const float* r1, const float* r2, float* y, int relu) {
         if (record) {
             WnStackLayer& L = sa->layers[li];
@@ -29,7 +29,9 @@ struct StackWalk {
             ++li;
             return IC_OK;
         }
-        const int rc = ic_conv3x3_c128_auto_f32(x, l[0], l[1], l[2], r1, r2, y, N, H, W, relu, layer_flags(flags, li), st);
+        // (the table holds the stack's layers one after the other: l + 3 is the next layer's entry)
+        const int rc = icx_conv3x3_c128_auto_next(x, l[0], l[1], l[2], r1, r2, y, N, H, W, relu, layer_flags(flags, li),
+                                                  li + 1 < nlayers ? l[3] : nullptr, st);
         ++li;
         return rc;
     }
@@ -93,7 +95,7 @@ static int res_stack(const void* const* tab, int B, float* const bufs[5], int N,
 #ifdef IC_TUNING
     if (nb) {
         WnStackArgs sa{};
-        StackWalk w{true, &sa, flags, N, H, W, st, 0};
+        StackWalk w{true, &sa, flags, N, H, W, st, 0, nlayers};
         int rc = res_stack_walk(w, tab, B, bufs, out_idx);
         if (rc) return rc;
         sa.flags = sync; sa.N = N; sa.H = H; sa.W = W; sa.grows = ic_cdiv(H, 4); sa.gcols = ic_cdiv(W, 32);
@@ -102,7 +104,7 @@ static int res_stack(const void* const* tab, int B, float* const bufs[5], int N,
     }
 #endif
     (void)nb;
-    StackWalk w{false, nullptr, flags, N, H, W, st, 0};
+    StackWalk w{false, nullptr, flags, N, H, W, st, 0, nlayers};
     return res_stack_walk(w, tab, B, bufs, out_idx);
 }
 

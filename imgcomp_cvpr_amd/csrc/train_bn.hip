@@ -2,34 +2,38 @@
 //   reference: code/autoencoder.py:106-125 (slim.batch_norm, is_training=True: batch statistics over (N,H,W), biased
 //   variance, eps 1e-5, decay 0.9), :127-134 (_quantize, qbar = qsoft + stop_gradient(qhard - qsoft)),
 //   :171-200 (heatmap), code/quantizer.py:43-100.
-// All of it is HBM streaming: every kernel reads/writes each activation once, per-channel sums are reduced in
-// float64 in a fixed order by ONE work-group per channel (deterministic, no atomics).
+// All of it is HBM streaming.  Per-channel sums are reduced in float64 in a FIXED order (deterministic, no atomics): BN_SPLIT
+// work-groups per channel each sum a slice of the batch (per-thread double accumulators, LDS tree) into the caller's workspace,
+// and whoever needs the totals adds the BN_SPLIT partials in index order -- the element-wise kernel that applies them does it
+// itself in its prologue (a handful of loads), so a layer's forward is two launches and so is its backward:
 //
 // forward :  raw = conv(x)                      (conv kernels with scale = 1, shift = 0)
-//            mean, var = ic_bn_stats_f32(raw)   -> host folds scale = gamma / sqrt(var + eps), shift = beta - mean * scale
-//            y = ic_bn_apply_f32(raw, scale, shift, relu, res1, res2)
+//            ic_bn_train_forward_f32(raw)       partial sums; then per plane: totals -> mean, var -> scale = gamma / sqrt(var + eps),
+//                                               shift = beta - mean * scale -> y = act(raw * scale + shift) + res1 + res2
+//                                               (one designated work-group per channel writes the statistics and the moving averages)
 // backward:  g = dy * [raw * scale + shift > 0]  (ReLU mask recomputed, the residual adds pass dy through unchanged)
-//            ic_bn_bwd_reduce_f32 -> sum_g, sum_gxhat per channel  (= dbeta, dgamma)
-//            ic_bn_bwd_apply_f32  -> draw = gamma * invstd * (g - sum_g / M - xhat * sum_gxhat / M)
+//            ic_bn_backward_f32                 partial sums of (g, g xhat); then per plane: totals (= dbeta, dgamma) ->
+//                                               draw = gamma * invstd * (g - sum_g / M - xhat * sum_gxhat / M)
+// Round 5: one 1024-thread work-group per channel (rounds 2-4) used 128 of the 256 CUs and was bound by what one CU can pull
+// (7.3 / 10.4 us per layer for 16.8 / 33.5 MB); four work-groups per channel and 16-byte accesses in the element-wise kernels
+// took the four BatchNorm launches of a 32 x 128 x 32 x 32 layer from 35.0 to the figures in DESIGN.md section 3 (training step).
 #include "common.h"
 
-#define BN_CHUNKS 64      // (workspace layout of ABI version 1: [C][BN_CHUNKS][2] partials, then the [2][C] sums still used)
+#define BN_CHUNKS 64      // workspace layout: [C][BN_CHUNKS][2] partials (BN_SPLIT of the BN_CHUNKS slots are used), then [2][C] sums
+#define BN_SPLIT 4        // work-groups per channel in the reductions
 
 struct BnArgs {
     const float* x; const float* dy; const float* scale; const float* shift;
     const float* mean; const float* invstd; const float* gamma;
-    const double* sums;       // [2][C] (sum_g, sum_gxhat)
+    const double* sums;       // [2][C] (sum_g, sum_gxhat); nullptr: take the totals from `partial`
     double* partial;          // workspace
     float* out0; float* out1; // stats: mean, var ; bwd_apply: dx
     int N, C, HW, relu;
     long long count;          // bwd_apply: elements per channel the sums run over (0 = N * HW; larger under sync BatchNorm)
+    double* sums_out;         // bwd_apply with partials: where the designated work-group of a channel leaves the totals (or nullptr)
+    float* dbeta; float* dgamma;
 };
 
-// ---- one work-group of 1024 threads per channel: sums, and what follows from them, in ONE launch ----------------------------
-// The two-stage form of round 1 cost two launches per reduction (stage 1 over [C][chunks] blocks, stage 2 over the partials) and
-// the forward pass a third for the fold -- 5-6 us each of mostly launch latency, 140 + 70 times per training step.  A channel
-// of the training shapes is 128 K elements: one 1024-thread block streams it in a few microseconds (16-byte loads, 128
-// blocks on 128 CUs), reduces in a fixed order (per-thread double accumulators, LDS tree) and finishes the job itself.
 __device__ __forceinline__ void bn_block_reduce2_1024(double& a, double& b) {
     __shared__ double sa[1024], sb[1024];
     sa[threadIdx.x] = a; sb[threadIdx.x] = b;
@@ -41,9 +45,10 @@ __device__ __forceinline__ void bn_block_reduce2_1024(double& a, double& b) {
     a = sa[0]; b = sb[0];
 }
 
+// Sums of channel c over the images [n0, n0 + nn) by one 1024-thread work-group.
 // MODE 0: (sum x, sum x^2)   MODE 1: (sum g, sum g * xhat), g = dy masked by the ReLU of the forward pass
 template <int MODE>
-__device__ __forceinline__ void bn_channel_sums(const BnArgs& a, int c, double& s0, double& s1) {
+__device__ __forceinline__ void bn_channel_sums(const BnArgs& a, int c, int n0, int nn, double& s0, double& s1) {
     float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
     if (MODE == 1) { sc = a.scale[c]; sh = a.shift[c]; mu = a.mean[c]; is = a.invstd[c]; }
     s0 = 0.0; s1 = 0.0;
@@ -56,14 +61,14 @@ __device__ __forceinline__ void bn_channel_sums(const BnArgs& a, int c, double& 
     };
     if ((a.HW & 3) == 0) {
         // flattened float4 index i = n * HW4 + p4, stepped by 1024 with a carry instead of a division per load; four loads
-        // in flight per thread (the block is alone on its CU: memory-level parallelism has to come from within the thread)
+        // in flight per thread
         const int HW4 = a.HW >> 2;
-        const long long E4 = (long long)a.N * HW4;
+        const long long E4 = (long long)nn * HW4;
         const int dn = 1024 / HW4, dp = 1024 - dn * HW4;
         int n = (int)(threadIdx.x / HW4), p4 = (int)(threadIdx.x - n * HW4);
         long long i = threadIdx.x;
         auto step = [&]() __attribute__((always_inline)) { i += 1024; p4 += dp; n += dn; if (p4 >= HW4) { p4 -= HW4; ++n; } };
-        auto offs = [&]() __attribute__((always_inline)) -> size_t { return ((size_t)n * a.C + c) * a.HW + 4 * (size_t)p4; };
+        auto offs = [&]() __attribute__((always_inline)) -> size_t { return ((size_t)(n0 + n) * a.C + c) * a.HW + 4 * (size_t)p4; };
         for (; i + 3 * 1024 < E4;) {
             float4 xv[4], g[4];
 #pragma unroll
@@ -84,29 +89,52 @@ __device__ __forceinline__ void bn_channel_sums(const BnArgs& a, int c, double& 
             acc(xv.x, g.x); acc(xv.y, g.y); acc(xv.z, g.z); acc(xv.w, g.w);
         }
     } else {
-        const long long E = (long long)a.N * a.HW;
+        const long long E = (long long)nn * a.HW;
         for (long long i = threadIdx.x; i < E; i += 1024) {
             const int n = (int)(i / a.HW), p = (int)(i - (long long)n * a.HW);
-            const size_t o = ((size_t)n * a.C + c) * a.HW + p;
+            const size_t o = ((size_t)(n0 + n) * a.C + c) * a.HW + p;
             acc(a.x[o], MODE == 1 ? a.dy[o] : 0.f);
         }
     }
     bn_block_reduce2_1024(s0, s1);
 }
 
-// what the forward pass derives from a channel's (sum x, sum x^2) over M elements: invstd, the folded scale/shift and the
-// moving-average update (decay 0.9; TF's fused kernel feeds the UNBIASED variance to the moving average while normalising
-// with the biased one).  One function for the fused and the cross-replica path: the same bits from the same sums.
-__device__ __forceinline__ void bn_fold_channel(int c, double s0, double s1, long long M, const float* gamma, const float* beta,
-                                                float* moving_mean, float* moving_var, float decay, float eps, float* mean,
-                                                float* invstd, float* scale, float* shift) {
+// grid (BN_SPLIT, C): slice s of the batch of channel c -> partial[c][s]
+template <int MODE>
+__global__ __launch_bounds__(1024) void bn_partial_kernel(const BnArgs a) {
+    const int s = blockIdx.x, c = blockIdx.y;
+    const int per = (a.N + BN_SPLIT - 1) / BN_SPLIT;
+    const int n0 = s * per < a.N ? s * per : a.N, n1 = n0 + per < a.N ? n0 + per : a.N;
+    double s0, s1;
+    bn_channel_sums<MODE>(a, c, n0, n1 - n0, s0, s1);
+    if (threadIdx.x == 0) { a.partial[((size_t)c * BN_CHUNKS + s) * 2] = s0; a.partial[((size_t)c * BN_CHUNKS + s) * 2 + 1] = s1; }
+}
+// the totals of channel c: the partials in index order (the ONE place that defines the order -- every consumer calls this)
+__device__ __forceinline__ void bn_totals(const double* __restrict__ partial, int c, double& s0, double& s1) {
+    s0 = 0.0; s1 = 0.0;
+#pragma unroll
+    for (int s = 0; s < BN_SPLIT; ++s) { s0 += partial[((size_t)c * BN_CHUNKS + s) * 2]; s1 += partial[((size_t)c * BN_CHUNKS + s) * 2 + 1]; }
+}
+
+// what the forward pass derives from a channel's (sum x, sum x^2) over M elements: invstd and the folded scale / shift
+__device__ __forceinline__ void bn_fold_values(double s0, double s1, long long M, float gamma, float beta, float eps,
+                                               float& mf, float& vf, float& is, float& sc, float& sh) {
     const double m = s0 / (double)M;
     double v = s1 / (double)M - m * m;
     if (v < 0.0) v = 0.0;
-    const float mf = (float)m, vf = (float)v;
-    const float is = 1.0f / sqrtf(vf + eps);
-    const float sc = gamma[c] * is;
-    mean[c] = mf; invstd[c] = is; scale[c] = sc; shift[c] = beta[c] - mf * sc;
+    mf = (float)m; vf = (float)v;
+    is = 1.0f / sqrtf(vf + eps);
+    sc = gamma * is;
+    sh = beta - mf * sc;
+}
+// ... and the moving-average update (decay 0.9; TF's fused kernel feeds the UNBIASED variance to the moving average while
+// normalising with the biased one).  One function for the fused and the cross-replica path: the same bits from the same sums.
+__device__ __forceinline__ void bn_fold_channel(int c, double s0, double s1, long long M, const float* gamma, const float* beta,
+                                                float* moving_mean, float* moving_var, float decay, float eps, float* mean,
+                                                float* invstd, float* scale, float* shift) {
+    float mf, vf, is, sc, sh;
+    bn_fold_values(s0, s1, M, gamma[c], beta[c], eps, mf, vf, is, sc, sh);
+    mean[c] = mf; invstd[c] = is; scale[c] = sc; shift[c] = sh;
     if (moving_mean) moving_mean[c] = moving_mean[c] * decay + mf * (1.f - decay);
     if (moving_var) {
         const float unbiased = vf * (float)((double)M / (double)(M > 1 ? M - 1 : 1));
@@ -119,72 +147,129 @@ struct BnFoldArgs {
     float* mean; float* invstd; float* scale; float* shift;
 };
 
-// OUT 0: mean / biased variance (ic_bn_stats_f32)   1: the sums as doubles (cross-replica path)   2: the whole fold
+// one thread per channel: the totals, and what the caller asked to be made of them
+// OUT 0: mean / biased variance (ic_bn_stats_f32)   1: the sums as doubles (cross-replica paths; + dbeta / dgamma)   2: the whole fold
 template <int OUT>
-__global__ __launch_bounds__(1024) void bn_channel_stats_kernel(const BnArgs a, double* __restrict__ sums, const BnFoldArgs f) {
-    const int c = blockIdx.x;
+__global__ __launch_bounds__(64) void bn_finish_kernel(const double* __restrict__ partial, int C, long long M, double* __restrict__ sums,
+                                                       float* __restrict__ out0, float* __restrict__ out1, const BnFoldArgs f) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
     double s0, s1;
-    bn_channel_sums<0>(a, c, s0, s1);
-    if (threadIdx.x != 0) return;
-    const long long M = (long long)a.N * a.HW;
+    bn_totals(partial, c, s0, s1);
     if (OUT == 0) {
         const double m = s0 / (double)M;
         double v = s1 / (double)M - m * m;
         if (v < 0.0) v = 0.0;
-        a.out0[c] = (float)m; a.out1[c] = (float)v;
+        out0[c] = (float)m; out1[c] = (float)v;
     } else if (OUT == 1) {
-        sums[c] = s0; sums[a.C + c] = s1;
+        sums[c] = s0; sums[C + c] = s1;
+        if (out0) out0[c] = (float)s0;          // dbeta
+        if (out1) out1[c] = (float)s1;          // dgamma
     } else {
         bn_fold_channel(c, s0, s1, M, f.gamma, f.beta, f.moving_mean, f.moving_var, f.decay, f.eps, f.mean, f.invstd, f.scale, f.shift);
     }
 }
 
-// backward: (sum g, sum g xhat) -> sums[2][C] (doubles, for the data gradient) and dbeta / dgamma
-__global__ __launch_bounds__(1024) void bn_channel_bwd_sums_kernel(const BnArgs a, double* __restrict__ sums, float* __restrict__ dbeta,
-                                                                   float* __restrict__ dgamma) {
-    const int c = blockIdx.x;
-    double s0, s1;
-    bn_channel_sums<1>(a, c, s0, s1);
-    if (threadIdx.x != 0) return;
-    sums[c] = s0; sums[a.C + c] = s1;
-    if (dbeta) dbeta[c] = (float)s0;
-    if (dgamma) dgamma[c] = (float)s1;
-}
-
-// grid (plane chunks, N*C planes): one (n, c) plane per blockIdx.y -> channel constants are block-uniform
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, const float* __restrict__ res1,
-                                                       const float* __restrict__ res2, float* __restrict__ y,
-                                                       int C, int HW, long long total, int relu) {
-    const int c = blockIdx.y % C;
-    const float sc = scale[c], sh = shift[c];
-    const size_t base = (size_t)blockIdx.y * HW;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
-        float v = fmaf(x[base + p], sc, sh);
-        if (relu) v = fmaxf(v, 0.f);
-        if (res1) v += res1[base + p];
-        if (res2) v += res2[base + p];
-        y[base + p] = v;
+// ---- element-wise halves: grid (plane chunks, N*C planes): one (n, c) plane per blockIdx.y -> channel constants are block-uniform;
+// VEC: 16-byte accesses (HW % 4 == 0 and 16-byte aligned planes) ----
+struct BnApplyArgs {
+    const float* x; const float* scale; const float* shift; const float* res1; const float* res2; float* y;
+    int C, HW, relu;
+    const double* partial;    // != nullptr: scale / shift are OUTPUTS -- folded here from the partial sums (BnFoldArgs f, count M)
+    long long M;
+};
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a, const BnFoldArgs f) {
+    const int c = blockIdx.y % a.C;
+    float sc, sh;
+    if (a.partial) {
+        double s0, s1;
+        bn_totals(a.partial, c, s0, s1);
+        float mf, vf, is;
+        bn_fold_values(s0, s1, a.M, f.gamma[c], f.beta[c], f.eps, mf, vf, is, sc, sh);
+        // plane (n = 0, c), first chunk, first thread: the channel's statistics and moving averages, once
+        if ((int)blockIdx.y == c && blockIdx.x == 0 && threadIdx.x == 0)
+            bn_fold_channel(c, s0, s1, a.M, f.gamma, f.beta, f.moving_mean, f.moving_var, f.decay, f.eps, f.mean, f.invstd, f.scale, f.shift);
+    } else { sc = a.scale[c]; sh = a.shift[c]; }
+    const size_t base = (size_t)blockIdx.y * a.HW;
+    if (VEC) {
+        const int HW4 = a.HW >> 2;
+        const float4* x4 = reinterpret_cast<const float4*>(a.x + base);
+        const float4* r1 = a.res1 ? reinterpret_cast<const float4*>(a.res1 + base) : nullptr;
+        const float4* r2 = a.res2 ? reinterpret_cast<const float4*>(a.res2 + base) : nullptr;
+        float4* y4 = reinterpret_cast<float4*>(a.y + base);
+        for (int p = blockIdx.x * 256 + threadIdx.x; p < HW4; p += gridDim.x * 256) {
+            float4 v = x4[p];
+            v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
+            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (r1) { const float4 r = r1[p]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+            if (r2) { const float4 r = r2[p]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+            y4[p] = v;
+        }
+    } else {
+        for (int p = blockIdx.x * 256 + threadIdx.x; p < a.HW; p += gridDim.x * 256) {
+            float v = fmaf(a.x[base + p], sc, sh);
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (a.res1) v += a.res1[base + p];
+            if (a.res2) v += a.res2[base + p];
+            a.y[base + p] = v;
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs a, long long total) {
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs a) {
     const double M = a.count > 0 ? (double)a.count : (double)a.N * a.HW;
     const int c = blockIdx.y % a.C;
     const float sc = a.scale[c], sh = a.shift[c], mu = a.mean[c], is = a.invstd[c];
-    const float k = a.gamma[c] * is, mg = (float)(a.sums[c] / M), mgx = (float)(a.sums[a.C + c] / M);
+    double t0, t1;
+    if (a.sums) { t0 = a.sums[c]; t1 = a.sums[a.C + c]; }
+    else {
+        bn_totals(a.partial, c, t0, t1);
+        if ((int)blockIdx.y == c && blockIdx.x == 0 && threadIdx.x == 0) {
+            if (a.sums_out) { a.sums_out[c] = t0; a.sums_out[a.C + c] = t1; }
+            if (a.dbeta) a.dbeta[c] = (float)t0;
+            if (a.dgamma) a.dgamma[c] = (float)t1;
+        }
+    }
+    const float k = a.gamma[c] * is, mg = (float)(t0 / M), mgx = (float)(t1 / M);
     const size_t base = (size_t)blockIdx.y * a.HW;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < a.HW; p += gridDim.x * 256) {
-        const float xv = a.x[base + p];
-        float g = a.dy[base + p];
+    auto one = [&](float xv, float g) __attribute__((always_inline)) -> float {
         if (a.relu && !(fmaf(xv, sc, sh) > 0.f)) g = 0.f;
-        a.out0[base + p] = k * (g - mg - (xv - mu) * is * mgx);
+        return k * (g - mg - (xv - mu) * is * mgx);
+    };
+    if (VEC) {
+        const int HW4 = a.HW >> 2;
+        const float4* x4 = reinterpret_cast<const float4*>(a.x + base);
+        const float4* g4 = reinterpret_cast<const float4*>(a.dy + base);
+        float4* o4 = reinterpret_cast<float4*>(a.out0 + base);
+        for (int p = blockIdx.x * 256 + threadIdx.x; p < HW4; p += gridDim.x * 256) {
+            const float4 xv = x4[p], g = g4[p];
+            o4[p] = float4{one(xv.x, g.x), one(xv.y, g.y), one(xv.z, g.z), one(xv.w, g.w)};
+        }
+    } else {
+        for (int p = blockIdx.x * 256 + threadIdx.x; p < a.HW; p += gridDim.x * 256) a.out0[base + p] = one(a.x[base + p], a.dy[base + p]);
     }
 }
 
-static int ew_grid(long long total) {
-    long long g = (total + 255) / 256;
-    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+static inline bool bn_vec_ok(int HW, const void* p0, const void* p1, const void* p2, const void* p3, const void* p4) {
+    auto al = [](const void* p) { return p == nullptr || ((uintptr_t)p & 15) == 0; };
+    return (HW & 3) == 0 && al(p0) && al(p1) && al(p2) && al(p3) && al(p4);
+}
+static inline dim3 bn_ew_grid(int HW, int planes, bool vec) {
+    const int per = vec ? 1024 : 1024;            // elements per work-group of 256 threads: one float4 or four floats per thread
+    int gx = ic_cdiv(HW, per);
+    return dim3(gx < 1 ? 1 : gx, planes);
+}
+static void bn_launch_apply(const BnApplyArgs& a, const BnFoldArgs& f, int planes, hipStream_t st) {
+    const bool vec = bn_vec_ok(a.HW, a.x, a.res1, a.res2, a.y, nullptr);
+    if (vec) hipLaunchKernelGGL(bn_apply_kernel<true>, bn_ew_grid(a.HW, planes, true), dim3(256), 0, st, a, f);
+    else hipLaunchKernelGGL(bn_apply_kernel<false>, bn_ew_grid(a.HW, planes, false), dim3(256), 0, st, a, f);
+}
+static void bn_launch_bwd_apply(const BnArgs& a, hipStream_t st) {
+    const bool vec = bn_vec_ok(a.HW, a.x, a.dy, a.out0, nullptr, nullptr);
+    if (vec) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, bn_ew_grid(a.HW, a.N * a.C, true), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, bn_ew_grid(a.HW, a.N * a.C, false), dim3(256), 0, st, a);
 }
 
 extern "C" size_t ic_bn_workspace_bytes(int C) { return C > 0 ? ((size_t)C * BN_CHUNKS * 2 + 2 * (size_t)C) * sizeof(double) : 0; }
@@ -195,8 +280,8 @@ extern "C" int ic_bn_stats_f32(const float* x, float* mean, float* var, int N, i
     BnArgs a{};
     a.x = x; a.N = N; a.C = C; a.HW = HW; a.partial = (double*)workspace;
     hipStream_t st = (hipStream_t)stream;
-    a.out0 = mean; a.out1 = var;
-    hipLaunchKernelGGL(bn_channel_stats_kernel<0>, dim3(C), dim3(1024), 0, st, a, (double*)nullptr, BnFoldArgs{});
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(BN_SPLIT, C), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(bn_finish_kernel<0>, dim3(ic_cdiv(C, 64)), dim3(64), 0, st, a.partial, C, (long long)N * HW, (double*)nullptr, mean, var, BnFoldArgs{});
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
@@ -209,7 +294,26 @@ extern "C" int ic_bn_train_stats_f32(const float* x, const float* gamma, const f
     a.x = x; a.N = N; a.C = C; a.HW = HW; a.partial = (double*)workspace;
     hipStream_t st = (hipStream_t)stream;
     const BnFoldArgs f{gamma, beta, moving_mean, moving_var, decay, eps, mean, invstd, scale, shift};
-    hipLaunchKernelGGL(bn_channel_stats_kernel<2>, dim3(C), dim3(1024), 0, st, a, (double*)nullptr, f);
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(BN_SPLIT, C), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(bn_finish_kernel<2>, dim3(ic_cdiv(C, 64)), dim3(64), 0, st, a.partial, C, (long long)N * HW, (double*)nullptr, (float*)nullptr, (float*)nullptr, f);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
+// statistics + fold + moving averages + normalise / activate / residual adds of one layer in two launches (the training loop's
+// forward): same values, bit for bit, as ic_bn_train_stats_f32 followed by ic_bn_apply_f32
+extern "C" int ic_bn_train_forward_f32(const float* x, const float* gamma, const float* beta, float* moving_mean, float* moving_var,
+                                       float decay, float eps, float* mean, float* invstd, float* scale, float* shift,
+                                       const float* res1, const float* res2, float* y, int N, int C, int HW, int relu,
+                                       void* workspace, ic_stream_t stream) {
+    IC_CHECK_ARG(x && gamma && beta && mean && invstd && scale && shift && y && workspace && N > 0 && C > 0 && HW > 0);
+    BnArgs a{};
+    a.x = x; a.N = N; a.C = C; a.HW = HW; a.partial = (double*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(BN_SPLIT, C), dim3(1024), 0, st, a);
+    const BnFoldArgs f{gamma, beta, moving_mean, moving_var, decay, eps, mean, invstd, scale, shift};
+    BnApplyArgs ap{x, nullptr, nullptr, res1, res2, y, C, HW, relu, a.partial, (long long)N * HW};
+    bn_launch_apply(ap, f, N * C, st);
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
@@ -225,7 +329,8 @@ extern "C" int ic_bn_moments_f32(const float* x, double* sums, int N, int C, int
     BnArgs a{};
     a.x = x; a.N = N; a.C = C; a.HW = HW; a.partial = (double*)workspace;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_channel_stats_kernel<1>, dim3(C), dim3(1024), 0, st, a, sums, BnFoldArgs{});
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(BN_SPLIT, C), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(bn_finish_kernel<1>, dim3(ic_cdiv(C, 64)), dim3(64), 0, st, a.partial, C, (long long)N * HW, sums, (float*)nullptr, (float*)nullptr, BnFoldArgs{});
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
@@ -255,9 +360,10 @@ extern "C" int ic_bn_backward_reduce_f32(const float* dy, const float* x, const 
     IC_CHECK_ARG(dy && x && scale && shift && mean && invstd && sums && workspace && N > 0 && C > 0 && HW > 0);
     BnArgs a{};
     a.x = x; a.dy = dy; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd;
-    a.N = N; a.C = C; a.HW = HW; a.relu = relu;
+    a.N = N; a.C = C; a.HW = HW; a.relu = relu; a.partial = (double*)workspace;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_channel_bwd_sums_kernel, dim3(C), dim3(1024), 0, st, a, sums, dbeta, dgamma);
+    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(BN_SPLIT, C), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(bn_finish_kernel<1>, dim3(ic_cdiv(C, 64)), dim3(64), 0, st, a.partial, C, (long long)N * HW, sums, dbeta, dgamma, BnFoldArgs{});
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
@@ -269,9 +375,7 @@ extern "C" int ic_bn_backward_apply_f32(const float* dy, const float* x, const f
     BnArgs a{};
     a.x = x; a.dy = dy; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.gamma = gamma;
     a.N = N; a.C = C; a.HW = HW; a.relu = relu; a.sums = sums; a.out0 = dx; a.count = count;
-    const long long total = (long long)N * C * HW;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ic_cdiv(HW, 1024) < 1 ? 1 : ic_cdiv(HW, 1024), N * C), dim3(256), 0,
-                       (hipStream_t)stream, a, total);
+    bn_launch_bwd_apply(a, (hipStream_t)stream);
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
@@ -279,9 +383,8 @@ extern "C" int ic_bn_backward_apply_f32(const float* dy, const float* x, const f
 extern "C" int ic_bn_apply_f32(const float* x, const float* scale, const float* shift, const float* res1,
                                const float* res2, float* y, int N, int C, int HW, int relu, ic_stream_t stream) {
     IC_CHECK_ARG(x && scale && shift && y && N > 0 && C > 0 && HW > 0);
-    const long long total = (long long)N * C * HW;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(ic_cdiv(HW, 1024) < 1 ? 1 : ic_cdiv(HW, 1024), N * C), dim3(256), 0,
-                       (hipStream_t)stream, x, scale, shift, res1, res2, y, C, HW, total, relu);
+    BnApplyArgs ap{x, scale, shift, res1, res2, y, C, HW, relu, nullptr, 0};
+    bn_launch_apply(ap, BnFoldArgs{}, N * C, (hipStream_t)stream);
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
@@ -295,12 +398,10 @@ extern "C" int ic_bn_backward_f32(const float* dy, const float* x, const float* 
     a.x = x; a.dy = dy; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.gamma = gamma;
     a.N = N; a.C = C; a.HW = HW; a.relu = relu;
     a.partial = (double*)workspace;
-    double* sums = a.partial + (size_t)C * BN_CHUNKS * 2;
-    a.sums = sums; a.out0 = dx;
+    a.sums = nullptr; a.sums_out = nullptr; a.dbeta = dbeta; a.dgamma = dgamma; a.out0 = dx;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_channel_bwd_sums_kernel, dim3(C), dim3(1024), 0, st, a, sums, dbeta, dgamma);
-    const long long total = (long long)N * C * HW;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ic_cdiv(HW, 1024) < 1 ? 1 : ic_cdiv(HW, 1024), N * C), dim3(256), 0, st, a, total);
+    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(BN_SPLIT, C), dim3(1024), 0, st, a);
+    bn_launch_bwd_apply(a, st);
     IC_LAUNCH_CHECK();
     return IC_OK;
 }

@@ -24,6 +24,7 @@ struct WnArgs {
     int store_wt;               // NB-segment kernels: 1 = write-through output stores (single-round launches)
     unsigned mg_cols, mg_rows;  // NB-segment kernels: 2^32 / gcols + 1, 2^32 / grows + 1 (0 for a divisor of 1); set by the launcher
     unsigned long long* prof;   // profiling builds (WN_PROF) only
+    const float* wp_next;       // F(4x4) kernel: the NEXT layer's fragments to pull into this XCD's L2 while this layer runs (nullptr: none)
 };
 
 // conv3x3_wino_stack.hip: a whole residual stack (<= WN_STACK_MAX_LAYERS convs on one shape) as one persistent launch.
@@ -62,6 +63,12 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
 }
 #endif
 
+// conv3x3_wino4.hip: ic_wino4_3x3_c128_bn_act_f32 with the next layer's F(4x4) fragments to prefetch (nullptr: none)
+int icx_wino4_3x3_c128_next(const float* x, const float* w_packed, const float* scale, const float* shift, const float* res1, const float* res2,
+                            float* y, int N, int H, int W, int relu, int flags, const float* w_packed_next, hipStream_t st);
+// conv3x3_wino.hip: ic_conv3x3_c128_auto_f32 with the next layer's `both` blob (nullptr: none)
+int icx_conv3x3_c128_auto_next(const float* x, const float* w_both, const float* scale, const float* shift, const float* res1, const float* res2,
+                               float* y, int N, int H, int W, int relu, int flags, const float* w_both_next, hipStream_t st);
 // conv3x3_wino_tn.hip: launches the NB-segment kernel over tile groups [a.g0, a.g0 + a.ngroups); nb in {1, 2, 3}
 int icx_wino_tn_launch(const WnArgs& a, int nb, int scalar_transform, hipStream_t st);
 // conv3x3_wino_tp.hip: tile-pair / position-split jobs over tile groups [a.g0, a.g0 + a.ngroups), two work-groups per CU

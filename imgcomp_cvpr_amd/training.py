@@ -32,6 +32,7 @@ critical path.  sync_bn=True / None: an RCCL all-reduce each; sync_bn='p2p': one
 replication of the TF graph: no exchange at all, but 8 x 4 crops are then not the reference's 32).
 """
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -207,15 +208,21 @@ class TrainGraph(object):
         # 32 x 32 31.8 against 40.3 us, 30 of 40 x 40 68 against 95) and where at least half of the segments' tiles exist
         wgs = int(lib.ic_wino4_3x3_c128_workgroups(N, H, W))
         tiles = N * (-(-H // 4)) * (-(-W // 4))
-        self._w3_f4 = bool(self.WINO4) and wgs >= 160 and 2 * tiles >= 8 * wgs
-        if self._w3_f4 not in self._w3_bufs:
-            n_pk = lib.ic_wino4_3x3_c128_packed_floats() if self._w3_f4 else lib.ic_wino3x3_c128_packed_floats()
-            self._w3_bufs[self._w3_f4] = self._new(2, len(self._w3_names), n_pk)
-        buf = self._w3_bufs[self._w3_f4]
-        pack = lib.ic_pack_wino4_3x3_c128_batch_f32 if self._w3_f4 else lib.ic_pack_wino3x3_c128_batch_f32
+        fits = wgs >= 160 and 2 * tiles >= 8 * wgs
+        mode = self.WINO4
+        # per direction: (forward, data gradient) -- WINO4 True: both, 'fwd' / 'bwd': one of them (A/B runs and the parity report)
+        self._w3_f4 = (fits and mode in (True, 'fwd'), fits and mode in (True, 'bwd'))
+        bufs = []
         for b in (0, 1):
-            check(pack(ptr(self._w3_table), ptr(buf[b]), len(self._w3_names), b, self._st()), 'batched winograd pack')
-        self._wino_pk = buf
+            f4 = self._w3_f4[b]
+            if (b, f4) not in self._w3_bufs:
+                n_pk = lib.ic_wino4_3x3_c128_packed_floats() if f4 else lib.ic_wino3x3_c128_packed_floats()
+                self._w3_bufs[(b, f4)] = self._new(len(self._w3_names), n_pk)
+            buf = self._w3_bufs[(b, f4)]
+            pack = lib.ic_pack_wino4_3x3_c128_batch_f32 if f4 else lib.ic_pack_wino3x3_c128_batch_f32
+            check(pack(ptr(self._w3_table), ptr(buf), len(self._w3_names), b, self._st()), 'batched winograd pack')
+            bufs.append(buf)
+        self._wino_pk = bufs
 
     def _conv3x3(self, x, name, backward=False, res1=None, res2=None):
         """raw 3x3 128->128 conv (backward: its adjoint = the data gradient), + res1 + res2 in the kernel's epilogue (the skip
@@ -227,8 +234,8 @@ class TrainGraph(object):
         w_tf = self.params[name] if isinstance(name, str) else name
         if lib.ic_conv3x3_c128_pick_algo(N, H, W, 0) == 1:
             if isinstance(name, str) and getattr(self, '_wino_pk', None) is not None:
-                wp = self._wino_pk[int(backward), self._w3_index[name]]
-                if self._w3_f4:
+                wp = self._wino_pk[int(backward)][self._w3_index[name]]
+                if self._w3_f4[int(backward)]:
                     # Winograd F(4x4,3x3) (csrc/conv3x3_wino4.hip; 2 x 8-tile segments on the crops' small maps): same contract
                     check(lib.ic_wino4_3x3_c128_bn_act_f32(ptr(x), ptr(wp), ptr(self.ones), ptr(self.zeros), ptr(res1), ptr(res2), ptr(y),
                                                            N, H, W, 0, 0, st), 'conv3x3 (winograd F(4x4))')
@@ -386,12 +393,14 @@ class TrainGraph(object):
         mean, invstd, scale, shift = stats[0], stats[1], stats[2], stats[3]
         P = self.params
         world = self._bn_world()
+        y = self._new(N, Cc, H, W)
         if world == 1:
-            # batch statistics, folded scale/shift and the moving-average update (decay 0.9) in one call
-            check(lib.ic_bn_train_stats_f32(ptr(raw), ptr(P[scope + '/BatchNorm/gamma']), ptr(P[scope + '/BatchNorm/beta']),
-                                            ptr(P[scope + '/BatchNorm/moving_mean']), ptr(P[scope + '/BatchNorm/moving_variance']),
-                                            BN_DECAY, BN_EPS, ptr(mean), ptr(invstd), ptr(scale), ptr(shift), N, Cc, H * W,
-                                            ptr(self.bn_ws), self._st()), 'bn statistics')
+            # batch statistics, folded scale / shift, the moving-average update (decay 0.9) and the normalised, activated output
+            # (+ the residual adds) in one call of two launches
+            check(lib.ic_bn_train_forward_f32(ptr(raw), ptr(P[scope + '/BatchNorm/gamma']), ptr(P[scope + '/BatchNorm/beta']),
+                                              ptr(P[scope + '/BatchNorm/moving_mean']), ptr(P[scope + '/BatchNorm/moving_variance']),
+                                              BN_DECAY, BN_EPS, ptr(mean), ptr(invstd), ptr(scale), ptr(shift), ptr(res1), ptr(res2),
+                                              ptr(y), N, Cc, H * W, int(relu), ptr(self.bn_ws), self._st()), 'bn forward')
         else:
             # cross-replica statistics: this rank's float64 moments, summed over the ranks, folded over the global count
             sums = torch.empty(2 * Cc, dtype=torch.float64, device=self.dev)
@@ -401,9 +410,8 @@ class TrainGraph(object):
                                                    ptr(P[scope + '/BatchNorm/beta']), ptr(P[scope + '/BatchNorm/moving_mean']),
                                                    ptr(P[scope + '/BatchNorm/moving_variance']), BN_DECAY, BN_EPS, ptr(mean),
                                                    ptr(invstd), ptr(scale), ptr(shift), Cc, self._st()), 'bn fold')
-        y = self._new(N, Cc, H, W)
-        check(lib.ic_bn_apply_f32(ptr(raw), ptr(scale), ptr(shift), ptr(res1), ptr(res2), ptr(y), N, Cc, H * W,
-                                  int(relu), self._st()))
+            check(lib.ic_bn_apply_f32(ptr(raw), ptr(scale), ptr(shift), ptr(res1), ptr(res2), ptr(y), N, Cc, H * W,
+                                      int(relu), self._st()))
         if tape is not None:
             tape.append((l, x, raw, mean, invstd, scale, shift, relu))
         return y
@@ -660,12 +668,18 @@ class TrainGraph(object):
     # HIP_LOSS: the MS-SSIM distortion and its gradient from csrc/msssim.hip (one launch per scale and direction) instead of the
     # ~300 torch kernels of ms_ssim.py -- no graph, no static buffers, any shape with five scales.  False: torch, eagerly.
     HIP_LOSS = True
-    # WINO4: forward and data-gradient 3x3 convolutions in Winograd F(4x4,3x3) form (2 x 8-tile segments on the crops' small maps;
-    # filter gradients stay in the F(2x2) domain, conv3x3_wgrad_wino.hip).  OFF: measured in round 4 on the cfg3 step -- 16.31 against
-    # 16.10 ms (a launch is 31.8 against 40.3 us in a loop over one layer, tools/w4sweep.py, but here every launch brings 2.36 MB of
-    # freshly packed fragments and 256 work-groups leave one wave per SIMD to wait for them), and the gradients through 35 layers
-    # leave the cfg3 bounds (test_cfg3_training_step_full_size).  Kept as a switch for A/B runs.
-    WINO4 = False
+    # WINO4: which 3x3 convolutions of the step run in Winograd F(4x4,3x3) form (2 x 8-tile segments on the crops' small maps; filter
+    # gradients stay in the F(2x2) domain, conv3x3_wgrad_wino.hip): False / 'fwd' / 'bwd' / True (both).  Round 5, cfg3 step on the
+    # MI355X (tools/train_f4_report.py: forward_backward ms; gradient error against float64 autograd, relative to the tensor scale):
+    #     False 16.17 ms   'bwd' 15.77 ms   'fwd' 15.90 ms   True 15.36 ms
+    #   'bwd' leaves every one of the 219 gradients where F(2x2) has it (worst 1.405e-2 either way, the tensors the cfg3 test checks
+    #   agree to three digits): the data gradient meets each layer once, behind a BatchNorm backward that re-centres it.
+    #   'fwd' / True move z from 7.1e-6 to 3.6e-5 (still inside 1e-4) and multiply the checked gradients' errors by 1.1 - 4.5:
+    #   enc_2_2/conv1/weights 9.7e-4 -> 4.3e-3 (test bound 3e-3), h12/weights 9.6e-4 -> 2.8e-3, to_bn/weights 4.5e-4 -> 1.5e-3.
+    #   The forward error is what every later layer's gradient is evaluated at, 35 layers deep.
+    # So: 'bwd' by default; the forward stays F(2x2) and the cfg3 parity bounds stay where they were.  The forward numbers are in the
+    # parity report under their own labels (tests/test_gpu_configs.py::test_cfg3_training_step_f4_forward_is_reported).
+    WINO4 = {'0': False, '': False, '1': True, 'fwd': 'fwd', 'bwd': 'bwd'}[os.environ.get('IMGCOMP_TRAIN_WINO4', 'bwd')]
 
     def _hip_distortion(self, x):
         """the HIP distortion of this input shape, or None when MS-SSIM is undefined for it (fewer than five scales)"""

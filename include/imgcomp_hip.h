@@ -326,6 +326,13 @@ int ic_ae_res_stack_f32(const float* x, const void* const* tab_host, int B, floa
 int ic_bn_train_stats_f32(const float* x, const float* gamma, const float* beta, float* moving_mean,
                           float* moving_var, float decay, float eps, float* mean, float* invstd, float* scale,
                           float* shift, int N, int C, int HW, void* workspace, ic_stream_t stream);
+/* One layer's training-mode BatchNorm forward (slim.batch_norm is_training=True, autoencoder.py:106-125) in two launches:
+ * ic_bn_train_stats_f32 followed by ic_bn_apply_f32 (y = act(x * scale + shift) + res1 + res2), bit for bit -- the element-wise
+ * kernel folds the statistics from the partial sums itself instead of waiting for a fold kernel. */
+int ic_bn_train_forward_f32(const float* x, const float* gamma, const float* beta, float* moving_mean, float* moving_var,
+                            float decay, float eps, float* mean, float* invstd, float* scale, float* shift,
+                            const float* res1, const float* res2, float* y, int N, int C, int HW, int relu,
+                            void* workspace, ic_stream_t stream);
 
 /* =============================================================================================
  * Training (train.py:101-106, :303-349): training-mode BatchNorm, backward kernels.

@@ -168,7 +168,8 @@ def test_conv3x3_plan_queries_are_host_logic():
     assert wg(1, 128, 192) == 192 and wg(8, 128, 192) == 1536 and wg(1, 540, 960) == 4050
     assert wg(32, 32, 32) == 256 and wg(1, 32, 32) == 8            # 8 x 8 tiles: 2 x 8-tile segments (1 x 16 would need 16)
     assert wg(1, 128, 190) == 0 and pf(1, 128, 190, 0) == 1        # W % 4 != 0: F(2x2)
-    assert pf(1, 128, 192, 0) == 1 and pf(1, 128, 192, L.CONV3_IN_FLIGHT(4)) == 2 and pf(8, 128, 192, 0) == 2
+    assert pf(1, 128, 192, 0) == 2 and pf(1, 128, 192, L.CONV3_IN_FLIGHT(4)) == 2 and pf(8, 128, 192, 0) == 2      # a Kodak map: 192 work-groups
+    assert pf(1, 128, 128, 0) == 1 and pf(1, 128, 128, L.CONV3_IN_FLIGHT(4)) == 2 and pf(1, 64, 64, L.CONV3_IN_FLIGHT(4)) == 1  # 128 / 32 work-groups
     assert pf(8, 128, 192, L.CONV3_NO_WINO4) == 1 and pf(8, 128, 192, L.CONV3_DIRECT) == 0 and pf(1, 4096, 2048, 0) == 0
     assert pf(30, 40, 40, 0) == 2 and pf(200, 12, 12, 0) == 1      # 62 % / 28 % of the segments' tiles exist
     assert L.lib.ic_wino4_conv5s2_supported(1, 128, 192) == 1 and L.lib.ic_wino4_conv5s2_supported(1, 128, 190) == 0

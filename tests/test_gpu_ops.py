@@ -449,11 +449,10 @@ def test_conv3x3_c128_auto_selection(cuda):
     wp = torch.empty(L.lib.ic_conv3x3_c128_both_packed_floats(), device=cuda)
     L.check(L.lib.ic_pack_conv3x3_c128_both_f32(L.ptr(wd), L.ptr(wp), 0, L.current_stream()))
     ref = _ref_conv(x, w, scale, shift, 1, 1)
-    # which of the three kernels: F(4x4) where two of its work-groups per CU are resident (alone from 512 of them, with the launches
-    # in flight beside it from 384 together) and the map fills its 16-tile segments; F(2x2) otherwise, and always against an
-    # explicit F(2x2) form or IC_CONV3_NO_WINO4
+    # which of the three kernels: F(4x4) from 160 work-groups (a Kodak map has 192), with launches in flight beside it from 384
+    # together, where the map fills its 16-tile segments; F(2x2) otherwise, and always against an explicit F(2x2) form or IC_CONV3_NO_WINO4
     pf = L.lib.ic_conv3x3_c128_pick_form
-    assert pf(1, 128, 192, 0) == 1 and pf(8, 128, 192, 0) == 2 and pf(1, 512, 512, 0) == 2
+    assert pf(1, 128, 192, 0) == 2 and pf(1, 128, 128, 0) == 1 and pf(8, 128, 192, 0) == 2 and pf(1, 512, 512, 0) == 2
     assert pf(1, 128, 192, L.CONV3_IN_FLIGHT(6)) == 2 and pf(1, 32, 32, L.CONV3_IN_FLIGHT(6)) == 1
     assert pf(200, 12, 12, 0) == 1 and pf(30, 40, 40, 0) == 2              # 800 work-groups 28 % full; 600 work-groups 62 % full
     assert pf(8, 128, 192, L.CONV3_NO_WINO4) == 1 and pf(8, 128, 192, L.CONV3_WINO) == 2 and pf(8, 128, 190, 0) == 1

@@ -140,16 +140,46 @@ cfg = line.get('config', {})
 # steps / that span.  A kernel's share of the chip's time per launch is avg_us / concurrency.
 # (steady state only: the window from the middle 3x3 launch of the run to the last one -- the first steps load code objects)
 k3s = sorted(t for t in all_k if t[2].startswith(('wino3x3', 'wino4_3x3_kernel<128, 128>', 'conv3x3_c128')))
-span_us = in_span = 0.0
+span_us = in_span = union_us = 0.0
+steps_in_window = 0.0
+k3_in_window_us = k3_in_window_n = 0
 if len(k3s) >= 4:
     w0, w1 = k3s[len(k3s) // 2][0], max(t[1] for t in k3s)
     span_us = (w1 - w0) / 1e3
-    in_span = sum((min(e, w1) - max(b, w0)) / 1e3 for b, e, k in all_k if e > w0 and b < w1 and 'copyBuffer' not in k)
+    inside = [(max(b, w0), min(e, w1), k) for b, e, k in all_k if e > w0 and b < w1 and 'copyBuffer' not in k]
+    in_span = sum((e - b) / 1e3 for b, e, k in inside)
+    # time with at least one kernel running (union of the intervals): span - union = the window's idle time
+    cur_b = cur_e = None
+    for b, e, k in sorted(inside):
+        if cur_e is None or b > cur_e:
+            if cur_e is not None:
+                union_us += (cur_e - cur_b) / 1e3
+            cur_b, cur_e = b, e
+        else:
+            cur_e = max(cur_e, e)
+    if cur_e is not None:
+        union_us += (cur_e - cur_b) / 1e3
+    per_step_3x3 = len(k3s) / float(steps)                      # 3x3 launches per step (64 for the cvpr networks)
+    in_w = [t for t in k3s if t[0] >= w0]
+    k3_in_window_n = len(in_w)
+    k3_in_window_us = sum((e - b) / 1e3 for b, e, k in in_w)
+    steps_in_window = k3_in_window_n / per_step_3x3
 concurrency = in_span / span_us if span_us > 0 else 1.0
 out = {'source': 'profiles/{}_counters.txt: rocprofv3 --kernel-trace and --pmc passes over `python bench.py --steps 20 --warmup 5 --no_extras '
                  '--calib_copy` (tools/profile_round.sh), one counter group per pass'.format(tag),
        'input_shape': [cfg.get('batch_per_gpu'), 3, cfg.get('height'), cfg.get('width')], 'branch_sharing': line.get('branch_sharing'),
        'steps_profiled': steps, 'value_under_rocprof': line.get('value'), 'images_in_flight': line.get('images_in_flight'),
+       # the WINDOW every figure below refers to: from the middle 3x3 launch of the trace to the end of the last one (steady state;
+       # the first steps load code objects).  Round 4's file put the window's sums next to the count of ALL steps; now each sum
+       # has the number of steps it covers beside it, and the identities hold:
+       #   concurrency = sum_of_kernel_durations_us / span_of_the_window_us
+       #   sum_of_kernel_durations_us / steps_in_window = kernel time per step (3x3 part: launches_per_step x avg_us_in_flight)
+       'window': {'steps_in_window': round(steps_in_window, 2), 'span_of_the_window_us': round(span_us, 1),
+                  'sum_of_kernel_durations_us': round(in_span, 1), 'union_busy_us': round(union_us, 1),
+                  'kernel_us_per_step': round(in_span / steps_in_window, 1) if steps_in_window else None,
+                  'wall_us_per_step': round(span_us / steps_in_window, 1) if steps_in_window else None,
+                  'launches_3x3_in_window': k3_in_window_n,
+                  'avg_us_3x3_in_window': round(k3_in_window_us / k3_in_window_n, 2) if k3_in_window_n else None},
        'span_of_the_steps_us': round(span_us, 1), 'sum_of_kernel_durations_us': round(in_span, 1), 'concurrency': round(concurrency, 3),
        'kernels': {}}
 groups = {}
