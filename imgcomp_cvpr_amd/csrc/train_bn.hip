@@ -170,17 +170,22 @@ __global__ __launch_bounds__(64) void bn_finish_kernel(const double* __restrict_
     }
 }
 
-// ---- element-wise halves: grid (plane chunks, N*C planes): one (n, c) plane per blockIdx.y -> channel constants are block-uniform;
-// VEC: 16-byte accesses (HW % 4 == 0 and 16-byte aligned planes) ----
+// ---- element-wise halves: grid (plane chunks, C x image groups); a work-group serves BN_PL images of ONE channel (channel constants
+// are block-uniform).  VEC (HW % 4 == 0, 16-byte aligned tensors): 16-byte accesses.  Measured on the cfg3 layer (32 x 128 x 32 x 32,
+// 33.5 MB in + out, rocprofv3): scalar, one plane 8.5 us; 16-byte, one plane 8.9; 16-byte, 8 planes per work-group 10.3 -- all of them
+// ~3.7 TB/s of read + write, which is what a device copy reaches on this chip: these passes are at the memory system's rate and only
+// removing a pass (fusing the apply into the consumer's load) would make the layer's BatchNorm cheaper.  One plane per work-group. ----
+#define BN_PL 1
 struct BnApplyArgs {
     const float* x; const float* scale; const float* shift; const float* res1; const float* res2; float* y;
-    int C, HW, relu;
+    int N, C, HW, relu;
     const double* partial;    // != nullptr: scale / shift are OUTPUTS -- folded here from the partial sums (BnFoldArgs f, count M)
     long long M;
 };
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a, const BnFoldArgs f) {
     const int c = blockIdx.y % a.C;
+    const int n_first = VEC ? (int)(blockIdx.y / a.C) * BN_PL : (int)(blockIdx.y / a.C);      // (grid.y = C x image groups)
     float sc, sh;
     if (a.partial) {
         double s0, s1;
@@ -188,23 +193,32 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a, cons
         float mf, vf, is;
         bn_fold_values(s0, s1, a.M, f.gamma[c], f.beta[c], f.eps, mf, vf, is, sc, sh);
         // plane (n = 0, c), first chunk, first thread: the channel's statistics and moving averages, once
-        if ((int)blockIdx.y == c && blockIdx.x == 0 && threadIdx.x == 0)
+        if (n_first == 0 && blockIdx.x == 0 && threadIdx.x == 0)
             bn_fold_channel(c, s0, s1, a.M, f.gamma, f.beta, f.moving_mean, f.moving_var, f.decay, f.eps, f.mean, f.invstd, f.scale, f.shift);
     } else { sc = a.scale[c]; sh = a.shift[c]; }
-    const size_t base = (size_t)blockIdx.y * a.HW;
+    const size_t base = ((size_t)n_first * a.C + c) * a.HW;
     if (VEC) {
         const int HW4 = a.HW >> 2;
+        const size_t img4 = (size_t)a.C * HW4;                  // float4s from an image's plane to the next image's
+        const int npl = a.N - n_first < BN_PL ? a.N - n_first : BN_PL;
         const float4* x4 = reinterpret_cast<const float4*>(a.x + base);
         const float4* r1 = a.res1 ? reinterpret_cast<const float4*>(a.res1 + base) : nullptr;
         const float4* r2 = a.res2 ? reinterpret_cast<const float4*>(a.res2 + base) : nullptr;
         float4* y4 = reinterpret_cast<float4*>(a.y + base);
         for (int p = blockIdx.x * 256 + threadIdx.x; p < HW4; p += gridDim.x * 256) {
-            float4 v = x4[p];
-            v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
-            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (r1) { const float4 r = r1[p]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-            if (r2) { const float4 r = r2[p]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-            y4[p] = v;
+            float4 v[BN_PL];
+#pragma unroll
+            for (int j = 0; j < BN_PL; ++j) v[j] = j < npl ? x4[j * img4 + p] : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < BN_PL; ++j) {
+                if (j >= npl) break;
+                float4 w = v[j];
+                w.x = fmaf(w.x, sc, sh); w.y = fmaf(w.y, sc, sh); w.z = fmaf(w.z, sc, sh); w.w = fmaf(w.w, sc, sh);
+                if (a.relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+                if (r1) { const float4 r = r1[j * img4 + p]; w.x += r.x; w.y += r.y; w.z += r.z; w.w += r.w; }
+                if (r2) { const float4 r = r2[j * img4 + p]; w.x += r.x; w.y += r.y; w.z += r.z; w.w += r.w; }
+                y4[j * img4 + p] = w;
+            }
         }
     } else {
         for (int p = blockIdx.x * 256 + threadIdx.x; p < a.HW; p += gridDim.x * 256) {
@@ -221,31 +235,40 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs a) {
     const double M = a.count > 0 ? (double)a.count : (double)a.N * a.HW;
     const int c = blockIdx.y % a.C;
+    const int n_first = VEC ? (int)(blockIdx.y / a.C) * BN_PL : (int)(blockIdx.y / a.C);      // (grid.y = C x image groups)
     const float sc = a.scale[c], sh = a.shift[c], mu = a.mean[c], is = a.invstd[c];
     double t0, t1;
     if (a.sums) { t0 = a.sums[c]; t1 = a.sums[a.C + c]; }
     else {
         bn_totals(a.partial, c, t0, t1);
-        if ((int)blockIdx.y == c && blockIdx.x == 0 && threadIdx.x == 0) {
+        if (n_first == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
             if (a.sums_out) { a.sums_out[c] = t0; a.sums_out[a.C + c] = t1; }
             if (a.dbeta) a.dbeta[c] = (float)t0;
             if (a.dgamma) a.dgamma[c] = (float)t1;
         }
     }
     const float k = a.gamma[c] * is, mg = (float)(t0 / M), mgx = (float)(t1 / M);
-    const size_t base = (size_t)blockIdx.y * a.HW;
+    const size_t base = ((size_t)n_first * a.C + c) * a.HW;
     auto one = [&](float xv, float g) __attribute__((always_inline)) -> float {
         if (a.relu && !(fmaf(xv, sc, sh) > 0.f)) g = 0.f;
         return k * (g - mg - (xv - mu) * is * mgx);
     };
     if (VEC) {
         const int HW4 = a.HW >> 2;
+        const size_t img4 = (size_t)a.C * HW4;
+        const int npl = a.N - n_first < BN_PL ? a.N - n_first : BN_PL;
         const float4* x4 = reinterpret_cast<const float4*>(a.x + base);
         const float4* g4 = reinterpret_cast<const float4*>(a.dy + base);
         float4* o4 = reinterpret_cast<float4*>(a.out0 + base);
         for (int p = blockIdx.x * 256 + threadIdx.x; p < HW4; p += gridDim.x * 256) {
-            const float4 xv = x4[p], g = g4[p];
-            o4[p] = float4{one(xv.x, g.x), one(xv.y, g.y), one(xv.z, g.z), one(xv.w, g.w)};
+            float4 xv[BN_PL], g[BN_PL];
+#pragma unroll
+            for (int j = 0; j < BN_PL; ++j) { xv[j] = j < npl ? x4[j * img4 + p] : float4{0.f, 0.f, 0.f, 0.f}; g[j] = j < npl ? g4[j * img4 + p] : float4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int j = 0; j < BN_PL; ++j) {
+                if (j >= npl) break;
+                o4[j * img4 + p] = float4{one(xv[j].x, g[j].x), one(xv[j].y, g[j].y), one(xv[j].z, g[j].z), one(xv[j].w, g[j].w)};
+            }
         }
     } else {
         for (int p = blockIdx.x * 256 + threadIdx.x; p < a.HW; p += gridDim.x * 256) a.out0[base + p] = one(a.x[base + p], a.dy[base + p]);
@@ -256,20 +279,19 @@ static inline bool bn_vec_ok(int HW, const void* p0, const void* p1, const void*
     auto al = [](const void* p) { return p == nullptr || ((uintptr_t)p & 15) == 0; };
     return (HW & 3) == 0 && al(p0) && al(p1) && al(p2) && al(p3) && al(p4);
 }
-static inline dim3 bn_ew_grid(int HW, int planes, bool vec) {
-    const int per = vec ? 1024 : 1024;            // elements per work-group of 256 threads: one float4 or four floats per thread
-    int gx = ic_cdiv(HW, per);
-    return dim3(gx < 1 ? 1 : gx, planes);
+static inline dim3 bn_ew_grid(int HW, int N, int C, bool vec) {
+    int gx = ic_cdiv(HW, 1024);                   // elements of a plane per work-group of 256 threads: one float4 or four floats per thread
+    return dim3(gx < 1 ? 1 : gx, vec ? C * ic_cdiv(N, BN_PL) : N * C);
 }
-static void bn_launch_apply(const BnApplyArgs& a, const BnFoldArgs& f, int planes, hipStream_t st) {
+static void bn_launch_apply(const BnApplyArgs& a, const BnFoldArgs& f, int N, hipStream_t st) {
     const bool vec = bn_vec_ok(a.HW, a.x, a.res1, a.res2, a.y, nullptr);
-    if (vec) hipLaunchKernelGGL(bn_apply_kernel<true>, bn_ew_grid(a.HW, planes, true), dim3(256), 0, st, a, f);
-    else hipLaunchKernelGGL(bn_apply_kernel<false>, bn_ew_grid(a.HW, planes, false), dim3(256), 0, st, a, f);
+    if (vec) hipLaunchKernelGGL(bn_apply_kernel<true>, bn_ew_grid(a.HW, N, a.C, true), dim3(256), 0, st, a, f);
+    else hipLaunchKernelGGL(bn_apply_kernel<false>, bn_ew_grid(a.HW, N, a.C, false), dim3(256), 0, st, a, f);
 }
 static void bn_launch_bwd_apply(const BnArgs& a, hipStream_t st) {
     const bool vec = bn_vec_ok(a.HW, a.x, a.dy, a.out0, nullptr, nullptr);
-    if (vec) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, bn_ew_grid(a.HW, a.N * a.C, true), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, bn_ew_grid(a.HW, a.N * a.C, false), dim3(256), 0, st, a);
+    if (vec) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, bn_ew_grid(a.HW, a.N, a.C, true), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, bn_ew_grid(a.HW, a.N, a.C, false), dim3(256), 0, st, a);
 }
 
 extern "C" size_t ic_bn_workspace_bytes(int C) { return C > 0 ? ((size_t)C * BN_CHUNKS * 2 + 2 * (size_t)C) * sizeof(double) : 0; }
@@ -312,8 +334,8 @@ extern "C" int ic_bn_train_forward_f32(const float* x, const float* gamma, const
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(BN_SPLIT, C), dim3(1024), 0, st, a);
     const BnFoldArgs f{gamma, beta, moving_mean, moving_var, decay, eps, mean, invstd, scale, shift};
-    BnApplyArgs ap{x, nullptr, nullptr, res1, res2, y, C, HW, relu, a.partial, (long long)N * HW};
-    bn_launch_apply(ap, f, N * C, st);
+    BnApplyArgs ap{x, nullptr, nullptr, res1, res2, y, N, C, HW, relu, a.partial, (long long)N * HW};
+    bn_launch_apply(ap, f, N, st);
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
@@ -383,8 +405,8 @@ extern "C" int ic_bn_backward_apply_f32(const float* dy, const float* x, const f
 extern "C" int ic_bn_apply_f32(const float* x, const float* scale, const float* shift, const float* res1,
                                const float* res2, float* y, int N, int C, int HW, int relu, ic_stream_t stream) {
     IC_CHECK_ARG(x && scale && shift && y && N > 0 && C > 0 && HW > 0);
-    BnApplyArgs ap{x, scale, shift, res1, res2, y, C, HW, relu, nullptr, 0};
-    bn_launch_apply(ap, BnFoldArgs{}, N * C, (hipStream_t)stream);
+    BnApplyArgs ap{x, scale, shift, res1, res2, y, N, C, HW, relu, nullptr, 0};
+    bn_launch_apply(ap, BnFoldArgs{}, N, (hipStream_t)stream);
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
