@@ -79,6 +79,11 @@
 #ifndef W4_WT_MAX
 #define W4_WT_MAX 512                                // launches of at most this many work-groups (a single round) store write-through
 #endif
+#ifndef W4_SOFT
+#define W4_SOFT 0                                   // 1: two barriers per iteration between MFMA quads (B1 / B2 below); 0: one at its end (measured equal: below)
+#endif
+#define W4_B1 29
+#define W4_B2 8
 #ifndef W4_SPREAD
 #define W4_SPREAD 1                                 // 1: the transform of a turn is cut into 26 pieces of 6 vector instructions, two per
 #endif                                              //    quad, each behind an MFMA (whose 8 passes hide them); 0: one block of ~200
@@ -194,6 +199,12 @@ __device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, fl
     y3 = fmaf(8.f, d2, d1) + m5;
 }
 
+// (Round 5, for launches alone on the chip with one work-group per CU -- a Kodak map one image at a time --: a second build for ONE wave
+// per SIMD and 512 registers, all 36 accumulators in AGPRs, filter ring 18 quads, B ring 6.  Audit clean, correct, and no faster:
+// one image at a time 168.9 against 169.3 Mpix/s at 512 x 768, 201.5 against 201.9 at 640 x 768.  The 6 -> 9 step of the ring had
+// bought 18 % there; beyond 9 a lone wave's loop -- 53.1 k clocks for 36.9 k of MFMA issue, tools/w4prof.py -- is no longer waiting for
+// filter fragments.  What is left per iteration of 4608 MFMA clocks: the barrier and the restart of the B-operand reads behind it,
+// 8 times per work-group.  Removed.)
 // (Also built and measured in round 4 for launches that are alone on the chip -- one Kodak map, 192 work-groups, one wave per SIMD --:
 // an 8-wave K-split work-group, waves 0..3 the first half of the k-steps, waves 4..7 the second, two rings, the partial sums
 // exchanged through LDS and each group finishing two of a lane's four channels.  Correct, and slower: 37.4 against 29.2 us per
@@ -447,10 +458,25 @@ void wino4_3x3_kernel(const WnArgs a) {
     // fragments W4_RA - 1 quads ahead into the ring slot the PREVIOUS quad consumed, then the B operands W4_RB - 1 quads ahead into the
     // slot the previous quad consumed: a register is overwritten by a load issued at least 4 MFMAs after its last reader.
     // `last`: the eighth iteration has no next k-steps to prepare; the epilogue's first operands are requested in its place.
-    auto iteration = [&](const int j, const int u2, const bool last) __attribute__((always_inline)) {      // reads ring half u2
-        f32x4 bq[W4_RB];
+    // Barriers (W4_SOFT, round 5): the ring's two hazards have 11 and 13 quads of slack, so neither needs the pipeline to stop.
+    //   RAW  the other half is complete once every wave is past its last slice (quad 23): barrier B1 behind quad W4_B1 = 29; the B
+    //        operands of the next iteration's first quads are then requested from quad 34 on, like any others, W4_RB - 1 ahead;
+    //   WAR  the other half may be overwritten (first ring write of an iteration: quad 18; 11 with W4_SPREAD 0) once every wave has
+    //        consumed its last operands of the previous iteration: barrier B2 behind quad W4_B2 = 8 of iterations 1 .. IT - 2.
+    // Both sit between MFMA quads whose operands are already in registers, where the form of rounds 4 (W4_SOFT 0) ends every iteration
+    // with `s_waitcnt lgkmcnt(0); s_barrier` and re-starts the B-operand reads behind it.  Built, tested (same values) and measured in
+    // round 5 -- and it changes nothing: bench 282.3 / 281.8 / 281.3 against 283.0 / 281.9 / 281.6 Mpix/s, one image at a time 170.0
+    // against 170.1, 8 Kodak maps 179.0 against 179.0 us.  The barrier is not where a wave's loop loses its 53 k - 37 k clocks; a lone
+    // wave issues in order, and the dependent chains of its transform slices (6 vector instructions behind an MFMA, 4-8 clocks each)
+    // take about the MFMA's own 32.  Kept as a switch, off.
+    f32x4 bq[W4_RB];
 #pragma unroll
-        for (int q0 = 0; q0 < W4_RB - 1; ++q0) bq[q0] = ring[((u2 * 4 + 0) * W4_QUADS + q0) * 64 + lane];
+    for (int q0 = 0; q0 < W4_RB - 1; ++q0) bq[q0] = ring[((0 * 4 + 0) * W4_QUADS + q0) * 64 + lane];
+    auto iteration = [&](const int j, const int u2, const bool last) __attribute__((always_inline)) {      // reads ring half u2
+        if (!W4_SOFT && j > 0) {
+#pragma unroll
+            for (int q0 = 0; q0 < W4_RB - 1; ++q0) bq[q0] = ring[((u2 * 4 + 0) * W4_QUADS + q0) * 64 + lane];
+        }
 #pragma unroll
         for (int lq = 0; lq < 36; ++lq) {                         // quad of the iteration: k-step lq / 9, positions 4 (lq % 9) ..
             const int q = lq % W4_QUADS;
@@ -467,17 +493,27 @@ void wino4_3x3_kernel(const WnArgs a) {
                 }
             }
             if (!last || lq + W4_RA - 1 < 36) load_filter((lq + W4_RA - 1) % W4_RA, Q + W4_RA - 1);      // 36 % W4_RA == 0: the slot depends on lq only
-            if (lq + W4_RB - 1 < 36)
-                bq[(lq + W4_RB - 1) % W4_RB] = ring[((u2 * 4 + (lq + W4_RB - 1) / W4_QUADS) * W4_QUADS + (lq + W4_RB - 1) % W4_QUADS) * 64 + lane];
+            {
+                const int ah = lq + W4_RB - 1;                    // the quad whose B operands are requested now
+                if (ah < 36) bq[ah % W4_RB] = ring[((u2 * 4 + ah / W4_QUADS) * W4_QUADS + ah % W4_QUADS) * 64 + lane];
+                else if (W4_SOFT && !last) bq[ah % W4_RB] = ring[(((u2 ^ 1) * 4 + 0) * W4_QUADS + (ah - 36)) * 64 + lane];   // behind B1
+            }
             // the wave's own k-step of the NEXT iteration: requested, then from W4_GAP quads later on transformed and written into
             // the other half (W4_SPREAD: in 13 slices behind MFMAs; else as one block)
             if (lq == W4_TURN && !last) load_patch(4 * (j + 1) + pw);
             if (!W4_SPREAD && lq == W4_TURN + W4_GAP && !last) transform_put(u2 ^ 1);
             if (last && lq == W4_PRE) request_first(0, W4_PRE_N);
+            if (W4_SOFT && !last && lq == W4_B1) {                // the other half is complete (own ring writes landed: LDS works in order)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (W4_SOFT && !last && lq == W4_B2 && j > 0) __builtin_amdgcn_s_barrier();      // the other half has been read by everybody
             __builtin_amdgcn_sched_barrier(0);                    // quads stay in program order: the rings are sized for exactly that
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                             // next half complete, this half read by everybody
+        if (!W4_SOFT) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                         // next half complete, this half read by everybody
+        }
     };
     for (int jj = 0; jj < IT - 2; jj += 2) {
         iteration(jj, 0, false);
