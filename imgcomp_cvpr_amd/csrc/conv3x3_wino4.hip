@@ -79,6 +79,10 @@
 #ifndef W4_WT_MAX
 #define W4_WT_MAX 512                                // launches of at most this many work-groups (a single round) store write-through
 #endif
+#ifndef W4_SLICE1
+#define W4_SLICE1 1                                 // 1: both parts of a transform slice behind ONE MFMA of the quad: 13 gaps of ~12 instructions per turn instead of
+                                                    //    26 of ~6 (round 5: one image at a time 171.2 against 169.3 Mpix/s, in flight equal)
+#endif
 #ifndef W4_SOFT
 #define W4_SOFT 0                                   // 1: two barriers per iteration between MFMA quads (B1 / B2 below); 0: one at its end (measured equal: below)
 #endif
@@ -334,6 +338,9 @@ void wino4_3x3_kernel(const WnArgs a) {
     //   k = 0: the outer patch columns from the neighbour lanes;  k = 1 .. 6: Bt over columns 0, 5, 1, 2, 3, 4 (in place);
     //   k = 7 .. 12: Bt over row k - 7, written to the ring as soon as a position quad is complete.
     // Same operations in the same order per value as transform_put: bit-identical.
+    // (Round 5: the same slices cut finer -- four parts of ~3 instructions, one behind EVERY MFMA of a quad instead of six behind two of
+    // them -- are slower: one image at a time 163.4 against 169.8 Mpix/s, four in flight 269.2 against 272.8.  An instruction behind an
+    // MFMA costs the issue slot between two MFMAs whatever its length; fewer, fuller gaps win.  Not kept.)
     float su[6][6], sp = 0.f, sq = 0.f, sr = 0.f, se = 0.f, sa = 0.f, sh4 = 0.f, sh5 = 0.f;
     auto bt_first = [&](float d0, float d1, float d2, float d3, float d4) __attribute__((always_inline)) {
         sp = fmaf(-4.f, d2, d4); sq = fmaf(-4.f, d1, d3); sr = d4 - d2; se = d3 - d1;
@@ -486,9 +493,10 @@ void wino4_3x3_kernel(const WnArgs a) {
             for (int i = 0; i < 4; ++i) {
                 if (4 * q + i < W4_ACC_A) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[4 * q + i]) : "v"(fa[lq % W4_RA][i]), "v"(bq[lq % W4_RB][i]));
                 else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[4 * q + i]) : "v"(fa[lq % W4_RA][i]), "v"(bq[lq % W4_RB][i]));
-                if (W4_SPREAD && !last && i < 2 && sk >= 0 && sk < 13) {
+                if (W4_SPREAD && !last && i < (W4_SLICE1 ? 1 : 2) && sk >= 0 && sk < 13) {
                     __builtin_amdgcn_sched_barrier(0);
                     slice(sk, i, u2 ^ 1);
+                    if (W4_SLICE1) slice(sk, 1, u2 ^ 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
