@@ -453,31 +453,35 @@ def main():
                             '`encoder.alone` = the same launch with nothing beside it (its duration in a kernel trace, on plan.cus of 256 CUs)'.format(n_flight),
                     'from_profiles': from_profiles, 'encoder': enc_l, 'decoder': dec_l}
         # The in-flight figure cannot be read from a kernel trace (the tracer serialises the streams); tools/w4_inflight_stamps.py
-        # measures the same schedule with in-kernel stamps on a -DW4_LAUNCH_STAMPS build and commits profiles/rNN_inflight_stamps.json.
-        # `frac` of this line is checked against it: within 5 % of the file's figure for the SAME scenario (n stacks in flight, the
-        # scenario the HIP events above bracket), else the file's figure replaces it and the live one moves to `frac_live_events`.
+        # measures the same schedule with in-kernel stamps on a -DW4_LAUNCH_STAMPS build and commits profiles/rNN_inflight_stamps.json:
+        #   stacks  the scenario `frac` is measured on (n residual stacks in flight), timed BOTH ways in one run: HIP events as here
+        #           (wall time of the burst / launches) and stamps (union of the launches' [first wave start, last store acknowledged]
+        #           intervals / launches -- the events figure also pays the gaps in which no launch runs: events_over_stamps);
+        #   step    the timed region of this benchmark itself (other kernels share the chip there), stamps only.
+        # `frac` of this line must be reproducible from that file: it is compared with the file's events figure of the same scenario;
+        # more than 5 % apart, the file's figure replaces it and the live one moves to `frac_live_events`.
         stamps = load_stamps(ROOT)
         if stamps and stamps.get('input_shape') == [N, 3, H, Wd] and stamps.get('images_in_flight') == n_flight and form3 == 2 \
                 and 'dominant' in stamps.get('stacks', {}) and 'dominant' in stamps.get('step', {}):
             sk, sp = stamps['stacks'], stamps['step']
-            ratio = roofline['frac'] / sk['dominant']['frac'] if sk['dominant']['frac'] else None
+            file_frac = sk.get('hip_events_frac') or sk['dominant']['frac']
+            ratio = roofline['frac'] / file_frac if file_frac else None
             roofline['from_stamps'] = {
                 'file': stamps['file'],
-                'stacks_in_flight': {'us_per_launch': sk['dominant']['us_per_launch_under_concurrency'], 'frac': sk['dominant']['frac'],
-                                     'hip_events_us_per_launch_same_run': sk.get('hip_events_us_per_launch'),
-                                     'events_over_stamps_same_run': sk.get('events_over_stamps')},
-                'in_step': {'us_per_launch': sp['dominant']['us_per_launch_under_concurrency'], 'frac': sp['dominant']['frac'],
+                'stacks_in_flight': {'hip_events_us_per_launch': sk.get('hip_events_us_per_launch'), 'hip_events_frac': sk.get('hip_events_frac'),
+                                     'stamps_us_per_launch': sk['dominant']['us_per_launch_under_concurrency'], 'stamps_frac': sk['dominant']['frac'],
+                                     'events_over_stamps': sk.get('events_over_stamps')},
+                'in_step': {'stamps_us_per_launch': sp['dominant']['us_per_launch_under_concurrency'], 'stamps_frac': sp['dominant']['frac'],
                             'launch_duration_us_mean': sp['kernels'][sp['dominant']['kernel']]['launch_duration_us']['mean'],
                             'concurrency': sp['kernels'][sp['dominant']['kernel']]['concurrency'],
-                            'chip_mfma_issue_share': sp.get('chip_mfma_issue_share'), 'shader_clock_ghz': sp.get('shader_clock_ghz_under_load')},
-                'this_run_frac_over_file_frac': round(ratio, 4) if ratio else None,
-                'note': 'in-kernel s_memrealtime stamps, no tracer: us_per_launch = union of the launches\' [first wave start, last store '
-                        'acknowledged] intervals / launches; `stacks_in_flight` is the scenario `frac` is measured on, `in_step` the timed '
-                        'region of this benchmark itself (other kernels share the chip there)'}
+                            'chip_mfma_issue_share': sp.get('chip_mfma_issue_share'), 'shader_clock_ghz': sp.get('shader_clock_ghz_under_load'),
+                            'mpix_per_s_wall_with_stamps': sp.get('mpix_per_s_wall')},
+                'this_run_frac_over_file_events_frac': round(ratio, 4) if ratio else None,
+                'note': 'in-kernel s_memrealtime stamps, no tracer; frac = executed FLOPs per launch / us per launch / 157.3 TFLOP/s'}
             if ratio is not None and abs(ratio - 1.0) > 0.05:
                 roofline['frac_live_events'], roofline['achieved_live_events'] = roofline['frac'], roofline['achieved']
-                roofline['frac'] = sk['dominant']['frac']
-                roofline['achieved'] = sk['dominant']['achieved_tflops']
+                roofline['frac'] = file_frac
+                roofline['achieved'] = round(file_frac * PEAK_F32_MFMA_TFLOPS, 2)
                 roofline['from_stamps']['replaced_frac'] = True
         sym = N * int(ae_cfg.num_chan_bn) * (H // 8) * (Wd // 8)
         roofline_pc = {'kernel': 'context model, 4 masked conv3d layers + cross-entropy (ic_pc_bitcost_f32), standalone',

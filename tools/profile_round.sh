@@ -23,4 +23,10 @@ timeout 320 $t pmc b_l2 "TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum" $STEP
 timeout 320 $t trace pc python tools/run_pc.py 40
 # the training step (BASELINE configs[2])
 timeout 320 $t trace train python bench.py --mode train --steps 6 --warmup 2
+# the in-flight schedule WITHOUT a tracer: in-kernel launch stamps (needs the -DW4_LAUNCH_STAMPS build, made in the build container:
+#   tools/build_variants.sh conv3x3_wino4.hip ls="-fno-slp-vectorize -DW4_LAUNCH_STAMPS")
+if [ -f imgcomp_cvpr_amd/csrc/variants/lib_ls.so ]; then
+  IMGCOMP_HIP_LIB=$PWD/imgcomp_cvpr_amd/csrc/variants/lib_ls.so timeout 300 python tools/w4_inflight_stamps.py --out gpurun_out/inflight_stamps.json > gpurun_out/inflight_stamps.log 2>&1
+  tail -2 gpurun_out/inflight_stamps.log
+fi
 ls gpurun_out | head -40
