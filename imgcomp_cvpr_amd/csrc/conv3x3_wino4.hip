@@ -79,6 +79,9 @@
 #ifndef W4_WT_MAX
 #define W4_WT_MAX 512                                // launches of at most this many work-groups (a single round) store write-through
 #endif
+#ifndef W4_ABL
+#define W4_ABL 0                                    // timing-only ablations (wrong values; never in the shipped library): see the loop
+#endif
 #ifndef W4_SLICE1
 #define W4_SLICE1 1                                 // 1: both parts of a transform slice behind ONE MFMA of the quad: 13 gaps of ~12 instructions per turn instead of
                                                     //    26 of ~6 (round 5: one image at a time 171.2 against 169.3 Mpix/s, in flight equal)
@@ -493,17 +496,21 @@ void wino4_3x3_kernel(const WnArgs a) {
             for (int i = 0; i < 4; ++i) {
                 if (4 * q + i < W4_ACC_A) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[4 * q + i]) : "v"(fa[lq % W4_RA][i]), "v"(bq[lq % W4_RB][i]));
                 else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[4 * q + i]) : "v"(fa[lq % W4_RA][i]), "v"(bq[lq % W4_RB][i]));
-                if (W4_SPREAD && !last && i < (W4_SLICE1 ? 1 : 2) && sk >= 0 && sk < 13) {
+                if (W4_SPREAD && !last && !(W4_ABL & 4) && i < (W4_SLICE1 ? 1 : 2) && sk >= 0 && sk < 13) {      // (W4_ABL & 4: no transform at all)
                     __builtin_amdgcn_sched_barrier(0);
                     slice(sk, i, u2 ^ 1);
                     if (W4_SLICE1) slice(sk, 1, u2 ^ 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#if W4_ABL & 1
+            if ((lq & 1) == 0)      // TIMING-ONLY ablation (wrong values): half of the filter-fragment requests
+#endif
             if (!last || lq + W4_RA - 1 < 36) load_filter((lq + W4_RA - 1) % W4_RA, Q + W4_RA - 1);      // 36 % W4_RA == 0: the slot depends on lq only
             {
                 const int ah = lq + W4_RB - 1;                    // the quad whose B operands are requested now
-                if (ah < 36) bq[ah % W4_RB] = ring[((u2 * 4 + ah / W4_QUADS) * W4_QUADS + ah % W4_QUADS) * 64 + lane];
+                if (ah < 36 && !((W4_ABL & 2) && (lq & 1)))   // (W4_ABL & 2: timing-only ablation, half of the B-operand reads)
+                    bq[ah % W4_RB] = ring[((u2 * 4 + ah / W4_QUADS) * W4_QUADS + ah % W4_QUADS) * 64 + lane];
                 else if (W4_SOFT && !last) bq[ah % W4_RB] = ring[(((u2 ^ 1) * 4 + 0) * W4_QUADS + (ah - 36)) * 64 + lane];   // behind B1
             }
             // the wave's own k-step of the NEXT iteration: requested, then from W4_GAP quads later on transformed and written into
