@@ -292,6 +292,9 @@ void wino4_3x3_kernel(const WnArgs a) {
         // on its own) they would sit in 12 registers next to 144 accumulators and spill
         int ob = obase, eb = ebase;
         asm volatile("" : "+v"(ob), "+v"(eb));
+        // (Round 5: a second path for segments whose six patch rows all lie inside the image -- row steps in the SCALAR offset, the two
+        // lane offsets carrying only the column's validity, no vector instruction per load instead of an add and a select -- was
+        // slower: one image at a time 163.2 against 171.0 Mpix/s, 8 Kodak maps 183.3 against 179.7 us.  Removed.)
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const bool row_lo = r_first + i >= 0 && r_first + i < H;          // scalar
