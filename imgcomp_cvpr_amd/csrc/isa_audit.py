@@ -49,45 +49,64 @@ def kernels(path):
             continue
         if body is None: continue
         s = ln.split(';')[0].strip()
-        if not s or s.startswith('.') or s.endswith(':'): continue
-        body.append(s)
+        if not s or (s.startswith('.') and not s.endswith(':')): continue
+        body.append(s)              # instructions and labels (`.LBBn_m:`): the back edges of loops are followed below
+
+
+def _step(s, age, recent, findings, tag=''):
+    """one instruction through both rules; age: register -> wait states since an MFMA wrote it; recent: recent VALU writes.  -> is MFMA"""
+    op, _, rest = s.partition(' ')
+    args = [a.strip() for a in rest.split(',')] if rest else []
+    states = int(args[0], 0) + 1 if op == 's_nop' else 1
+    mfma = op.startswith('v_mfma') or op.startswith('v_smfmac')
+    if mfma:
+        dst, src = regs_of(args[0]), set().union(*(regs_of(a) for a in args[1:4]))
+        for ws, wr, text in recent:
+            if ws < VALU_TO_SRC and (wr & src):
+                findings.append('(B){} VALU write {} wait state(s) before an MFMA that reads it:  {}  ->  {}'.format(tag, ws, text, s))
+        # an MFMA reading another MFMA's destination as SrcC (the accumulate chain) is the hardware's business; as SrcA / SrcB it is not
+        early = [r for r in set().union(*(regs_of(a) for a in args[1:3])) if r in age and age[r] < XDL_TO_ANY]
+        if early: findings.append('(A){} MFMA result used as SrcA / SrcB after {} wait states:  {}'.format(tag, min(age[r] for r in early), s))
+        for r in dst: age[r] = 0
+    else:
+        touched = regs_of(rest) if not op.startswith('s_') else set()
+        hit = [r for r in touched if r in age and age[r] < XDL_TO_ANY]
+        if hit:
+            findings.append('(A){} {} wait state(s) after an MFMA wrote {}{}:  {}'.format(tag, min(age[r] for r in hit), hit[0][0], hit[0][1], s))
+    new_recent = None
+    if op.startswith('v_') and not op.startswith(('v_mfma', 'v_smfmac', 'v_cmp', 'v_nop')) and args:
+        new_recent = [0, regs_of(args[0]), s]
+    for r in list(age):
+        if not (mfma and age[r] == 0): age[r] += states
+        if age[r] > 4 * XDL_TO_ANY: del age[r]
+    for e in recent: e[0] += states
+    recent[:] = [e for e in recent if e[0] < VALU_TO_SRC + 1]
+    if new_recent: recent.append(new_recent)
+    return mfma
 
 
 def audit_kernel(name, body):
     findings = []
-    # (A): age (in wait states) of every register an MFMA wrote
-    age = {}
-    # (B): recent VALU writes: list of (wait states ago, registers, text)
-    recent = []
+    age, recent = {}, []
     n_mfma = 0
-    for s in body:
+    labels = {s[:-1]: i for i, s in enumerate(body) if s.endswith(':')}
+    for i, s in enumerate(body):
+        if s.endswith(':'):
+            continue
+        n_mfma += _step(s, age, recent, findings)
+        # a backward branch: the first instructions of the loop body run again right behind the last ones -- follow the back edge
+        # for as many wait states as a hazard can span, with a COPY of the state at the branch
         op, _, rest = s.partition(' ')
-        args = [a.strip() for a in rest.split(',')] if rest else []
-        states = int(args[0], 0) + 1 if op == 's_nop' else 1
-        if op.startswith('v_mfma') or op.startswith('v_smfmac'):
-            n_mfma += 1
-            dst, src = regs_of(args[0]), set().union(*(regs_of(a) for a in args[1:4]))
-            for ws, wr, text in recent:
-                if ws < VALU_TO_SRC and (wr & src):
-                    findings.append('(B) VALU write %d wait state(s) before an MFMA that reads it:  %s  ->  %s' % (ws, text, s))
-            # an MFMA reading another MFMA's destination as SrcC (the accumulate chain) is the hardware's business; as SrcA / SrcB it is not
-            early = [r for r in set().union(*(regs_of(a) for a in args[1:3])) if r in age and age[r] < XDL_TO_ANY]
-            if early: findings.append('(A) MFMA result used as SrcA / SrcB after %d wait states:  %s' % (min(age[r] for r in early), s))
-            for r in dst: age[r] = 0
-            touched = set()
-        else:
-            touched = regs_of(rest) if not op.startswith('s_') else set()
-            hit = [r for r in touched if r in age and age[r] < XDL_TO_ANY]
-            if hit:
-                findings.append('(A) %d wait state(s) after an MFMA wrote %s%d:  %s' % (min(age[r] for r in hit), hit[0][0], hit[0][1], s))
-        if op.startswith('v_') and not op.startswith(('v_mfma', 'v_smfmac', 'v_cmp', 'v_nop')) and args:
-            recent.append([0, regs_of(args[0]), s])
-        for r in list(age):
-            if not (op.startswith('v_mfma') and age[r] == 0): age[r] += states
-            if age[r] > 4 * XDL_TO_ANY: del age[r]
-        for e in recent:
-            if e[2] is not s: e[0] += states
-        recent = [e for e in recent if e[0] < VALU_TO_SRC + 1]
+        if op.startswith(('s_cbranch', 's_branch')) and rest.strip() in labels and labels[rest.strip()] < i:
+            age2, recent2 = dict(age), [list(e) for e in recent]
+            states, j = 0, labels[rest.strip()]
+            while j < i and states < XDL_TO_ANY + 2:
+                t = body[j]
+                j += 1
+                if t.endswith(':'):
+                    continue
+                _step(t, age2, recent2, findings, ' [across the back edge of the loop at {}]'.format(rest.strip()))
+                states += int(t.split()[1], 0) + 1 if t.startswith('s_nop') else 1
     return n_mfma, findings
 
 

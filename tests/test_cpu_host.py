@@ -863,3 +863,16 @@ def test_pin_reference_inventory_on_written_and_hand_assembled_bundles(tmp_path,
         P.pin(flipped, 'unused', inventory_only=True, verbose=False)
     with pytest.raises(P.PinError, match='expected exactly one log dir'):
         P.pin(str(tmp_path / 'nowhere'), 'unused', inventory_only=True, verbose=False)
+
+
+def test_isa_audit_follows_loop_back_edges(tmp_path):
+    """a hazard whose two halves sit at the end and at the top of a loop body is found too (the audit follows backward branches)"""
+    loop = ('.LBB0_1:\n\tv_add_f32_e32 v38, 1.0, v38\n\ts_nop 15\n\tv_mfma_f32_16x16x4_f32 v[38:41], v25, v33, v[38:41]\n'
+            '\ts_cbranch_scc1 .LBB0_1\n')
+    f = _audit(tmp_path, loop)
+    assert any('(A)' in x and 'back edge' in x for x in f), f
+    ok = ('.LBB0_1:\n\ts_nop 11\n\tv_add_f32_e32 v38, 1.0, v38\n\ts_nop 15\n\tv_mfma_f32_16x16x4_f32 v[38:41], v25, v33, v[38:41]\n'
+          '\ts_cbranch_scc1 .LBB0_1\n')
+    assert not _audit(tmp_path, ok)
+    vb = ('.LBB0_2:\n\tv_mfma_f32_16x16x4_f32 a[0:3], v25, v33, a[0:3]\n\ts_nop 15\n\tv_fma_f32 v33, v1, v2, v3\n\ts_cbranch_scc1 .LBB0_2\n')
+    assert any('(B)' in x and 'back edge' in x for x in _audit(tmp_path, vb))
