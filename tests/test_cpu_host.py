@@ -876,3 +876,38 @@ def test_isa_audit_follows_loop_back_edges(tmp_path):
     assert not _audit(tmp_path, ok)
     vb = ('.LBB0_2:\n\tv_mfma_f32_16x16x4_f32 a[0:3], v25, v33, a[0:3]\n\ts_nop 15\n\tv_fma_f32 v33, v1, v2, v3\n\ts_cbranch_scc1 .LBB0_2\n')
     assert any('(B)' in x and 'back edge' in x for x in _audit(tmp_path, vb))
+
+
+def test_profile_evidence_is_self_consistent():
+    """the committed evidence files of the newest round agree with themselves (a digest whose sums and step count described
+    different windows): profiles/rNN_counters.json -- concurrency = kernel time / span of the SAME window, kernel time per step = the
+    window's sum / the steps it covers, and the 3x3 kernel's launches x duration fit inside it; profiles/rNN_inflight_stamps.json --
+    frac = executed FLOPs / (us per launch) / peak for both scenarios, the events figure and the stamps figure of one run related by the
+    ratio the file states."""
+    import glob
+    import json
+    cs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_counters.json')))
+    c = json.load(open(cs[-1]))
+    if 'window' not in c:
+        pytest.skip('digest of an older round')
+    w = c['window']
+    assert abs(c['concurrency'] - w['sum_of_kernel_durations_us'] / w['span_of_the_window_us']) < 2e-3
+    assert abs(w['kernel_us_per_step'] - w['sum_of_kernel_durations_us'] / w['steps_in_window']) < 1.0
+    assert w['union_busy_us'] <= w['span_of_the_window_us'] + 0.5 and w['sum_of_kernel_durations_us'] >= w['union_busy_us']
+    k3 = c['kernels'][c['plan_3x3']]
+    assert k3['launches_per_step'] * k3['avg_us_in_flight'] < w['kernel_us_per_step']
+    assert abs(w['launches_3x3_in_window'] / w['steps_in_window'] - k3['launches_per_step']) < 0.5
+    ss = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_inflight_stamps.json')))
+    if not ss:
+        pytest.skip('no stamps file')
+    s = json.load(open(ss[-1]))
+    for scen in ('step', 'stacks'):
+        d = s[scen]['dominant']
+        frac = d['executed_flop_per_launch'] / (d['us_per_launch_under_concurrency'] * 1e-6) / 1e12 / s['peak_tflops']
+        assert abs(frac - d['frac']) < 2e-3, scen
+        k = s[scen]['kernels'][d['kernel']]
+        assert abs(k['union_busy_us'] / k['launches'] - d['us_per_launch_under_concurrency']) < 0.01
+        assert 0 < s[scen]['chip_mfma_issue_share'] < 1 and 1.0 < s[scen]['shader_clock_ghz_under_load'] < 2.5
+    st = s['stacks']
+    assert abs(st['hip_events_us_per_launch'] / st['dominant']['us_per_launch_under_concurrency'] - st['events_over_stamps']) < 2e-3
+    assert abs(st['dominant']['executed_flop_per_launch'] / (st['hip_events_us_per_launch'] * 1e-6) / 1e12 / s['peak_tflops'] - st['hip_events_frac']) < 2e-3
