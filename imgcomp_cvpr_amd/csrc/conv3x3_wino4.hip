@@ -212,6 +212,12 @@ __device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, fl
 // bought 18 % there; beyond 9 a lone wave's loop -- 53.1 k clocks for 36.9 k of MFMA issue, tools/w4prof.py -- is no longer waiting for
 // filter fragments.  What is left per iteration of 4608 MFMA clocks: the barrier and the restart of the B-operand reads behind it,
 // 8 times per work-group.  Removed.)
+// (Round 5, same case, after the ablations had shown a lone wave's transform fully exposed -- one image at a time 171 -> 207 Mpix/s without
+// it: a build with FOUR PRODUCER WAVES per work-group, waves 4..7 requesting the patches and making Bt d B for waves 0..3, which keep the
+// filter stream, the MFMAs and the epilogue; same ring and barrier, bit-identical, audit clean, 240 registers, two waves per SIMD, one of
+// each kind.  Slower: 162.2 against 171.4 Mpix/s; with the producers requesting their patches a whole iteration ahead (two register
+// sets) 163.9 against 171.0.  MFMAs and vector instructions share a SIMD's vector issue port whichever wave they come from: moving the
+// transform to another wave moves it out of the consumer's program order, not out of its way.  Removed.)
 // (Also built and measured in round 4 for launches that are alone on the chip -- one Kodak map, 192 work-groups, one wave per SIMD --:
 // an 8-wave K-split work-group, waves 0..3 the first half of the k-steps, waves 4..7 the second, two rings, the partial sums
 // exchanged through LDS and each group finishing two of a lane's four channels.  Correct, and slower: 37.4 against 29.2 us per
