@@ -1056,6 +1056,7 @@ extern "C" int ic_conv3x3_c128_pick_algo(int N, int H, int W, int flags) {
 //     network (bench.py --in_flight 1, automatic F(2x2) plan against F(4x4) forced, Mpix/s):
 //         384x512 (96 work-groups) 111.5 / 91.1    512x512 (128) 143.6 / 119.4    448x768 (168) 145.3 / 150.2    512x768 (192) 162.8 / 169.3
 //         640x768 (240) 174.0 / 201.9    768x768 (288) 152.7 / 162.4    768x1024 (384) 170.6 / 213.0
+//     (with the patch requested 10 quads ahead of its transform, later in round 5: 512x768 175.6, 640x768 210.4, 768x1024 216.3)
 //     (round 4, 6-quad ring, no prefetch: 512x768 162.5 / 140.7 -- the threshold stood at 512 work-groups, two per CU, then);
 //   * with several independent launches in flight (IC_CONV3_IN_FLIGHT: the images of an evaluation set) from 384 work-groups together;
 //   * and only where the map fills its 16-tile segments (1 x 16 tiles, or 2 x 8 on narrow maps: whichever needs fewer): 30 maps of

@@ -57,7 +57,7 @@
 #define W4_QUADS 9                                  // 36 positions in quads of 4
 #define W4_PACKED_FLOATS (36 * WN_C * WN_C)
 #define W4_ACC_A 32                                 // accumulators (of 36) kept in AGPRs
-// tuning knobs (defaults = the measured best, round 4: 4 waves, rings 6 / 3, turn at quad 6, transform 3 quads after its request)
+// tuning knobs (defaults = the measured best, round 4: 4 waves, round 5: rings 9 / 3, turn at quad 6, transform 10 quads after its request)
 #ifndef W4_RA
 #define W4_RA 9                                     // filter-fragment ring, in quads (36 % W4_RA == 0); round 5: 6 -> 9 (below)
 #endif
@@ -68,7 +68,8 @@
 #define W4_TURN 6                                   // quad of an iteration at which a wave requests its k-step of the next one
 #endif
 #ifndef W4_GAP
-#define W4_GAP 5                                    // quads between that request and the transform
+#define W4_GAP 10                                   // quads between that request and the transform (round 5: 5 -> 10: a lone wave has nobody to cover
+                                                    //    the patch's round trip; one image at a time 171.1 -> 175.6 Mpix/s, four in flight unchanged; 8, 14, 16, 22 the same)
 #endif
 #ifndef W4_PRE_N
 #define W4_PRE_N 2                                  // channels whose residual 1 is requested that early (the other of the first two: at the epilogue's start)
