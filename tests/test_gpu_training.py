@@ -907,10 +907,15 @@ def _peer_timeout_worker(rank, world, port, device_index, out_q):
     dev_ = torch.device('cuda', device_index)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        px = peer.PeerExchange(dev_, spin_limit=5000)
+        # exchange 1 with the library's default bound (seconds): the two processes share ONE GPU here and a process's first launch of
+        # the kernel also loads its code object -- with the short bound of exchange 2 rank 0 gave up on a rank 1 that was merely
+        # late, once in five full runs of round 5 (the failure this test is NOT about)
+        px = peer.PeerExchange(dev_, spin_limit=0)
         t = torch.ones(8, dtype=torch.float64, device=dev_) * (rank + 1)
         px.allreduce_f64(t)                                   # exchange 1: both ranks
         px.check_status()
+        dist.barrier()
+        px.spin_limit = 5000                                  # (read per call)
         raised = None
         if rank == 0:
             u = torch.ones(8, dtype=torch.float64, device=dev_)
