@@ -14,7 +14,7 @@ issued round-robin and EVERY step is still one image through the whole path.  Th
 bubbles of the others, and a 3x3 launch no longer has to fill the chip alone (IC_CONV3_IN_FLIGHT: the plan takes the form with
 the least CU-time).  --in_flight 1 is one image at a time (what rounds 1-2 reported; kept in the line as `one_image_at_a_time`).
 The HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues, 4 unless set: with more streams than
-queues, streams that share a queue run one after the other.  bench.py asks for 8 below, before the runtime starts (round 4:
+queues, streams that share a queue run one after the other.  bench.py asks for 16 below, before the runtime starts (round 4:
 4 images in flight 207.7 Mpix/s on 4 queues, 251.5 on 8; 6 images 236 / 240).
 
   python bench.py --gpus N --steps K --warmup W            (--mode train: one cfg3 training step per step)
@@ -40,7 +40,8 @@ import os
 import sys
 import time
 
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # one hardware queue per image in flight (+ the default stream); see the docstring
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')     # one hardware queue per image in flight (+ the default stream); see the docstring
+                                                     # (16 since round 6: small images keep up to 15 in flight, flight_for_shape)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -165,6 +166,16 @@ class InFlight(object):
         self.i += 1
         with self.torch.cuda.stream(self.streams[k]):
             return self.pipes[k].step()
+
+
+def flight_for_shape(lib, n, h, w, n_default):
+    """images in flight for a shape: at least the benchmark's own count, and enough of them that the 3x3 launches in flight hold
+    >= 512 F(4x4) work-groups together (two per CU) -- a 256 x 256 image is 32 work-groups per launch, so 4 in flight fill an eighth
+    of the chip.  IC_CONV3_IN_FLIGHT carries 4 bits: at most 15."""
+    if n_default <= 1:
+        return 1
+    wgs = int(lib.ic_wino4_3x3_c128_workgroups(n, h // 4, w // 4)) or 1
+    return int(min(15, max(n_default, -(-512 // wgs))))
 
 
 def res_stack_runner(torch, lib, _lib, W, ae, ae_cfg, pipe, enc, which, flags, st):
@@ -305,6 +316,7 @@ def main():
     sched = InFlight(torch, pipe, dev, n_flight, a.ae_config, rank, graphs=bool(a.graphs)) if n_flight > 1 else pipe
     elapsed, (bpp, x_out) = run(sched, a.steps, a.warmup, collective=True)
     elapsed = max_over_ranks(torch, dist, elapsed, dev, world, a.backend)
+    ranks_seen = ranks_report(torch, dist, dev, rank, world, a.backend)
     value = N * H * Wd * world * a.steps / elapsed / 1e6
     if a.calib_copy:
         src = torch.randn(64 * 1024 * 1024, device=dev)
@@ -478,11 +490,8 @@ def main():
                             'mpix_per_s_wall_with_stamps': sp.get('mpix_per_s_wall')},
                 'this_run_frac_over_file_events_frac': round(ratio, 4) if ratio else None,
                 'note': 'in-kernel s_memrealtime stamps, no tracer; frac = executed FLOPs per launch / us per launch / 157.3 TFLOP/s'}
-            if ratio is not None and abs(ratio - 1.0) > 0.05:
-                roofline['frac_live_events'], roofline['achieved_live_events'] = roofline['frac'], roofline['achieved']
-                roofline['frac'] = file_frac
-                roofline['achieved'] = round(file_frac * PEAK_F32_MFMA_TFLOPS, 2)
-                roofline['from_stamps']['replaced_frac'] = True
+            # `frac` / `achieved` stay THIS run's measurement; a disagreement with the committed file is flagged, never substituted
+            roofline['from_stamps']['agrees_within_5_percent'] = bool(ratio is not None and abs(ratio - 1.0) <= 0.05)
         sym = N * int(ae_cfg.num_chan_bn) * (H // 8) * (Wd // 8)
         roofline_pc = {'kernel': 'context model, 4 masked conv3d layers + cross-entropy (ic_pc_bitcost_f32), standalone',
                        'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': PEAK_F32_MFMA_TFLOPS,
@@ -518,16 +527,27 @@ def main():
                 continue
             ps = Pipeline(dev, a.ae_config, share, seed=rank).set_input(n2, h2, w2)
             dt1, _ = run(ps, 30, 5)
-            sch = InFlight(torch, ps, dev, n_flight, a.ae_config, rank, graphs=bool(a.graphs)) if n_flight > 1 else ps
-            dt, _ = run(sch, 30, 5) if n_flight > 1 else (dt1, None)
+            nf2 = flight_for_shape(lib, n2, h2, w2, n_flight)          # enough launches in flight to fill the chip with THIS shape
+            k2 = 30 if nf2 <= 6 else 5 * nf2
+            sch = InFlight(torch, ps, dev, nf2, a.ae_config, rank, graphs=bool(a.graphs)) if nf2 > 1 else ps
+            dt, _ = run(sch, k2, nf2 + 2) if nf2 > 1 else (dt1 * k2 / 30.0, None)
             # executed FLOPs: the 64 3x3 layers (589,824 FLOP per input pixel and network half) in the form the plan runs, the 5x5 layers direct
-            f3 = {0: 1.0, 1: 16.0 / 36.0, 2: 36.0 / 144.0}[lib.ic_conv3x3_c128_pick_form(n2, h2 // 4, w2 // 4, (_lib.CONV3_IN_FLIGHT(n_flight) if n_flight > 1 else 0))]
+            fl2 = _lib.CONV3_IN_FLIGHT(nf2) if nf2 > 1 else 0
+            f3 = {0: 1.0, 1: 16.0 / 36.0, 2: 36.0 / 144.0}[lib.ic_conv3x3_c128_pick_form(n2, h2 // 4, w2 // 4, fl2)]
             flop = n2 * h2 * w2 * (2 * 589824.0 * f3 + (FLOP_PER_PX_ENC - 589824.0) + (FLOP_PER_PX_DEC - 589824.0))
-            shapes.append({'batch': n2, 'height': h2, 'width': w2, 'value': round(n2 * h2 * w2 * 30 / dt / 1e6, 3), 'unit': 'Mpix/s',
-                           'ms_per_step': round(dt / 30 * 1e3, 4), 'images_in_flight': n_flight,
-                           'one_image_at_a_time': {'value': round(n2 * h2 * w2 * 30 / dt1 / 1e6, 3), 'ms_per_step': round(dt1 / 30 * 1e3, 4)},
-                           'executed_frac_of_mfma_peak_whole_step': round(flop * 30 / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                           'plan_3x3': plan_name(lib, _lib, n2, h2 // 4, w2 // 4, 0)['kernel']})
+            ent = {'batch': n2, 'height': h2, 'width': w2, 'value': round(n2 * h2 * w2 * k2 / dt / 1e6, 3), 'unit': 'Mpix/s',
+                   'ms_per_step': round(dt / k2 * 1e3, 4), 'images_in_flight': nf2,
+                   'one_image_at_a_time': {'value': round(n2 * h2 * w2 * 30 / dt1 / 1e6, 3), 'ms_per_step': round(dt1 / 30 * 1e3, 4)},
+                   'executed_frac_of_mfma_peak_whole_step': round(flop * k2 / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                   'plan_3x3': plan_name(lib, _lib, n2, h2 // 4, w2 // 4, fl2)['kernel']}
+            if nf2 != n_flight and n_flight > 1:
+                # the Kodak schedule's count on this shape too (what rounds 3-5 reported for it)
+                del sch
+                sch4 = InFlight(torch, ps, dev, n_flight, a.ae_config, rank, graphs=bool(a.graphs))
+                dt4_, _ = run(sch4, 30, 5)
+                ent['with_{}_in_flight'.format(n_flight)] = {'value': round(n2 * h2 * w2 * 30 / dt4_ / 1e6, 3), 'ms_per_step': round(dt4_ / 30 * 1e3, 4)}
+                del sch4
+            shapes.append(ent)
             ps.branch.close()
         extra['shapes'] = shapes
         # BASELINE configs[4]: the high-rate configuration on a 4K frame (one image per GPU; a frame fills the chip by itself:
@@ -608,6 +628,7 @@ def main():
         # with the reference's one-sess.run-per-image loop (val.py:157-158) rides in `config` (numbers only) so that it survives too
         one = extra.get('one_image_at_a_time')
         out['config']['images_in_flight'] = n_flight
+        out['ranks'] = ranks_seen
         out['config']['one_image_at_a_time_mpix_s'] = one['value'] if one else (round(value, 3) if n_flight == 1 else None)
         out['config']['one_image_at_a_time_ms_per_step'] = one['ms_per_step'] if one else (round(elapsed / a.steps * 1e3, 4) if n_flight == 1 else None)
         print(json.dumps(out), flush=True)
@@ -741,6 +762,29 @@ def load_stamps(root):
         return None
 
 
+def ranks_report(torch, dist, dev, rank, world, backend):
+    """self-verification of a multi-GPU run (every rank calls it once, after the timed region): an all-reduce (SUM) of a one-hot rank
+    mask must come back all ones -- every rank of the world took part in a collective over this backend --, and an all-gather of
+    (HIP device index, PCI bus id hash) shows that the ranks sit on distinct devices.  -> dict on every rank."""
+    info = {'world_size': world, 'backend': ('rccl (torch nccl)' if backend == 'nccl' else backend) if world > 1 else None}
+    if world == 1:
+        info.update({'rccl_ranks_seen': 1, 'devices': [torch.cuda.get_device_name(dev) + ' #{}'.format(dev.index)]})
+        return info
+    cdev = dev if backend == 'nccl' else 'cpu'
+    mask = torch.zeros(world, dtype=torch.int32, device=cdev)
+    mask[rank] = 1
+    dist.all_reduce(mask, op=dist.ReduceOp.SUM)
+    props = torch.cuda.get_device_properties(dev)
+    ident = torch.tensor([dev.index, int(getattr(props, 'pci_bus_id', -1)), int(getattr(props, 'pci_device_id', -1))], dtype=torch.int64, device=cdev)
+    allid = [torch.zeros_like(ident) for _ in range(world)]
+    dist.all_gather(allid, ident)
+    ids = [tuple(int(v) for v in t.tolist()) for t in allid]
+    info.update({'rccl_ranks_seen': int((mask == 1).sum().item()), 'dist_world_size': dist.get_world_size(),
+                 'devices': ['rank {}: hip device {} pci bus {} dev {}'.format(r, *i) for r, i in enumerate(ids)],
+                 'distinct_devices': len(set(ids))})
+    return info
+
+
 def max_over_ranks(torch, dist, elapsed, dev, world, backend):
     if world == 1:
         return elapsed
@@ -824,7 +868,13 @@ def train_main(a, dev, rank, world):
     else:
         N = GLOBAL
     elapsed, out, tr = train_steps_timed(torch, dist, dev, rank, world, N, H, Wd, a.steps, a.warmup, a.backend)
+    ranks_seen = ranks_report(torch, dist, dev, rank, world, a.backend)
     if rank == 0:
+        from imgcomp_cvpr_amd import _lib, weights as W
+        try:
+            roof = train_roofline(torch, _lib.lib, _lib, W, tr, dev, N, H, Wd, elapsed / a.steps * 1e3)
+        except Exception as ex:                                    # informational
+            roof = {'error': str(ex)[:300]}
         print(json.dumps({
             'metric': 'training images/s (cfg3: cvpr/med + res_shallow, 128x128 crops, {})'.format(
                 'batch 32 per GPU' if a.scaling == 'weak' else 'global batch 32 split over the GPUs'),
@@ -835,6 +885,7 @@ def train_main(a, dev, rank, world):
                                    'per GPU, MS-SSIM loss, two Adam optimisers, data-parallel gradient all-reduce'.format(N, H, Wd),
                        'batch_per_gpu': N, 'global_batch': N * world, 'parallelism': 'dp{}'.format(world),
                        'cross_replica_batchnorm': tr.graph._bn_world() > 1},
+            'ranks': ranks_seen, 'roofline': roof,
             'mpix_per_s': round(N * H * Wd * world * a.steps / elapsed / 1e6, 3),
             'last_step': {k: round(float(v), 5) for k, v in out.items()}}), flush=True)
     if world > 1:
@@ -866,6 +917,95 @@ def train_steps_timed(torch, dist, dev, rank, world, N, H, Wd, steps, warmup, ba
     return max_over_ranks(torch, dist, time.perf_counter() - t0, dev, world, backend), out, tr
 
 
+def train_step_flops(W, graph, N, H, Wd):
+    """FLOPs one cfg3 training step EXECUTES on the matrix cores (2 FLOP per multiply-add), from the layer table of the graph that just
+    ran: per convolution forward + data gradient (none for h1: the image needs none) + filter gradient, each in the form it runs --
+    3x3 128 -> 128 layers: Winograd F(4x4) executes 36 / 144 of the direct multiplies, F(2x2) 16 / 36 (graph._w3_f4 says which per
+    direction; their filter gradients are taken in the F(2x2) domain: 16 / 36); every other layer direct; the context model's four
+    masked conv3d layers on their live taps (36,912 FLOP per symbol for k = 24 ... scaled from the filter shapes), x 3 passes.
+    -> (executed, direct-form equivalent)"""
+    C, B = int(graph.C), int(graph.B)
+    f4 = getattr(graph, '_w3_f4', (False, False))
+    executed = direct = 0.0
+    size = {'h1': (H // 2, Wd // 2), 'h2': (H // 4, Wd // 4), 'to_bn': (H // 8, Wd // 8), 'from_bn': (H // 4, Wd // 4),
+            'h12': (H // 2, Wd // 2), 'h13': (H, Wd)}
+    for scope, kind, shape in W.ae_conv_specs(C, B, bool(graph.heatmap)):
+        kh, kw, a_, b_ = shape
+        oh, ow = size.get(scope.rsplit('/', 1)[-1], (H // 4, Wd // 4))
+        taps = kh * kw * a_ * b_
+        if kind == 'deconv' or kh == 5:
+            # stride 2: a 5x5 / 2 convolution computes its output at (H/2 x W/2) positions; the transposed one meets every INPUT position
+            pos = oh * ow if kind == 'conv' else (oh // 2) * (ow // 2)
+        else:
+            pos = oh * ow
+        one = 2.0 * taps * pos * N
+        passes = 2 if scope.endswith('/h1') else 3
+        direct += passes * one
+        if (kh, kw, a_, b_) == (3, 3, 128, 128) and kind == 'conv':
+            executed += one * ((0.25 if f4[0] else 16.0 / 36.0) + (0.25 if f4[1] else 16.0 / 36.0) + 16.0 / 36.0)
+        else:
+            executed += passes * one
+    # context model: live taps of the causal masks (first layer's mask excludes the centre: 13 of 18 taps live, the others 14)
+    k, L = int(graph.k), int(graph.L)
+    sym = N * C * (H // 8) * (Wd // 8)
+    live = 2.0 * (13 * 1 * k + 14 * k * k + 14 * k * k + 14 * k * L)
+    dense = 2.0 * 18 * (1 * k + k * k + k * k + k * L)
+    executed += 3 * live * sym
+    direct += 3 * dense * sym
+    return executed, direct
+
+
+def train_roofline(torch, lib, _lib, W, tr, dev, N, H, Wd, ms_per_step):
+    """roofline object of the training step: executed FLOPs per step / step time / fp32 MFMA peak for the whole step,
+    and the dominant BACKWARD kernel -- the 3x3 128 -> 128 filter gradient in the Winograd domain (ic_conv3x3_c128_wgrad_f32: producer +
+    slice reduction, 64 calls per step) -- timed live with HIP events on the step's own shape."""
+    executed, direct = train_step_flops(W, tr.graph, N, H, Wd)
+    st = _lib.current_stream(dev)
+    h4, w4 = H // 4, Wd // 4
+    x = torch.relu(torch.randn((N, 128, h4, w4), device=dev))
+    dy = torch.randn((N, 128, h4, w4), device=dev) * 0.1
+    w = torch.randn((3, 3, 128, 128), device=dev) * 0.05
+    dw = torch.empty_like(w)
+    need = lib.ic_conv3x3_c128_wgrad_workspace_bytes(N, h4, w4)
+    ws = torch.empty(max(int(need), 16), dtype=torch.uint8, device=dev)
+    ev = [ctypes.c_void_p() for _ in range(2)]
+    for e in ev:
+        _lib.check(lib.ic_event_create(ctypes.byref(e)))
+
+    def call():
+        _lib.check(lib.ic_conv3x3_c128_wgrad_f32(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), N, h4, w4, _lib.ptr(w), 1e-4, _lib.ptr(ws), need, st))
+    for _ in range(5):
+        call()
+    torch.cuda.synchronize(dev)
+    _lib.check(lib.ic_event_record(ev[0], st))
+    for _ in range(30):
+        call()
+    _lib.check(lib.ic_event_record(ev[1], st))
+    ms = ctypes.c_float()
+    _lib.check(lib.ic_event_elapsed_ms(ev[0], ev[1], ctypes.byref(ms)))
+    for e in ev:
+        lib.ic_event_destroy(e)
+    us = ms.value / 30 * 1e3
+    wg_direct = 2.0 * 9 * 128 * 128 * N * h4 * w4
+    wg_exec = wg_direct * 16.0 / 36.0
+    n3 = 2 * (6 * int(tr.graph.B) + 2)
+    return {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': PEAK_F32_MFMA_TFLOPS,
+            'achieved': round(executed / (ms_per_step * 1e-3) / 1e12, 2),
+            'frac': round(executed / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            'executed_flop_per_step': executed, 'direct_equivalent_flop_per_step': direct,
+            'direct_equivalent_frac': round(direct / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            'forms_3x3': {'forward': 'F(4x4)' if tr.graph._w3_f4[0] else 'F(2x2)', 'data_gradient': 'F(4x4)' if tr.graph._w3_f4[1] else 'F(2x2)',
+                          'filter_gradient': 'F(2x2) domain'},
+            'dominant_backward_kernel': {
+                'kernel': 'wino3x3_c128_wgrad8_kernel + wino_wgrad_reduce_kernel (ic_conv3x3_c128_wgrad_f32), alone on the stream',
+                'calls_per_step': n3, 'avg_call_us': round(us, 2), 'executed_flop_per_call': wg_exec,
+                'achieved': round(wg_exec / us / 1e6, 2), 'frac': round(wg_exec / us / 1e6 / PEAK_F32_MFMA_TFLOPS, 4),
+                'share_of_step': round(n3 * us * 1e-3 / ms_per_step, 3)},
+            'note': 'whole step: executed FLOPs (Winograd forms counted at what they execute, filter gradients included) / step time / 157.3; '
+                    'the element-wise passes of a training step (BatchNorm statistics / apply / backward, optimiser, MS-SSIM) execute no matrix FLOPs and '
+                    'are what keeps the fraction below the inference step\'s'}
+
+
 def train_object(torch, dist, dev, steps=12, warmup=4):
     """the N = 1 inference line's `train` object: BASELINE configs[2] (cfg3) on this GPU -- images/s, ms per step and the last
     step's loss terms (MS-SSIM must lie in (0, 1]; d_loss_scaled = K (1 - MS-SSIM)), so that the driver's BENCH file carries a
@@ -878,6 +1018,11 @@ def train_object(torch, dist, dev, steps=12, warmup=4):
            'steps': steps, 'warmup': warmup, 'last_step': {k: round(float(v), 5) for k, v in out.items()},
            'checks': {'ms_ssim_in_unit_interval': bool(0.0 < out['ms_ssim'] <= 1.0),
                       'd_loss_is_K_times_one_minus_ms_ssim': bool(abs(out['d_loss_scaled'] - K * (1.0 - out['ms_ssim'])) < 2e-3 + 1e-6 * K)}}
+    try:
+        from imgcomp_cvpr_amd import _lib, weights as W
+        ent['roofline'] = train_roofline(torch, _lib.lib, _lib, W, tr, dev, 32, 128, 128, elapsed / steps * 1e3)
+    except Exception as ex:                                        # informational
+        ent['roofline'] = {'error': str(ex)[:300]}
     del tr
     torch.cuda.empty_cache()
     return ent

@@ -1,9 +1,12 @@
 """imgcomp-cvpr hot path on MI355X: the reference's plugin objects (autoencoder, probclass, val, train ...) over libimgcomp_hip.so."""
 import os
 
-# The HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues -- 4 unless set -- and streams that
-# share a queue run one after the other.  val.py / bench.py keep several images in flight, one stream each (+ the side stream of
-# the context model): ask for 8 unless the caller has decided.  Read when the runtime starts (the first device call), so this
-# works as long as the package is imported before that.  Measured (round 4, Kodak-sized images, 4 in flight): 207.7 Mpix/s on
-# 4 queues, 251.5 on 8.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
+def ask_for_hardware_queues(n=8):
+    """The HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues -- 4 unless set -- and streams that
+    share a queue run one after the other.  The ENTRY POINTS that keep several images in flight, one stream each (val.py, bench.py),
+    call this before the runtime starts (the variable is read at the first device call) unless the caller has decided; importing the
+    package changes nothing in the environment (a training rank has one compute stream and keeps the runtime's default).
+    Measured (round 4, Kodak-sized images, 4 in flight): 207.7 Mpix/s on 4 queues, 251.5 on 8.  -> the value in effect."""
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', str(int(n)))
+    return os.environ['GPU_MAX_HW_QUEUES']

@@ -25,6 +25,7 @@ CONV3_WINO_KSPLIT, CONV3_WINO_T16, CONV3_WINO_SEG1, CONV3_WINO_SEG2, CONV3_WINO_
 CONV3_WINO_PAIR = 10
 CONV3_WINO4 = 11                    # Winograd F(4x4,3x3)
 CONV3_NO_WINO4 = 0x800000
+CONV3_WINO4_WG8 = 0x8000000
 CONV5_BOTH_PACKED = 0x1000000         # h2 / h12 blobs carry the F(4x4)-over-phases fragments too (ic_pack_conv5s2_both_f32)
 CONV5_WINO4 = 0x2000000               # h2 / h12 on the F(4x4) kernel wherever the shape allows
 CONV5_NO_WINO4 = 0x4000000

@@ -233,10 +233,15 @@ __device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, fl
 // 16 tiles (training crops: 32 x 32 maps = 8 x 8 tiles) then fill their segments.  Row validity and row offsets become per-lane (two
 // values per wave: scalar conditions combined with the lane's half), and the lanes 7 / 8 in the middle of a DPP row take the column
 // outside from their own edge load like the lanes 0 / 15 at its ends.
-template <bool WT, int RES, int CIN, int COUT, bool SHUF, bool SEG2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// WG8 (round 6): ONE work-group of 8 waves covers all 128 output channels of a segment (COUT / 128 work-groups per segment), one per CU.
+// Waves w and w + 4 share a SIMD.  The input transform is made ONCE per segment: the waves 0..3 (group 0) make the k-steps of the even
+// iterations, the waves 4..7 (group 1) those of the odd ones -- every SIMD has one transforming and one MFMA-only wave in every iteration.
+// Same ring, same barrier (now 512 threads), same values in the same order: bit-identical to the 4-wave form.
+template <bool WT, int RES, int CIN, int COUT, bool SHUF, bool SEG2, bool WG8>
+__global__ __launch_bounds__(WG8 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void wino4_3x3_kernel(const WnArgs a) {
-    constexpr int KS = CIN / 4, IT = KS / 4, PARTS = COUT / 64;   // k-steps, iterations of 4 k-steps, work-groups per segment
+    constexpr int WAVES = WG8 ? 8 : 4;
+    constexpr int KS = CIN / 4, IT = KS / 4, PARTS = COUT / (16 * WAVES);   // k-steps, iterations of 4 k-steps, work-groups per segment
     __shared__ f32x4 ring[2 * 4 * W4_QUADS * 64];                 // [half][k-step of the iteration][position quad][lane]: 72 KB
     __shared__ float pf_sink[64];                                 // where the prefetch below lands (never read)
 #ifdef W4_STAMPS
@@ -252,8 +257,9 @@ void wino4_3x3_kernel(const WnArgs a) {
     const int seg = b / PARTS + a.g0;
     const int sx = seg % a.gcols, t_ = seg / a.gcols;
     const int ty = t_ % a.grows, n = t_ / a.grows;
-    const int cot = part * 4 + wave;                              // 16-channel tile of this wave
+    const int cot = part * WAVES + wave;                          // 16-channel tile of this wave
     const int pw = wave & 3;                                      // k-step of an iteration this wave produces
+    const int grp = WG8 ? wave >> 2 : 0;                          // WG8: this wave transforms the iterations of this parity (scalar)
     const int hrow = SEG2 ? (n16 >> 3) : 0;                       // SEG2: which of the segment's two tile rows this lane works on
     const int tx = SEG2 ? 8 * sx + (n16 & 7) : 16 * sx + n16;
     const int H = a.H, W = a.W, HW = H * W;
@@ -290,6 +296,17 @@ void wino4_3x3_kernel(const WnArgs a) {
         else asm volatile("" : "+v"(acc[p]));
     }
     __builtin_amdgcn_sched_barrier(0);
+
+    // B-operand reads of ring half 1 (byte offsets 0x9000 .. 0x12000): a ds_read's immediate offset has 16 bits, so the compiler keeps
+    // one address register per 1 KB quad beyond 0x10000 -- eight of them through the whole loop (the 4-wave form has the room, the
+    // 8-wave form spilled five).  WG8: ONE opaque base register at the start of half 1 instead.
+    typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+    unsigned rb1 = (unsigned)(size_t)&ring[4 * W4_QUADS * 64 + lane];
+    if (WG8) asm volatile("" : "+v"(rb1));
+    auto ring_rd = [&](int half, int idx) __attribute__((always_inline)) -> f32x4 {      // ring[(half * 4 * W4_QUADS + idx) * 64 + lane]
+        if (WG8 && half) return *(reinterpret_cast<lds_f32x4*>((size_t)rb1) + idx * 64);
+        return ring[(half * 4 * W4_QUADS + idx) * 64 + lane];
+    };
 
     f32x4 pr[6];            // own 4 pixels of the 6 patch rows
     float pe[6];            // the column outside (lanes 0 / 15 of a tile row)
@@ -392,6 +409,22 @@ void wino4_3x3_kernel(const WnArgs a) {
             }
         }
     };
+    // WG8: a wave transforms in every OTHER iteration, behind scalar branches.  The compiler cannot see that the conditions of the
+    // branches are one and the same, so every conditionally written value stays alive into the next conditional block -- across the
+    // iterations that do not transform -- and the allocator spills 116-163 registers.  An empty asm that "defines" them in front of the
+    // first conditional write ends the old value there: the live ranges are those of the 4-wave form again.  No instruction is emitted.
+    auto kill_patch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { asm volatile("" : "=v"(pr[i])); asm volatile("" : "=v"(pe[i])); }
+    };
+    auto kill_slices = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int jx = 0; jx < 6; ++jx) asm volatile("" : "=v"(su[i][jx]));
+        asm volatile("" : "=v"(sp)); asm volatile("" : "=v"(sq)); asm volatile("" : "=v"(sr)); asm volatile("" : "=v"(se));
+        asm volatile("" : "=v"(sa)); asm volatile("" : "=v"(sh4)); asm volatile("" : "=v"(sh5));
+    };
     // filter fragments: quad index Q = ks * 9 + q of this wave's channel tile: 1 KB per quad
     f32x4 fa[W4_RA];
     auto load_filter = [&](int slot, int Q) __attribute__((always_inline)) {       // slot = Q % W4_RA, passed as a constant
@@ -445,7 +478,7 @@ void wino4_3x3_kernel(const WnArgs a) {
     // (what a persistent work-group that inherits its first k-steps from its predecessor would save was measured with this block
     // compiled out -- wrong results, right timing: 8 Kodak maps 177.0 -> 170.8 us, a 4K map 434 -> 418 us, the bench step +1.5 %:
     // the other wave of the SIMD fills most of it.  Not built.)
-    load_patch(pw);
+    if (!WG8 || grp == 0) load_patch(pw);
 #pragma unroll
     for (int Q = 0; Q < W4_RA - 1; ++Q) load_filter(Q, Q);
     // The NEXT layer's fragments into this XCD's L2 while this layer computes (one call at a time only: a lone launch starts every
@@ -460,14 +493,14 @@ void wino4_3x3_kernel(const WnArgs a) {
         const unsigned per = (LINES + n_x - 1) / n_x, l0 = j_x * per;
         const __amdgpu_buffer_rsrc_t nr = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp_next, 0, 36 * CIN * COUT * 4, 0x00020000);
         const unsigned sink = (unsigned)(size_t)pf_sink;          // LDS byte address (wave-uniform)
-        for (unsigned l = threadIdx.x; l < per; l += 256) {
+        for (unsigned l = threadIdx.x; l < per; l += 64 * WAVES) {
             const unsigned off = (l0 + l) < LINES ? (l0 + l) * 128u : WN_OOB;
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(off), "s"(nr), "s"(sink) : "memory");
         }
     }
-    transform_put(0);
+    if (!WG8 || grp == 0) transform_put(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -491,11 +524,12 @@ void wino4_3x3_kernel(const WnArgs a) {
     // take about the MFMA's own 32.  Kept as a switch, off.
     f32x4 bq[W4_RB];
 #pragma unroll
-    for (int q0 = 0; q0 < W4_RB - 1; ++q0) bq[q0] = ring[((0 * 4 + 0) * W4_QUADS + q0) * 64 + lane];
-    auto iteration = [&](const int j, const int u2, const bool last) __attribute__((always_inline)) {      // reads ring half u2
+    for (int q0 = 0; q0 < W4_RB - 1; ++q0) bq[q0] = ring_rd(0, q0);
+    // `produce`: this wave prepares its k-step of the next iteration in this one (always in the 4-wave form; WG8: the group of the next half)
+    auto iteration = [&](const int j, const int u2, const bool last, const bool produce) __attribute__((always_inline)) {      // reads ring half u2
         if (!W4_SOFT && j > 0) {
 #pragma unroll
-            for (int q0 = 0; q0 < W4_RB - 1; ++q0) bq[q0] = ring[((u2 * 4 + 0) * W4_QUADS + q0) * 64 + lane];
+            for (int q0 = 0; q0 < W4_RB - 1; ++q0) bq[q0] = ring_rd(u2, q0);
         }
 #pragma unroll
         for (int lq = 0; lq < 36; ++lq) {                         // quad of the iteration: k-step lq / 9, positions 4 (lq % 9) ..
@@ -506,7 +540,8 @@ void wino4_3x3_kernel(const WnArgs a) {
             for (int i = 0; i < 4; ++i) {
                 if (4 * q + i < W4_ACC_A) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[4 * q + i]) : "v"(fa[lq % W4_RA][i]), "v"(bq[lq % W4_RB][i]));
                 else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[4 * q + i]) : "v"(fa[lq % W4_RA][i]), "v"(bq[lq % W4_RB][i]));
-                if (W4_SPREAD && !last && !(W4_ABL & 4) && i < (W4_SLICE1 ? 1 : 2) && sk >= 0 && sk < 13) {      // (W4_ABL & 4: no transform at all)
+                if (WG8 && !last && sk == 0 && i == 0) kill_slices();       // (see kill_slices)
+                if (W4_SPREAD && produce && !(W4_ABL & 4) && i < (W4_SLICE1 ? 1 : 2) && sk >= 0 && sk < 13) {      // (W4_ABL & 4: no transform at all)
                     __builtin_amdgcn_sched_barrier(0);
                     slice(sk, i, u2 ^ 1);
                     if (W4_SLICE1) slice(sk, 1, u2 ^ 1);
@@ -520,13 +555,14 @@ void wino4_3x3_kernel(const WnArgs a) {
             {
                 const int ah = lq + W4_RB - 1;                    // the quad whose B operands are requested now
                 if (ah < 36 && !((W4_ABL & 2) && (lq & 1)))   // (W4_ABL & 2: timing-only ablation, half of the B-operand reads)
-                    bq[ah % W4_RB] = ring[((u2 * 4 + ah / W4_QUADS) * W4_QUADS + ah % W4_QUADS) * 64 + lane];
-                else if (W4_SOFT && !last) bq[ah % W4_RB] = ring[(((u2 ^ 1) * 4 + 0) * W4_QUADS + (ah - 36)) * 64 + lane];   // behind B1
+                    bq[ah % W4_RB] = ring_rd(u2, ah);
+                else if (W4_SOFT && !last) bq[ah % W4_RB] = ring_rd(u2 ^ 1, ah - 36);   // behind B1
             }
             // the wave's own k-step of the NEXT iteration: requested, then from W4_GAP quads later on transformed and written into
             // the other half (W4_SPREAD: in 13 slices behind MFMAs; else as one block)
-            if (lq == W4_TURN && !last) load_patch(4 * (j + 1) + pw);
-            if (!W4_SPREAD && lq == W4_TURN + W4_GAP && !last) transform_put(u2 ^ 1);
+            if (WG8 && !last && lq == W4_TURN) kill_patch();
+            if (lq == W4_TURN && produce) load_patch(4 * (j + 1) + pw);
+            if (!W4_SPREAD && lq == W4_TURN + W4_GAP && produce) transform_put(u2 ^ 1);
             if (last && lq == W4_PRE) request_first(0, W4_PRE_N);
             if (W4_SOFT && !last && lq == W4_B1) {                // the other half is complete (own ring writes landed: LDS works in order)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -540,15 +576,18 @@ void wino4_3x3_kernel(const WnArgs a) {
             __builtin_amdgcn_s_barrier();                         // next half complete, this half read by everybody
         }
     };
+    // WG8: the group of the NEXT ring half produces in an iteration -- a scalar branch around each of its 13 slices and its patch request
+    // (two copies of the loop, one per group, made the allocator spill 174 registers: tried)
     for (int jj = 0; jj < IT - 2; jj += 2) {
-        iteration(jj, 0, false);
-        iteration(jj + 1, 1, false);
+        iteration(jj, 0, false, !WG8 || grp == 1);
+        iteration(jj + 1, 1, false, !WG8 || grp == 0);
     }
-    iteration(IT - 2, 0, false);
-    iteration(IT - 1, 1, true);
+    iteration(IT - 2, 0, false, !WG8 || grp == 1);
+    iteration(IT - 1, 1, true, false);
 #ifdef W4_STAMPS
     const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
 #endif
+
     // inline asm is opaque to the hazard recogniser: pad the last MFMAs' latency, then pass every accumulator through an empty
     // volatile asm so that no read of it can be scheduled above the pad (conv3x3_wino_tn.hip found that the hard way)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -682,14 +721,14 @@ void wino4_3x3_kernel(const WnArgs a) {
     if (a.prof && (threadIdx.x & 63) == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long ls_c1 = __builtin_amdgcn_s_memtime(), ls_r1 = __builtin_amdgcn_s_memrealtime();
-        unsigned long long* d = a.prof + 4 * ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6));
+        unsigned long long* d = a.prof + 4 * ((size_t)blockIdx.x * WAVES + (threadIdx.x >> 6));
         d[0] = ls_r0; d[1] = ls_r1; d[2] = ls_c1 - ls_c0; d[3] = (unsigned long long)(36 * KS);
     }
 #endif
 #ifdef W4_STAMPS
     if (a.prof && (threadIdx.x & 63) == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long* d = a.prof + 6 * ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6));
+        unsigned long long* d = a.prof + 6 * ((size_t)blockIdx.x * WAVES + (threadIdx.x >> 6));
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
         d[0] = t_loop0 - t_entry; d[1] = t_loop1 - t_loop0; d[2] = t_end - t_loop1; d[3] = t_entry; d[4] = t_end;
         // HW_ID (wave slot, SIMD, CU, SE) and XCC_ID: which waves followed each other on the same slot (tools/w4prof.py: turnover)
@@ -736,7 +775,7 @@ extern "C" long long ic_wino4_3x3_c128_workgroups(int N, int H, int W) {
     return 2ll * N * w4_segments(H, W, w4_seg2(H, W));
 }
 
-template <int RES, int CIN, int COUT, bool SHUF, bool SEG2>
+template <int RES, int CIN, int COUT, bool SHUF, bool SEG2, bool WG8>
 static int w4_launch2(const float* x, const float* w_packed, const float* scale, const float* shift, const float* res1, const float* res2,
                       float* y, int N, int H, int W, int relu, int flags, hipStream_t st, const float* w_next = nullptr) {
     WnArgs a{};
@@ -749,28 +788,34 @@ static int w4_launch2(const float* x, const float* w_packed, const float* scale,
 #ifdef W4_STAMPS
     a.prof = (unsigned long long*)g_w4_dbg;
 #endif
-    const long long wgs = (long long)(COUT / 64) * a.ngroups;
+    constexpr int WAVES = WG8 ? 8 : 4;
+    const long long wgs = (long long)(COUT / (16 * WAVES)) * a.ngroups;
 #ifdef W4_LAUNCH_STAMPS
     if (g_w4_ls) {
-        const long long first = g_w4_ls_next.fetch_add(4 * wgs), l = g_w4_ls_launch.load();
-        if (first + 4 * wgs <= g_w4_ls_cap && l < g_w4_ls_max_launches) {
+        const long long first = g_w4_ls_next.fetch_add(WAVES * wgs), l = g_w4_ls_launch.load();
+        if (first + WAVES * wgs <= g_w4_ls_cap && l < g_w4_ls_max_launches) {
             g_w4_ls_launch.fetch_add(1);
             a.prof = g_w4_ls + 4 * first;
-            g_w4_ls_table[3 * l] = first; g_w4_ls_table[3 * l + 1] = 4 * wgs; g_w4_ls_table[3 * l + 2] = CIN * 1000 + COUT;
+            g_w4_ls_table[3 * l] = first; g_w4_ls_table[3 * l + 1] = WAVES * wgs; g_w4_ls_table[3 * l + 2] = CIN * 1000 + COUT;
         }
     }
 #endif
-    const dim3 grid((unsigned)wgs), block(256);
-    if (wgs <= W4_WT_MAX) hipLaunchKernelGGL((wino4_3x3_kernel<true, RES, CIN, COUT, SHUF, SEG2>), grid, block, 0, st, a);     // a single round: write-through stores
-    else hipLaunchKernelGGL((wino4_3x3_kernel<false, RES, CIN, COUT, SHUF, SEG2>), grid, block, 0, st, a);
+    const dim3 grid((unsigned)wgs), block(64 * WAVES);
+    if (wgs * WAVES <= W4_WT_MAX * 4) hipLaunchKernelGGL((wino4_3x3_kernel<true, RES, CIN, COUT, SHUF, SEG2, WG8>), grid, block, 0, st, a);     // a single round: write-through stores
+    else hipLaunchKernelGGL((wino4_3x3_kernel<false, RES, CIN, COUT, SHUF, SEG2, WG8>), grid, block, 0, st, a);
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
 template <int RES, int CIN, int COUT, bool SHUF>
 static int w4_launch(const float* x, const float* w_packed, const float* scale, const float* shift, const float* res1, const float* res2,
                      float* y, int N, int H, int W, int relu, int flags, hipStream_t st, const float* w_next = nullptr) {
-    if (w4_seg2(H, W)) return w4_launch2<RES, CIN, COUT, SHUF, true>(x, w_packed, scale, shift, res1, res2, y, N, H, W, relu, flags, st, w_next);
-    return w4_launch2<RES, CIN, COUT, SHUF, false>(x, w_packed, scale, shift, res1, res2, y, N, H, W, relu, flags, st, w_next);
+    if (CIN == 128 && COUT == 128 && (flags & IC_CONV3_WINO4_WG8)) {      // 128-channel work-groups: the residual layers only
+        constexpr bool r = CIN == 128 && COUT == 128;                      // (keeps the other shapes from instantiating the form)
+        if (w4_seg2(H, W)) return w4_launch2<RES, CIN, COUT, SHUF, true, r>(x, w_packed, scale, shift, res1, res2, y, N, H, W, relu, flags, st, w_next);
+        return w4_launch2<RES, CIN, COUT, SHUF, false, r>(x, w_packed, scale, shift, res1, res2, y, N, H, W, relu, flags, st, w_next);
+    }
+    if (w4_seg2(H, W)) return w4_launch2<RES, CIN, COUT, SHUF, true, false>(x, w_packed, scale, shift, res1, res2, y, N, H, W, relu, flags, st, w_next);
+    return w4_launch2<RES, CIN, COUT, SHUF, false, false>(x, w_packed, scale, shift, res1, res2, y, N, H, W, relu, flags, st, w_next);
 }
 
 int icx_wino4_3x3_c128_next(const float* x, const float* w_packed, const float* scale, const float* shift, const float* res1, const float* res2,

@@ -16,10 +16,15 @@ The hand-written code keeps both by construction (operands come from LDS / buffe
 64-bit temporaries in the input transform it spilled / copied the four VGPR-resident accumulators (`scratch_store_dwordx4`,
 `v_mov_b64`) directly behind and in front of the MFMAs that own them -- wrong values whose place changed from launch to launch.
 Patching wait states for (A) and (B) into that assembly made it bit-exact again (0 of 150 launches against 150 of 150), (A) or (B)
-alone did not.  So: whatever flags or compiler produced the object, this audit proves the shipped ISA has neither pattern, and
-that nothing was spilled.
+alone did not.  So: whatever flags or compiler produced the object, this audit proves the shipped ISA has neither pattern.
+  (S) Spills: the code-object metadata of every audited kernel (`.vgpr_spill_count`, `.private_segment_fixed_size`) must show NO scratch
+      -- a spill is where the allocator's own instructions come from -- unless the kernel's name matches --allow-scratch (the
+      h12 phase-shuffle instantiations spill 1-4 registers in their epilogue, far from any MFMA; rules (A) / (B) still cover them).
+Control flow: the scan is linear, a backward branch is followed across its back edge and a FORWARD branch into its target (round 6:
+the 8-wave form skips its transform slices behind scalar branches -- the instructions skipped must not be counted as wait states),
+each with a copy of the state, for as many wait states as a hazard can span.
 
-usage: isa_audit.py file.s [--max-scratch BYTES-per-kernel-allowed-outside-the-MFMA-loops]   (exit 1 on a finding)
+usage: isa_audit.py file.s [--max-scratch BYTES] [--allow-scratch NAME-REGEX]   (exit 1 on a finding; BYTES per kernel, default 0)
 Wait states are counted the way LLVM does: every instruction 1, `s_nop N` N + 1."""
 import re, sys
 
@@ -97,28 +102,56 @@ def audit_kernel(name, body):
         # a backward branch: the first instructions of the loop body run again right behind the last ones -- follow the back edge
         # for as many wait states as a hazard can span, with a COPY of the state at the branch
         op, _, rest = s.partition(' ')
-        if op.startswith(('s_cbranch', 's_branch')) and rest.strip() in labels and labels[rest.strip()] < i:
+        if op.startswith(('s_cbranch', 's_branch')) and rest.strip() in labels:
+            back = labels[rest.strip()] < i
+            # (a taken FORWARD branch: the target's first instructions run right behind the branch, without the skipped ones)
+            tag = ' [across the back edge of the loop at {}]' if back else ' [behind the taken forward branch to {}]'
             age2, recent2 = dict(age), [list(e) for e in recent]
             states, j = 0, labels[rest.strip()]
-            while j < i and states < XDL_TO_ANY + 2:
+            while j < (i if back else len(body)) and states < XDL_TO_ANY + 2:
                 t = body[j]
                 j += 1
                 if t.endswith(':'):
                     continue
-                _step(t, age2, recent2, findings, ' [across the back edge of the loop at {}]'.format(rest.strip()))
+                if t.startswith(('s_cbranch', 's_branch', 's_endpgm')) and not back:
+                    break                                   # (the next branch forks its own copy when the linear scan reaches it)
+                _step(t, age2, recent2, findings, tag.format(rest.strip()))
                 states += int(t.split()[1], 0) + 1 if t.startswith('s_nop') else 1
     return n_mfma, findings
 
 
+def scratch_of(path):
+    """kernel name -> (private_segment_fixed_size, vgpr_spill_count) from the amdhsa metadata at the end of the assembly"""
+    out, name, priv = {}, None, 0
+    for ln in open(path):
+        m = re.match(r'\s+\.name:\s+(\S+)', ln)
+        if m: name, priv = m.group(1), 0
+        m = re.match(r'\s+\.private_segment_fixed_size:\s+(\d+)', ln)
+        if m: priv = int(m.group(1))
+        m = re.match(r'\s+\.vgpr_spill_count:\s+(\d+)', ln)
+        if m and name: out[name] = (priv, int(m.group(1)))
+    return out
+
+
 def main():
-    path = sys.argv[1]
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument('path')
+    ap.add_argument('--max-scratch', type=int, default=0)
+    ap.add_argument('--allow-scratch', default=None)
+    a = ap.parse_args()
+    path = a.path
     bad = 0
     audited = 0
+    scratch = scratch_of(path)
     for name, body in kernels(path):
         n_mfma, findings = audit_kernel(name, body)
         if not n_mfma: continue
         audited += 1
-        for rule in ('(A)', '(B)'):
+        priv, spilled = scratch.get(name, (0, 0))
+        if (priv > a.max_scratch or spilled) and not (a.allow_scratch and re.search(a.allow_scratch, name)):
+            findings.append('(S) {} bytes of scratch, {} register(s) spilled (limit {} bytes; --allow-scratch {})'.format(priv, spilled, a.max_scratch, a.allow_scratch))
+        for rule in ('(A)', '(B)', '(S)'):
             of_rule = [f for f in findings if f.startswith(rule)]
             for f in of_rule[:6]: print('%s: %s: %s' % (path, name, f))
             if len(of_rule) > 6: print('%s: %s: ... %d more of %s' % (path, name, len(of_rule) - 6, rule))

@@ -13,7 +13,7 @@
 // (a caller's side branch that needs its CUs for less than the whole stack).
 static inline int layer_flags(int flags, int li) {
     const int n = (flags >> 12) & 0x7f;
-    int f = flags & (0xfff | IC_CONV3_IN_FLIGHT(0xf) | IC_CONV3_NO_WINO4);
+    int f = flags & (0xfff | IC_CONV3_IN_FLIGHT(0xf) | IC_CONV3_NO_WINO4 | IC_CONV3_WINO4_BITS);
     if (n > 0 && li >= n) f &= ~IC_CONV3_LEAVE_IDLE_CUS;
     return f;
 }

@@ -183,8 +183,15 @@ class Fetcher(object):
 
     def enqueue(self, img_chw_uint8, want_symbols=False, want_image=False):
         """launch the whole path for one image on this fetcher's stream WITHOUT waiting for it: validate() keeps several
-        fetchers busy at once (the images are independent), collect() turns the device results into Python values."""
-        x_uint8 = torch.as_tensor(img_chw_uint8)[None]
+        fetchers busy at once (the images are independent), collect() turns the device results into Python values.
+        A LIST of same-shape images is evaluated as one batch (one pass of every kernel over all of them; the inference path has no
+        cross-image term -- BatchNorm is folded --, the measures are taken per image): collect() then returns a list."""
+        if isinstance(img_chw_uint8, (list, tuple)):
+            x_uint8 = torch.as_tensor(np.stack(img_chw_uint8))
+            batched = True
+        else:
+            x_uint8 = torch.as_tensor(img_chw_uint8)[None]
+            batched = False
         outer, main = torch.cuda.current_stream(self.device), self._streams.main
         main.wait_stream(outer)
         x_dev = None
@@ -198,10 +205,24 @@ class Fetcher(object):
                 x_dev = x_uint8.to(self.device)
             main.wait_stream(self._copy_stream)
         with torch.cuda.stream(main):
-            return self._measure(x_uint8, want_symbols, want_image, x_dev)
+            pending = self._measure(x_uint8, want_symbols, want_image, x_dev)
+        pending['batched'] = batched
+        return pending
 
     def collect(self, pending):
         main = self._streams.main
+        if 'device7xN' in pending['scalars']:
+            with torch.cuda.stream(main):
+                rows = pending['scalars']['device7xN'].tolist()            # ONE transfer for the whole batch
+                arrays = {k: v.cpu().numpy() for k, v in pending['arrays'].items()}
+            torch.cuda.current_stream(self.device).wait_stream(main)
+            outs = []
+            for i, v in enumerate(rows):
+                otp = {'bpp': float(np.float32(v[6])), 'ms-ssim': metrics.msssim_from_scale_values(v[:5]), 'psnr': metrics.psnr_from_mse(v[5])}
+                for k, arr in arrays.items():
+                    otp[k] = arr[i:i + 1]
+                outs.append(otp)
+            return outs if pending.get('batched') else outs[0]
         with torch.cuda.stream(main):
             sc = pending['scalars']
             if 'device7' in sc:
@@ -222,6 +243,8 @@ class Fetcher(object):
             x_uint8_dev = x_uint8.to(self.device, non_blocking=True)
         else:
             x_uint8_dev.record_stream(torch.cuda.current_stream(self.device))        # allocated on the copy stream, used on this one
+        if x_uint8.shape[0] > 1 and not self.host_metrics:
+            return self._measure_batch(x_uint8_dev, want_symbols, want_image)
         x = x_uint8_dev.float()
         enc = self.ae.encode(x, is_training=False)
         # decoder and context model are independent consumers of the encoder output: with a CU-range arrangement (streams.py) the
@@ -252,6 +275,26 @@ class Fetcher(object):
         if not self.host_metrics and torch.is_tensor(ms) and ms.is_cuda:
             return {'scalars': {'device7': torch.cat([ms, ps.reshape(1), bpp.reshape(1).to(torch.float64)])}, 'arrays': arrays}
         return {'scalars': {'bpp': bpp, 'ms-ssim': ms, 'psnr': ps}, 'arrays': arrays}
+
+    def _measure_batch(self, x_uint8_dev, want_symbols, want_image):
+        """B same-shape images through ONE pass of the codec; bpp, MS-SSIM terms and squared error per image -> [B, 7] on the device"""
+        x = x_uint8_dev.float()
+        B = int(x.shape[0])
+        enc = self.ae.encode(x, is_training=False)
+        bc = self.pc.bitcost(enc.qbar, enc.symbols, is_training=False, pad_value=self.pc.auto_pad_value(self.ae))
+        x_out = self.ae.decode(enc.qhard, is_training=False)
+        x_out_uint8_dev = x_out.to(torch.uint8)
+        rows = []
+        for i in range(B):
+            bpp = bits.bitcost_to_bpp(bc[i:i + 1], x[i:i + 1])
+            ms, ps = metrics.val_metrics_device(x_uint8_dev[i:i + 1], x_out_uint8_dev[i:i + 1], self._metrics_ws)
+            rows.append(torch.cat([ms, ps.reshape(1), bpp.reshape(1).to(torch.float64)]))
+        arrays = {}
+        if want_symbols:
+            arrays['sym'] = enc.symbols
+        if want_image:
+            arrays['img_out'] = x_out_uint8_dev
+        return {'scalars': {'device7xN': torch.stack(rows)}, 'arrays': arrays}
 
     def real_bpp(self, symbols, num_pixels):
         if self._bpp_fetcher is None:
@@ -284,12 +327,34 @@ def _decoded_ahead(image_paths, indices, pad, threads):
             yield idx, fut.result()
 
 
+def batch_size_for_shape(h, w, limit=8):
+    """how many images of one (padded) shape go into one step: as many as keep the step near a Kodak image's work -- 8 of 256 x 256,
+    2 of 384 x 512, 1 from 512 x 768 on (there 4 images in flight already fill the chip: bench.py, batch 2 x 2 in flight = batch 1 x 4)"""
+    return int(max(1, min(int(limit), (512 * 1024) // max(1, int(h) * int(w)))))
+
+
+def _same_shape_batches(decoded, limit):
+    """(index, image) in order -> lists [(index, image), ...] of CONSECUTIVE images of one shape, at most batch_size_for_shape of them:
+    the order of the images is the order of the batches' members"""
+    cur = []
+    for idx, img in decoded:
+        if cur and (img.shape != cur[0][1].shape or len(cur) >= batch_size_for_shape(img.shape[1], img.shape[2], limit)):
+            yield cur
+            cur = []
+        cur.append((idx, img))
+    if cur:
+        yield cur
+
+
 def validate(ae_config, pc_config, weights, image_paths, out_dir, flags, device='cuda', verbose=True, host_metrics=False,
-             in_flight=4, loader_threads=8):
+             in_flight=4, loader_threads=8, batch_same_shape=8):
     """-> dict of averages; writes out_dir/measures.csv (rank 0).
     in_flight: images of this rank processed concurrently, each by its own Fetcher (networks, workspace, stream): the images
     are independent (the reference runs one per sess.run, val.py:157-158), and the launches of one fill the kernel-boundary
-    bubbles of the others, and a 3x3 launch need not fill the chip alone (bench.py: 158 -> 183 Mpix/s on Kodak-sized images with 4).  --real_bpp codes one image at a time."""
+    bubbles of the others, and a 3x3 launch need not fill the chip alone (bench.py: 158 -> 183 Mpix/s on Kodak-sized images with 4).  --real_bpp codes one image at a time.
+    batch_same_shape: consecutive small images of one shape are evaluated as one batch (batch_size_for_shape: 8 of 256 x 256) -- one
+    step of a fetcher then carries the batch; rows of measures.csv and their order are those of the one-image-per-step loop (values
+    to the fp32 agreement of the plans the library picks for the two batch sizes: tests/test_gpu_network.py)."""
     from collections import deque
     rank, world = sharding.rank_and_world()
     n_f = 1 if (flags.real_bpp or host_metrics) else max(1, int(in_flight))
@@ -301,8 +366,12 @@ def validate(ae_config, pc_config, weights, image_paths, out_dir, flags, device=
     pending = deque()
 
     def finish():
-        idx, p, img, f, h = pending.popleft()
-        otp = f.collect(h)
+        members, f, h = pending.popleft()
+        outs = f.collect(h)
+        for (idx, img), otp in zip(members, outs if isinstance(outs, list) else [outs]):
+            finish_one(idx, image_paths[idx], img, f, otp)
+
+    def finish_one(idx, p, img, f, otp):
         if flags.real_bpp:
             bpp_real, bpp_theory = f.real_bpp(otp.pop('sym'), bpp_helpers.num_pixels_in_image(img))
             otp['bpp_real'], otp['bpp_theory'] = bpp_real, bpp_theory
@@ -316,12 +385,14 @@ def validate(ae_config, pc_config, weights, image_paths, out_dir, flags, device=
             save_img(path.basename(p), otp.pop('img_out'), out_dir)
         local.append((idx, (path.basename(p), otp)))
 
-    for k, (idx, img) in enumerate(_decoded_ahead(image_paths, list(sharding.shard_indices(len(image_paths), rank, world)), pad, loader_threads)):
-        p = image_paths[idx]
+    limit = 1 if (flags.real_bpp or host_metrics) else max(1, int(batch_same_shape))
+    decoded = _decoded_ahead(image_paths, list(sharding.shard_indices(len(image_paths), rank, world)), pad, loader_threads)
+    for k, members in enumerate(_same_shape_batches(decoded, limit)):
         f = fetchers[k % n_f]
         if len(pending) == n_f:
-            finish()                                  # the oldest image ran on this fetcher: its buffers are free again
-        pending.append((idx, p, img, f, f.enqueue(img, want_symbols=flags.real_bpp, want_image=flags.save_ours)))
+            finish()                                  # the oldest step ran on this fetcher: its buffers are free again
+        imgs = [img for _, img in members]
+        pending.append((members, f, f.enqueue(imgs if len(imgs) > 1 else imgs[0], want_symbols=flags.real_bpp, want_image=flags.save_ours)))
     while pending:
         finish()
     merged = sharding.gather_in_order(local, len(image_paths))
@@ -359,7 +430,17 @@ def load_weights_for_job(job_dir, weights_arg, ae_config, pc_config, restore_itr
     return tf_checkpoint.load_weights(p, itr=restore_itr)
 
 
+def default_loader_threads(world=None):
+    """host threads decoding PNGs ahead of the device: min(32, cores / ranks of this node), at least 1.  A Kodak-sized PNG takes one
+    core 7.7 ms to decode and the device path 1.5 ms: 8 threads fed 314 images/s, the device takes 514+."""
+    if world is None:
+        world = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1')) or 1)
+    return int(max(1, min(32, (os.cpu_count() or 1) // max(1, world))))
+
+
 def main(argv=None):
+    from . import ask_for_hardware_queues
+    ask_for_hardware_queues(8)          # several images in flight, one stream each: before the HIP runtime starts (package __init__)
     p = argparse.ArgumentParser()
     p.add_argument('log_dir_root', help='Path to dir containing log_dirs.')
     p.add_argument('job_ids', help='Comma separated list of job_ids.')
@@ -379,7 +460,11 @@ def main(argv=None):
     p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                    help='process group of a multi-rank run (nccl = RCCL, one GPU per rank; gloo lets ranks share a GPU in tests)')
     p.add_argument('--in_flight', type=int, default=4, help='images processed concurrently per GPU, one stream each (1 = one at a time)')
-    p.add_argument('--loader_threads', type=int, default=8, help='host threads decoding PNGs ahead of the device (1 = decode in the loop)')
+    p.add_argument('--loader_threads', type=int, default=None,
+                   help='host threads decoding PNGs ahead of the device (1 = decode in the loop; default: min(32, cores / ranks))')
+    p.add_argument('--batch_same_shape', type=int, default=8,
+                   help='consecutive images of one shape evaluated as ONE batch of up to this many when they are small (a 256 x 256 image '
+                        'alone fills an eighth of the chip); per-image measures and their order as without; 1 = never')
     flags, unknown = p.parse_known_args(argv)
     if unknown:
         print('Unknown flags: {}'.format(unknown))
@@ -414,7 +499,9 @@ def main(argv=None):
             sharding.barrier()
         avgs = validate(ae_config, pc_config, weights, image_paths, out_dir,
                         OutputFlags(flags.save_ours, -1, flags.real_bpp), device, host_metrics=bool(flags.host_metrics),
-                        in_flight=flags.in_flight, loader_threads=flags.loader_threads)
+                        in_flight=flags.in_flight,
+                        loader_threads=default_loader_threads() if flags.loader_threads is None else flags.loader_threads,
+                        batch_same_shape=flags.batch_same_shape)
         if sharding.rank_and_world()[0] == 0:
             print('Validation completed: {} | {}'.format(out_dir, avgs))
     print('*** All given job_ids validated.')

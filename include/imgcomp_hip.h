@@ -60,7 +60,10 @@ typedef void* ic_stream_t;
                                             TUNING builds only */
 #define IC_CONV3_WINO4            0x0b   /* Winograd F(4x4,3x3) (conv3x3_wino4.hip; W % 4 == 0, else the F(2x2) plan) */
 #define IC_CONV3_NO_WINO4         0x800000   /* automatic plan: F(2x2) forms only (A/B runs, bit-identity tests between F(2x2) forms) */
-#define IC_CONV3_WINO4_BITS       0          /* (no flag bits of its own besides the form) */
+#define IC_CONV3_WINO4_WG8        0x8000000  /* F(4x4) kernel: ONE 8-wave work-group per segment covers all 128 output channels (the input
+                                              transform is made once per segment instead of once per 64-channel half); bit-identical to the
+                                              4-wave form.  A/B runs and tests; the plan's own choice: ic_wino4_3x3_c128_form */
+#define IC_CONV3_WINO4_BITS       IC_CONV3_WINO4_WG8
 /* h2 / h12 of the whole-network entry points (ic_ae_encode_f32 / ic_ae_decode_f32): their filter blobs were packed by
  * ic_pack_conv5s2_both_f32 (MFMA fragments followed by the F(4x4)-over-phases fragments), so the library may run them on the
  * F(4x4) kernel where ic_conv3x3_c128_pick_form picks it for the residual stack of the same call or h2's launch has >= 160
@@ -341,6 +344,11 @@ int ic_bn_train_forward_f32(const float* x, const float* gamma, const float* bet
  * data gradient is the transposed conv with the same TF filter array and vice versa; the 3x3 stride-1 case takes
  * ic_pack_conv3x3_c128_bwd_f32).  Filter gradients: ic_conv2d_wgrad_f32.
  * ============================================================================================= */
+/* Workspace of the BatchNorm entry points (ic_bn_stats_f32, ic_bn_train_stats_f32, ic_bn_train_forward_f32, ic_bn_moments_f32,
+ * ic_bn_backward_reduce_f32, ic_bn_backward_f32): each call is TWO launches that communicate through it -- the first writes per-block
+ * partial sums [C][blocks][0..3], the second (the element-wise kernel included) re-reads them in every work-group.  A workspace
+ * must therefore NOT be shared by calls that can overlap in time: one per stream (calls on one stream are ordered and may
+ * share one, as imgcomp_cvpr_amd/training.py does with its single compute stream).  Sharing across streams is a silent race. */
 size_t ic_bn_workspace_bytes(int C);
 /* batch mean and BIASED variance per channel of x (N,C,HW) (autoencoder.py:114-125, is_training=True) */
 int ic_bn_stats_f32(const float* x, float* mean, float* var, int N, int C, int HW, void* workspace, ic_stream_t stream);

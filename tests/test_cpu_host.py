@@ -198,15 +198,61 @@ def test_val_decodes_images_ahead_in_order(tmp_path):
     assert list(val._decoded_ahead(paths, [], 8, 4)) == []
 
 
-def test_package_asks_for_enough_hardware_queues():
+def test_val_batches_consecutive_same_shape_images_in_order():
+    """val.py evaluates consecutive small images of one shape as one batch: the batches' members, read in order, are the image list
+    in order; a shape change or the per-shape limit closes a batch; Kodak-sized images stay alone."""
+    from imgcomp_cvpr_amd import val
+    assert val.batch_size_for_shape(256, 256) == 8 and val.batch_size_for_shape(512, 768) == 1 and val.batch_size_for_shape(384, 512) == 2
+    assert val.batch_size_for_shape(64, 64) == 8 and val.batch_size_for_shape(64, 64, limit=3) == 3 and val.batch_size_for_shape(2160, 3840) == 1
+    shapes = [(256, 256)] * 11 + [(512, 768)] * 3 + [(256, 256)] * 2 + [(256, 264)] + [(256, 256)]
+    decoded = [(7 * i % 1000, np.zeros((3,) + sh, np.uint8)) for i, sh in enumerate(shapes)]
+    got = list(val._same_shape_batches(iter(decoded), 8))
+    assert [len(b) for b in got] == [8, 3, 1, 1, 1, 2, 1, 1]
+    assert [i for b in got for i, _ in b] == [i for i, _ in decoded]
+    assert all(len({m[1].shape for m in b}) == 1 for b in got)
+    assert [len(b) for b in val._same_shape_batches(iter(decoded), 1)] == [1] * len(shapes)
+    assert list(val._same_shape_batches(iter([]), 8)) == []
+
+
+def test_val_loader_threads_default_follows_the_host():
+    from imgcomp_cvpr_amd import val
+    import os
+    n = os.cpu_count() or 1
+    assert val.default_loader_threads(1) == max(1, min(32, n))
+    assert val.default_loader_threads(8) == max(1, min(32, n // 8))
+    assert val.default_loader_threads(10 ** 6) == 1
+
+
+def test_only_the_entry_points_ask_for_hardware_queues():
     """the images in flight (val.py --in_flight, bench.py) have one stream each and the HIP runtime maps all streams onto
-    GPU_MAX_HW_QUEUES hardware queues, 4 by default: importing the package asks for 8 unless the caller has decided."""
+    GPU_MAX_HW_QUEUES hardware queues, 4 by default.  Importing the package leaves the environment alone (a training rank keeps the
+    runtime's default); the entry points that keep images in flight ask for more unless the caller has decided."""
     import subprocess
     import sys
-    code = 'import os; os.environ.pop("GPU_MAX_HW_QUEUES", None); import imgcomp_cvpr_amd; print(os.environ["GPU_MAX_HW_QUEUES"])'
-    assert subprocess.check_output([sys.executable, '-c', code], cwd=ROOT).decode().strip() == '8'
-    code = 'import os; os.environ["GPU_MAX_HW_QUEUES"] = "2"; import imgcomp_cvpr_amd; print(os.environ["GPU_MAX_HW_QUEUES"])'
-    assert subprocess.check_output([sys.executable, '-c', code], cwd=ROOT).decode().strip() == '2'
+    code = 'import os; os.environ.pop("GPU_MAX_HW_QUEUES", None); import imgcomp_cvpr_amd, imgcomp_cvpr_amd.training; print(os.environ.get("GPU_MAX_HW_QUEUES"))'
+    assert subprocess.check_output([sys.executable, '-c', code], cwd=ROOT).decode().strip() == 'None'
+    code = ('import os; os.environ.pop("GPU_MAX_HW_QUEUES", None); import imgcomp_cvpr_amd as P; a = P.ask_for_hardware_queues(8); '
+            'os.environ["GPU_MAX_HW_QUEUES"] = "2"; print(a, P.ask_for_hardware_queues(8))')
+    assert subprocess.check_output([sys.executable, '-c', code], cwd=ROOT).decode().strip() == '8 2'
+    src = open(os.path.join(ROOT, 'imgcomp_cvpr_amd', 'val.py')).read()
+    assert 'ask_for_hardware_queues(8)' in src.split('def main(argv=None):')[1][:300]
+    assert "os.environ.setdefault('GPU_MAX_HW_QUEUES'" in open(os.path.join(ROOT, 'bench.py')).read()
+
+
+def test_training_wino4_mode_is_validated_per_graph(monkeypatch):
+    """IMGCOMP_TRAIN_WINO4 is read when a TrainGraph is built (not at import), case- and spelling-tolerant, and a bad value names itself"""
+    from imgcomp_cvpr_amd import training
+    monkeypatch.delenv('IMGCOMP_TRAIN_WINO4', raising=False)
+    assert training.wino4_mode() is True                         # default: both directions
+    for v, want in (('0', False), ('', False), ('1', True), ('True', True), (' both ', True), ('2', True), ('FWD', 'fwd'), ('bwd', 'bwd'),
+                    (True, True), (False, False)):
+        assert training.wino4_mode(v) == want, v
+    monkeypatch.setenv('IMGCOMP_TRAIN_WINO4', 'Bwd')
+    assert training.wino4_mode() == 'bwd'
+    monkeypatch.setenv('IMGCOMP_TRAIN_WINO4', 'sideways')
+    with pytest.raises(ValueError, match='IMGCOMP_TRAIN_WINO4'):
+        training.wino4_mode()
+    assert not hasattr(training.TrainGraph, 'WINO4')              # no class-level (process-wide) setting
 
 
 def test_abi_header_bindings_and_exports_agree():
@@ -726,8 +772,12 @@ def test_isa_audit_is_part_of_the_build_and_the_shipped_assembly_is_clean():
         s = os.path.join(csrc, f + '.audit.s')
         if not os.path.exists(s):
             pytest.skip('library not built in this checkout')
-        r = subprocess.run([sys.executable, os.path.join(csrc, 'isa_audit.py'), s], stdout=subprocess.PIPE, universal_newlines=True)
+        import re
+        m = re.search(r"AUDIT_ARGS_{} := (.*)".format(f), mk)
+        extra = [t.strip("'") for t in m.group(1).split()] if m else []
+        r = subprocess.run([sys.executable, os.path.join(csrc, 'isa_audit.py'), s] + extra, stdout=subprocess.PIPE, universal_newlines=True)
         assert r.returncode == 0 and ' 0 finding(s)' in r.stdout, r.stdout[-2000:]
+    assert 'isa_audit.py $*.audit.s $(AUDIT_ARGS_$*)' in mk
 
 
 # ---- tools/pin_reference.py: the one command for the day a TF-written checkpoint arrives (N1) ----
@@ -876,6 +926,56 @@ def test_isa_audit_follows_loop_back_edges(tmp_path):
     assert not _audit(tmp_path, ok)
     vb = ('.LBB0_2:\n\tv_mfma_f32_16x16x4_f32 a[0:3], v25, v33, a[0:3]\n\ts_nop 15\n\tv_fma_f32 v33, v1, v2, v3\n\ts_cbranch_scc1 .LBB0_2\n')
     assert any('(B)' in x and 'back edge' in x for x in _audit(tmp_path, vb))
+
+
+def test_isa_audit_follows_taken_forward_branches_and_reads_the_spill_metadata(tmp_path):
+    """round 6: the 8-wave F(4x4) form skips its transform slices behind scalar branches.  The skipped instructions are not wait states:
+    a hazard that only exists when the branch is TAKEN is found; and a kernel whose metadata reports scratch is a finding of its own
+    unless its name is allow-listed (the documented guarantee `nothing was spilled` is now enforced: ADVICE r5)."""
+    mf = '\tv_mfma_f32_16x16x4_f32 v[38:41], v25, v33, v[38:41]\n'
+    pad12 = ''.join('\tv_add_f32_e32 v{}, 1.0, v{}\n'.format(60 + i, 60 + i) for i in range(12))
+    # linear scan: 12 VALU instructions separate the MFMA from the read of its result; taken branch: nothing does
+    skip = mf + '\ts_cbranch_vccnz .LBB0_5\n' + pad12 + '.LBB0_5:\n\tv_add_f32_e32 v38, 1.0, v38\n'
+    f = _audit(tmp_path, skip)
+    assert any('(A)' in x and 'forward branch' in x for x in f), f
+    assert not _audit(tmp_path, mf + '\ts_nop 11\n\ts_cbranch_vccnz .LBB0_5\n' + pad12 + '.LBB0_5:\n\tv_add_f32_e32 v38, 1.0, v38\n')
+    # (B) across a taken forward branch
+    vb = '\tv_fma_f32 v33, v1, v2, v3\n\ts_cbranch_scc1 .LBB0_6\n\ts_nop 3\n.LBB0_6:\n' + mf
+    assert any('(B)' in x and 'forward branch' in x for x in _audit(tmp_path, vb))
+    # (S) the metadata
+    sys.path.insert(0, os.path.join(ROOT, 'imgcomp_cvpr_amd', 'csrc'))
+    import isa_audit
+    meta = ('amdhsa.kernels:\n  - .args: []\n    .name:           _Z1kv\n    .private_segment_fixed_size: 24\n    .sgpr_count:     10\n'
+            '    .vgpr_count:     256\n    .vgpr_spill_count: 5\n')
+    p = tmp_path / 'm.s'
+    p.write_text(_AUDIT_HEAD + mf + _AUDIT_TAIL + meta)
+    assert isa_audit.scratch_of(str(p)) == {'_Z1kv': (24, 5)}
+    script = os.path.join(ROOT, 'imgcomp_cvpr_amd', 'csrc', 'isa_audit.py')
+    r = subprocess.run([sys.executable, script, str(p)], stdout=subprocess.PIPE, universal_newlines=True)
+    assert r.returncode == 1 and '(S) 24 bytes of scratch, 5 register(s) spilled' in r.stdout
+    r = subprocess.run([sys.executable, script, str(p), '--allow-scratch', '_Z1k'], stdout=subprocess.PIPE, universal_newlines=True)
+    assert r.returncode == 0 and ' 0 finding(s)' in r.stdout
+
+
+def test_bench_training_flop_count_matches_the_survey_figures():
+    """bench.py's executed-FLOP count of a training step (the `roofline` of extra.train / --mode train) from the layer table: in direct
+    form it is SURVEY 8(d)'s per-pixel figures x 3 passes (h1 has no data gradient), and the Winograd forms scale the 64 3x3 layers only"""
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    from imgcomp_cvpr_amd import weights as W
+    g = types.SimpleNamespace(C=32, B=5, L=6, k=24, heatmap=True, _w3_f4=(False, False))
+    N, H, Wd = 2, 64, 96
+    px, sym = N * H * Wd, N * 32 * (H // 8) * (Wd // 8)
+    ex, direct = bench.train_step_flops(W, g, N, H, Wd)
+    want = 3 * (bench.FLOP_PER_PX_ENC + bench.FLOP_PER_PX_DEC) * px - 2400.0 * px + 3 * bench.FLOP_PER_SYMBOL_PC * sym
+    assert abs(direct - want) < 1e-6 * want, (direct, want)
+    c3 = 2 * 589824.0 * px                                         # the 64 3x3 layers, one pass, direct form
+    rest = direct - 3 * c3 - 3 * bench.FLOP_PER_SYMBOL_PC * sym
+    assert abs(ex - (rest + c3 * 3 * 16.0 / 36.0 + 3 * bench.FLOP_PER_SYMBOL_PC_LIVE * sym)) < 1e-6 * ex
+    g._w3_f4 = (True, True)
+    ex4, _ = bench.train_step_flops(W, g, N, H, Wd)
+    assert abs(ex4 - (rest + c3 * (0.25 + 0.25 + 16.0 / 36.0) + 3 * bench.FLOP_PER_SYMBOL_PC_LIVE * sym)) < 1e-6 * ex4
 
 
 def test_profile_evidence_is_self_consistent():

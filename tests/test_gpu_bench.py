@@ -35,6 +35,8 @@ def test_bench_two_ranks_inference(cuda):
     assert out['roofline'] is not None and 0 < out['roofline']['frac'] <= 1
     assert out['cpu_baseline'] is None                              # N = 1 only
     assert len(out['shapes']) == 2
+    # the line verifies its own world: every rank took part in a collective, and where each of them ran
+    assert out['ranks']['rccl_ranks_seen'] == 2 and out['ranks']['dist_world_size'] == 2 and len(out['ranks']['devices']) == 2
 
 
 def test_bench_two_ranks_training_weak_and_strong(cuda):

@@ -513,6 +513,39 @@ def test_images_in_flight_plan_hint(cuda, nets, configs, syn_weights):
         assert torch.equal(s0, s1) and torch.equal(z0, z1) and torch.equal(o0, o1)
 
 
+def test_val_batches_small_same_shape_images(cuda, tmp_path):
+    """a directory of small images of one shape: val.py evaluates consecutive same-shape images as one batch of
+    up to 8 -- the rows of measures.csv, their order and the saved reconstructions are those of the one-image-per-step loop
+    (`--batch_same_shape 1`); values agree to the fp32 agreement of the plans the two batch sizes run (no cross-image term exists
+    in the inference path), a shape change closes a batch."""
+    from PIL import Image
+    from imgcomp_cvpr_amd import val, weights as W
+    imgs = tmp_path / 'small'
+    imgs.mkdir()
+    shapes = [(128, 128)] * 10 + [(104, 136)] + [(128, 128)] * 2
+    for i, (h, w) in enumerate(shapes):
+        im = W.synthetic_image((1, 3, h, w), 'natural', seed=60 + i)[0].transpose(1, 2, 0)
+        Image.fromarray(im).save(str(imgs / 'img{:02d}.png'.format(i)))
+    root = tmp_path / 'logs'
+    (root / '0515_1103 ae_configs@cvpr@low pc_configs@cvpr@res_shallow').mkdir(parents=True)
+    out = root / '0515_1103 small'
+    rows, saved = {}, {}
+    for mode in ('1', '8'):
+        val.main([str(root), '0515_1103', str(imgs), '--weights', 'synthetic', '--reset', '--save_ours', '--batch_same_shape', mode, '--in_flight', '2'])
+        rows[mode] = [r.split(',') for r in (out / 'measures.csv').read_text().strip().split('\n')]
+        saved[mode] = [np.asarray(Image.open(str(out / 'imgs' / 'img{:02d}.png'.format(i)))).astype(np.int32) for i in range(len(shapes))]
+    assert len(rows['1']) == len(rows['8']) == len(shapes) + 1 and rows['1'][0] == rows['8'][0]
+    for a_, b_ in zip(rows['1'][1:], rows['8'][1:]):
+        assert a_[0] == b_[0]                                                     # same image in the same row
+        assert abs(float(a_[1]) - float(b_[1])) < 1e-4 * max(1.0, float(a_[1]))   # bpp
+        assert abs(float(a_[2]) - float(b_[2])) < 1e-4 and abs(float(a_[3]) - float(b_[3])) < 1e-2
+    for a_, b_ in zip(saved['1'], saved['8']):
+        assert a_.shape == b_.shape and np.abs(a_ - b_).max() <= 1 and (a_ != b_).mean() < 1e-3
+    # the grouping that produced the batched rows: 8 + 2 | 1 | 2
+    got = [len(b) for b in val._same_shape_batches(((i, np.zeros((3, -(-h // 8) * 8, -(-w // 8) * 8), np.uint8)) for i, (h, w) in enumerate(shapes)), 8)]
+    assert got == [8, 2, 1, 2]
+
+
 def test_val_two_ranks_share_the_images(cuda, tmp_path):
     """multi-GPU inference as val.py does it (image-sharded, no data-path collective, one gather of the per-image
     scalars): two ranks under torch.distributed.run -- on this box's one GPU, so gloo and --device cuda:0 -- write the same

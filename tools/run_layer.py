@@ -9,7 +9,8 @@ import torch
 from imgcomp_cvpr_amd import _lib
 
 FORMS = {'auto': 0, 'wholek': _lib.CONV3_WINO_WHOLEK, 'ksplit': _lib.CONV3_WINO_KSPLIT, 't16': _lib.CONV3_WINO_T16, 'seg1': _lib.CONV3_WINO_SEG1,
-         'seg2': _lib.CONV3_WINO_SEG2, 'seg3': _lib.CONV3_WINO_SEG3, 'direct': _lib.CONV3_DIRECT}
+         'seg2': _lib.CONV3_WINO_SEG2, 'seg3': _lib.CONV3_WINO_SEG3, 'direct': _lib.CONV3_DIRECT,
+         'w4': _lib.CONV3_WINO4, 'w4wg8': _lib.CONV3_WINO4 | _lib.CONV3_WINO4_WG8}
 p = argparse.ArgumentParser()
 p.add_argument('--form', default='auto')
 p.add_argument('--n', type=int, default=1)

@@ -23,8 +23,7 @@ names = [n for n in p if p[n].grad is not None]
 out = {}
 xd = torch.as_tensor(x).float().to(dev)
 for m in modes:
-    training.TrainGraph.WINO4 = {'0': False, '1': True, 'fwd': 'fwd', 'bwd': 'bwd'}[m]
-    g = training.TrainGraph(ae, pc, wts, dev)
+    g = training.TrainGraph(ae, pc, wts, dev, wino4=m)
     g.forward_backward(xd)
     torch.cuda.synchronize()
     flips = int((g.last['symbols'].cpu() != comps['symbols']).sum())

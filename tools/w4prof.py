@@ -1,11 +1,12 @@
 """in-kernel stamps of the F(4x4) kernel (needs a build with -DW4_STAMPS: tools/build_variants.sh conv3x3_wino4.hip st="-fno-slp-vectorize -DW4_STAMPS"):
 prologue / loop / epilogue shader clocks per wave, and the TURNOVER of a wave slot: the clocks between the end of one work-group's wave and
 the first instruction of the next wave on the same slot (same XCC, SE, CU, SIMD, wave id -- they share a clock).
-   IMGCOMP_HIP_LIB=.../variants/lib_st.so python tools/w4prof.py [N H W]"""
+   IMGCOMP_HIP_LIB=.../variants/lib_st.so [W4_FLAGS=0x8000000] python tools/w4prof.py [N H W]        (W4_FLAGS: per-call plan flags, e.g. IC_CONV3_WINO4_WG8)"""
 import os, sys, ctypes
 from collections import defaultdict
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 exec(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'wino4_check.py')).read().split("torch.set_num_threads(16)")[0])
+FLAGS = int(os.environ.get('W4_FLAGS', '0'), 0)
 wgs = int(lib.ic_wino4_3x3_c128_workgroups(N, H, W))
 raw = ctypes.CDLL(L.LIB_PATH)
 buf = torch.zeros((wgs * 4, 6), dtype=torch.int64, device=dev)
@@ -14,7 +15,7 @@ yy = torch.empty((N, 128, H, W), device=dev)
 
 
 def go():
-    L.check(lib.ic_wino4_3x3_c128_bn_act_f32(L.ptr(xd), L.ptr(wp4), L.ptr(scd), L.ptr(shd), L.ptr(r1d), None, L.ptr(yy), N, H, W, 1, 0, L.current_stream(dev)))
+    L.check(lib.ic_wino4_3x3_c128_bn_act_f32(L.ptr(xd), L.ptr(wp4), L.ptr(scd), L.ptr(shd), L.ptr(r1d), None, L.ptr(yy), N, H, W, 1, FLAGS, L.current_stream(dev)))
 
 
 for _ in range(5):
@@ -27,6 +28,7 @@ e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / 20 * 1e3
 b = buf.cpu().numpy()
+print('flags %#x' % FLAGS)
 print('%d waves: prologue %.0f  loop %.0f  epilogue %.0f clocks (means); loop min %d max %d; ideal MFMA issue 36864 per wave; %.1f us per launch (events)' % (
     b.shape[0], b[:, 0].mean(), b[:, 1].mean(), b[:, 2].mean(), b[:, 1].min(), b[:, 1].max(), us))
 slots = defaultdict(list)
