@@ -25,7 +25,8 @@ CONV3_WINO_KSPLIT, CONV3_WINO_T16, CONV3_WINO_SEG1, CONV3_WINO_SEG2, CONV3_WINO_
 CONV3_WINO_PAIR = 10
 CONV3_WINO4 = 11                    # Winograd F(4x4,3x3)
 CONV3_NO_WINO4 = 0x800000
-CONV3_WINO4_WG8 = 0x8000000
+CONV3_WINO4_WG8 = 0x8000000       # F(4x4) kernel: 8-wave work-groups (all 128 channels of a segment)
+CONV3_WINO4_WG4 = 0x10000000      # F(4x4) kernel: always the 4-wave form
 CONV5_BOTH_PACKED = 0x1000000         # h2 / h12 blobs carry the F(4x4)-over-phases fragments too (ic_pack_conv5s2_both_f32)
 CONV5_WINO4 = 0x2000000               # h2 / h12 on the F(4x4) kernel wherever the shape allows
 CONV5_NO_WINO4 = 0x4000000
@@ -120,6 +121,7 @@ PROTOTYPES = {
     'ic_pack_wino4_3x3_c128_batch_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'ic_wino4_3x3_c128_supported': (c_int, [c_int, c_int, c_int]),
     'ic_wino4_3x3_c128_workgroups': (c_longlong, [c_int, c_int, c_int]),
+    'ic_wino4_3x3_c128_waves': (c_int, [c_int, c_int, c_int, c_int]),
     'ic_wino4_3x3_c128_bn_act_f32': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
     'ic_wino4_conv5s2_packed_floats': (c_size_t, []),
     'ic_pack_wino4_conv5s2_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),

@@ -90,6 +90,10 @@
 #ifndef W4_SOFT
 #define W4_SOFT 0                                   // 1: two barriers per iteration between MFMA quads (B1 / B2 below); 0: one at its end (measured equal: below)
 #endif
+#ifndef W4_WG8_FLAGS
+#define W4_WG8_FLAGS 1                              // 8-wave form: 1 = the ring's two hazards are kept by LDS sequence counters (no barrier inside the loop), 0 = one 512-thread barrier per iteration
+#endif
+#define W4_WG8_SPINS (1 << 16)                      // bound of a counter poll (~100 clocks each): a miscount gives wrong values, never a hung GPU
 #define W4_B1 29
 #define W4_B2 8
 #ifndef W4_SPREAD
@@ -244,6 +248,7 @@ void wino4_3x3_kernel(const WnArgs a) {
     constexpr int KS = CIN / 4, IT = KS / 4, PARTS = COUT / (16 * WAVES);   // k-steps, iterations of 4 k-steps, work-groups per segment
     __shared__ f32x4 ring[2 * 4 * W4_QUADS * 64];                 // [half][k-step of the iteration][position quad][lane]: 72 KB
     __shared__ float pf_sink[64];                                 // where the prefetch below lands (never read)
+    __shared__ unsigned w8_flag[4];                               // WG8: [h] = producer waves that completed ring half h, [2 + h] = waves that finished reading it (running totals)
 #ifdef W4_STAMPS
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -425,6 +430,35 @@ void wino4_3x3_kernel(const WnArgs a) {
         asm volatile("" : "=v"(sp)); asm volatile("" : "=v"(sq)); asm volatile("" : "=v"(sr)); asm volatile("" : "=v"(se));
         asm volatile("" : "=v"(sa)); asm volatile("" : "=v"(sh4)); asm volatile("" : "=v"(sh5));
     };
+    // WG8 without a barrier in the loop (W4_WG8_FLAGS): the two hazards of the ring as running counters in LDS.
+    //   RAW  the 4 producing waves of a half add 1 to w8_flag[half] behind their last ring write (LDS executes a wave's operations in
+    //        order: the add lands behind the writes); a wave starts iteration j -- reads half j & 1 -- once w8_flag[j & 1] >= 4 ((j + 1) >> 1);
+    //   WAR  every wave adds 1 to w8_flag[2 + half] behind its last read of the half; a producer writes half h in iteration j (for j + 1)
+    //        once w8_flag[2 + h] >= 8 ((j + 1) >> 1): everybody has finished iteration j - 1.
+    // A wave is then held only by the waves it really depends on, 8 and 25 quads after they got there (the slack the barriers B1 / B2
+    // describe), instead of meeting all seven others at the end of every iteration -- under the barrier the stamps show the waves of the
+    // 8-wave form parked 31 k clocks of their 110 k (4-wave form: 8 k of 100 k; profiles/r06_w4_wg8.md).
+    // One lane signals (exec = 1 around a ds_add_u32); the poll is bounded (W4_WG8_SPINS).
+    const unsigned w8_base = (unsigned)(size_t)w8_flag;
+    auto flag_add = [&](int k) __attribute__((always_inline)) {
+        asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" :: "v"(w8_base + 4u * k), "v"(1u) : "memory");
+    };
+    // (the poll is ONE asm statement: a C++ loop inside the unrolled quad loop keeps the compiler from unrolling it -- the register rings
+    // become indexed arrays in scratch: tried)
+    auto flag_wait = [&](int k, unsigned target) __attribute__((always_inline)) {
+        unsigned v, sv, spins;
+        asm volatile("s_mov_b32 %2, 0\n"
+                     "1:\tds_read_b32 %0, %3\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "v_readfirstlane_b32 %1, %0\n\t"
+                     "s_add_u32 %2, %2, 1\n\t"
+                     "s_cmp_ge_u32 %1, %4\n\t"
+                     "s_cbranch_scc1 2f\n\t"
+                     "s_cmp_lt_u32 %2, %5\n\t"
+                     "s_cbranch_scc1 1b\n"
+                     "2:"
+                     : "=&v"(v), "=&s"(sv), "=&s"(spins) : "v"(w8_base + 4u * k), "s"(target), "i"(W4_WG8_SPINS) : "memory", "scc");
+    };
     // filter fragments: quad index Q = ks * 9 + q of this wave's channel tile: 1 KB per quad
     f32x4 fa[W4_RA];
     auto load_filter = [&](int slot, int Q) __attribute__((always_inline)) {       // slot = Q % W4_RA, passed as a constant
@@ -501,6 +535,7 @@ void wino4_3x3_kernel(const WnArgs a) {
         }
     }
     if (!WG8 || grp == 0) transform_put(0);
+    if (WG8 && W4_WG8_FLAGS && threadIdx.x < 4) w8_flag[threadIdx.x] = 0u;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -527,6 +562,7 @@ void wino4_3x3_kernel(const WnArgs a) {
     for (int q0 = 0; q0 < W4_RB - 1; ++q0) bq[q0] = ring_rd(0, q0);
     // `produce`: this wave prepares its k-step of the next iteration in this one (always in the 4-wave form; WG8: the group of the next half)
     auto iteration = [&](const int j, const int u2, const bool last, const bool produce) __attribute__((always_inline)) {      // reads ring half u2
+        if (WG8 && W4_WG8_FLAGS && j > 0) flag_wait(u2, 4u * ((unsigned)(j + 1) >> 1));       // RAW: this half is complete
         if (!W4_SOFT && j > 0) {
 #pragma unroll
             for (int q0 = 0; q0 < W4_RB - 1; ++q0) bq[q0] = ring_rd(u2, q0);
@@ -543,8 +579,10 @@ void wino4_3x3_kernel(const WnArgs a) {
                 if (WG8 && !last && sk == 0 && i == 0) kill_slices();       // (see kill_slices)
                 if (W4_SPREAD && produce && !(W4_ABL & 4) && i < (W4_SLICE1 ? 1 : 2) && sk >= 0 && sk < 13) {      // (W4_ABL & 4: no transform at all)
                     __builtin_amdgcn_sched_barrier(0);
+                    if (WG8 && W4_WG8_FLAGS && sk == 7 && i == 0) flag_wait(2 + (u2 ^ 1), 8u * ((unsigned)(j + 1) >> 1));   // WAR: before the first ring write
                     slice(sk, i, u2 ^ 1);
                     if (W4_SLICE1) slice(sk, 1, u2 ^ 1);
+                    if (WG8 && W4_WG8_FLAGS && sk == 12 && i == (W4_SLICE1 ? 0 : 1)) flag_add(u2 ^ 1);                        // RAW: behind the last ring write
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -569,9 +607,10 @@ void wino4_3x3_kernel(const WnArgs a) {
                 __builtin_amdgcn_s_barrier();
             }
             if (W4_SOFT && !last && lq == W4_B2 && j > 0) __builtin_amdgcn_s_barrier();      // the other half has been read by everybody
+            if (WG8 && W4_WG8_FLAGS && !last && lq == 36 - W4_RB + 1) flag_add(2 + u2);      // WAR: behind this wave's last read of the half (quad 35's operands: requested at 36 - W4_RB)
             __builtin_amdgcn_sched_barrier(0);                    // quads stay in program order: the rings are sized for exactly that
         }
-        if (!W4_SOFT) {
+        if (!W4_SOFT && !(WG8 && W4_WG8_FLAGS)) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                         // next half complete, this half read by everybody
         }
@@ -775,6 +814,16 @@ extern "C" long long ic_wino4_3x3_c128_workgroups(int N, int H, int W) {
     return 2ll * N * w4_segments(H, W, w4_seg2(H, W));
 }
 
+// waves per work-group of the residual layers' launch: 8 (one work-group per segment, all 128 channels) where the caller asks for it
+// (IC_CONV3_WINO4_WG8) or the launch has >= 2048 four-wave work-groups (a 4K map: +1 - 1.5 %, profiles/r06_w4_wg8.md), 4 otherwise
+// and always with IC_CONV3_WINO4_WG4 or on maps with 2 x 8-tile segments
+extern "C" int ic_wino4_3x3_c128_waves(int N, int H, int W, int flags) {
+    if (!ic_wino4_3x3_c128_supported(N, H, W)) return 0;
+    if ((flags & IC_CONV3_WINO4_WG4) || w4_seg2(H, W)) return 4;
+    if (flags & IC_CONV3_WINO4_WG8) return 8;
+    return ic_wino4_3x3_c128_workgroups(N, H, W) >= 2048 ? 8 : 4;
+}
+
 template <int RES, int CIN, int COUT, bool SHUF, bool SEG2, bool WG8>
 static int w4_launch2(const float* x, const float* w_packed, const float* scale, const float* shift, const float* res1, const float* res2,
                       float* y, int N, int H, int W, int relu, int flags, hipStream_t st, const float* w_next = nullptr) {
@@ -809,9 +858,11 @@ static int w4_launch2(const float* x, const float* w_packed, const float* scale,
 template <int RES, int CIN, int COUT, bool SHUF>
 static int w4_launch(const float* x, const float* w_packed, const float* scale, const float* shift, const float* res1, const float* res2,
                      float* y, int N, int H, int W, int relu, int flags, hipStream_t st, const float* w_next = nullptr) {
-    if (CIN == 128 && COUT == 128 && (flags & IC_CONV3_WINO4_WG8)) {      // 128-channel work-groups: the residual layers only
+    // 128-channel work-groups: the residual layers on maps with 1 x 16-tile segments only (the 2 x 8 segments of narrow maps carry per-lane
+    // row conditions: with the counters' registers on top the allocator spills two of them -- isa_audit.py rule (S) -- and a map that narrow
+    // has too few segments for one-work-group-per-CU launches anyway)
+    if (CIN == 128 && COUT == 128 && ic_wino4_3x3_c128_waves(N, H, W, flags) == 8) {
         constexpr bool r = CIN == 128 && COUT == 128;                      // (keeps the other shapes from instantiating the form)
-        if (w4_seg2(H, W)) return w4_launch2<RES, CIN, COUT, SHUF, true, r>(x, w_packed, scale, shift, res1, res2, y, N, H, W, relu, flags, st, w_next);
         return w4_launch2<RES, CIN, COUT, SHUF, false, r>(x, w_packed, scale, shift, res1, res2, y, N, H, W, relu, flags, st, w_next);
     }
     if (w4_seg2(H, W)) return w4_launch2<RES, CIN, COUT, SHUF, true, false>(x, w_packed, scale, shift, res1, res2, y, N, H, W, relu, flags, st, w_next);

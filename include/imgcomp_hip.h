@@ -62,8 +62,9 @@ typedef void* ic_stream_t;
 #define IC_CONV3_NO_WINO4         0x800000   /* automatic plan: F(2x2) forms only (A/B runs, bit-identity tests between F(2x2) forms) */
 #define IC_CONV3_WINO4_WG8        0x8000000  /* F(4x4) kernel: ONE 8-wave work-group per segment covers all 128 output channels (the input
                                               transform is made once per segment instead of once per 64-channel half); bit-identical to the
-                                              4-wave form.  A/B runs and tests; the plan's own choice: ic_wino4_3x3_c128_form */
-#define IC_CONV3_WINO4_BITS       IC_CONV3_WINO4_WG8
+                                              4-wave form.  A/B runs and tests; the plan's own choice: ic_wino4_3x3_c128_waves */
+#define IC_CONV3_WINO4_WG4        0x10000000 /* F(4x4) kernel: always the 4-wave form (two 64-channel work-groups per segment); A/B runs */
+#define IC_CONV3_WINO4_BITS       (IC_CONV3_WINO4_WG8 | IC_CONV3_WINO4_WG4)
 /* h2 / h12 of the whole-network entry points (ic_ae_encode_f32 / ic_ae_decode_f32): their filter blobs were packed by
  * ic_pack_conv5s2_both_f32 (MFMA fragments followed by the F(4x4)-over-phases fragments), so the library may run them on the
  * F(4x4) kernel where ic_conv3x3_c128_pick_form picks it for the residual stack of the same call or h2's launch has >= 160
@@ -478,7 +479,11 @@ int ic_pack_wino4_3x3_c128_f32(const float* w_tf, float* w_packed, int backward,
 /* all 3x3 filters of a network in one launch: w_tf_table_dev (device array of device pointers) -> fragments l at w_packed + l * packed_floats */
 int ic_pack_wino4_3x3_c128_batch_f32(const float* const* w_tf_table_dev, float* w_packed, int layers, int backward, ic_stream_t stream);
 int ic_wino4_3x3_c128_supported(int N, int H, int W);
-long long ic_wino4_3x3_c128_workgroups(int N, int H, int W);
+long long ic_wino4_3x3_c128_workgroups(int N, int H, int W);     /* in units of the 4-wave form: 2 per segment of 16 tiles */
+/* waves per work-group the launch takes for this shape and flags: 4 (two 64-channel work-groups per segment, two per CU) or 8 (one
+ * work-group per segment and CU: IC_CONV3_WINO4_WG8, or by itself from 2048 four-wave work-groups on); 0: shape not supported.
+ * Both forms give the same bits (profiles/r06_w4_wg8.md has the measurements). */
+int ic_wino4_3x3_c128_waves(int N, int H, int W, int flags);
 int ic_wino4_3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
                                  const float* res1, const float* res2, float* y, int N, int H, int W, int relu,
                                  int flags, ic_stream_t stream);

@@ -397,6 +397,38 @@ def test_conv3x3_c128_winograd_f4_full_load_is_deterministic(cuda, label, N, H, 
     assert_close(ys[0][:n_ref], ref, 'winograd F(4x4) full load', W4_RTOL)
 
 
+@pytest.mark.parametrize('N,H,W,n_res', [(1, 128, 192, 1), (2, 37, 68, 2), (1, 64, 64, 0), (6, 128, 192, 1), (1, 540, 960, 2), (3, 100, 192, 1)])
+def test_conv3x3_c128_winograd_f4_eight_wave_form_is_bit_identical(cuda, N, H, W, n_res):
+    """IC_CONV3_WINO4_WG8 (round 6): ONE 8-wave work-group per segment covers all 128 output channels, the input transform is made
+    once per segment, the ring's hazards are kept by LDS counters instead of a barrier.  Same values in the same order as the
+    4-wave form -- bit-identical, 8 launches back to back (a lost or early counter hand-off would show as a stale B operand),
+    single-round (write-through) and multi-round launches, ragged borders, 0 / 1 / 2 residuals; and the plan: 8 waves when asked
+    for or from 2048 four-wave work-groups on, never on maps with 2 x 8-tile segments, never with IC_CONV3_WINO4_WG4."""
+    L = _lib()
+    waves = lambda n, h, w, f: int(L.lib.ic_wino4_3x3_c128_waves(n, h, w, f))
+    assert waves(1, 128, 192, 0) == 4 and waves(1, 128, 192, L.CONV3_WINO4_WG8) == 8 and waves(1, 540, 960, 0) == 8
+    assert waves(1, 540, 960, L.CONV3_WINO4_WG4) == 4 and waves(32, 32, 32, L.CONV3_WINO4_WG8) == 4 and waves(1, 128, 190, 0) == 0
+    g = torch.Generator().manual_seed(11 + H)
+    x = (torch.relu(torch.randn((N, 128, H, W), generator=g)) * 1.5).to(cuda)
+    w = (torch.randn((3, 3, 128, 128), generator=g) * 0.03).to(cuda)
+    sc, sh = (torch.rand(128, generator=g) * 0.6 + 0.5).to(cuda), (torch.randn(128, generator=g) * 0.1).to(cuda)
+    res = [torch.randn((N, 128, H, W), generator=g).to(cuda) for _ in range(n_res)]
+    wp = torch.empty(L.lib.ic_wino4_3x3_c128_packed_floats(), device=cuda)
+    L.check(L.lib.ic_pack_wino4_3x3_c128_f32(L.ptr(w), L.ptr(wp), 0, L.current_stream()))
+
+    def run(flags):
+        y = torch.full((N, 128, H, W), float('nan'), device=cuda)
+        L.check(L.lib.ic_wino4_3x3_c128_bn_act_f32(L.ptr(x), L.ptr(wp), L.ptr(sc), L.ptr(sh), L.ptr(res[0]) if n_res else None,
+                                                   L.ptr(res[1]) if n_res > 1 else None, L.ptr(y), N, H, W, 1, flags, L.current_stream()))
+        return y
+    y4 = run(L.CONV3_WINO4_WG4)
+    ys = [run(L.CONV3_WINO4_WG8) for _ in range(8)]
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(y4).all())
+    for k, y in enumerate(ys):
+        assert torch.equal(y4, y), 'launch {} of the 8-wave form differs from the 4-wave form in {} values'.format(k, int((y4 != y).sum()))
+
+
 @pytest.mark.parametrize('transposed', [0, 1])
 @pytest.mark.parametrize('N,H,W', [(4, 128, 192), (48, 32, 32)])
 def test_conv5s2_as_winograd_full_load_is_deterministic(cuda, transposed, N, H, W):
