@@ -14,7 +14,7 @@ issued round-robin and EVERY step is still one image through the whole path.  Th
 bubbles of the others, and a 3x3 launch no longer has to fill the chip alone (IC_CONV3_IN_FLIGHT: the plan takes the form with
 the least CU-time).  --in_flight 1 is one image at a time (what rounds 1-2 reported; kept in the line as `one_image_at_a_time`).
 The HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues, 4 unless set: with more streams than
-queues, streams that share a queue run one after the other.  bench.py asks for 16 below, before the runtime starts (round 4:
+queues, streams that share a queue run one after the other.  bench.py asks for 8 below, before the runtime starts (round 4:
 4 images in flight 207.7 Mpix/s on 4 queues, 251.5 on 8; 6 images 236 / 240).
 
   python bench.py --gpus N --steps K --warmup W            (--mode train: one cfg3 training step per step)
@@ -40,8 +40,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')     # one hardware queue per image in flight (+ the default stream); see the docstring
-                                                     # (16 since round 6: small images keep up to 15 in flight, flight_for_shape)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # one hardware queue per image in flight (+ the default stream); see the docstring
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -169,13 +168,14 @@ class InFlight(object):
 
 
 def flight_for_shape(lib, n, h, w, n_default):
-    """images in flight for a shape: at least the benchmark's own count, and enough of them that the 3x3 launches in flight hold
-    >= 512 F(4x4) work-groups together (two per CU) -- a 256 x 256 image is 32 work-groups per launch, so 4 in flight fill an eighth
-    of the chip.  IC_CONV3_IN_FLIGHT carries 4 bits: at most 15."""
-    if n_default <= 1:
-        return 1
-    wgs = int(lib.ic_wino4_3x3_c128_workgroups(n, h // 4, w // 4)) or 1
-    return int(min(15, max(n_default, -(-512 // wgs))))
+    """images in flight for a shape.  VERDICT r5 item 3a asked for enough of them that the 3x3 launches in flight hold >= 512 work-groups
+    (8 - 16 at 256 x 256).  Measured in round 6 (tools/flight_sweep.py, Mpix/s of the whole step, n = 1 / 2 / 4 / 6 / 8 / 12 / 15):
+        256 x 256  automatic plan  63.8 / 97.1 / 131.5 / 90.6 / 94.8 / 89.6 / 110.4   F(4x4) forced  30.4 / 55.1 / 90.1 / 63.8 / 84.6 / 73.1 / 80.9
+        384 x 512  automatic plan 110.7 / 149.1 / 222.2 / 181.1 / 180.3 / 230.2 / 235.2
+    More than four streams do not fill the chip better -- they share the hardware queues unevenly (the non-monotonic rows) and a 256 x 256
+    launch is bounded by its own 13 us chain, not by the CUs it leaves idle.  So: the benchmark's own count for
+    every shape; small images are batched instead (val.py --batch_same_shape: 8 x 256 x 256 per step, 275 Mpix/s)."""
+    return int(n_default)
 
 
 def res_stack_runner(torch, lib, _lib, W, ae, ae_cfg, pipe, enc, which, flags, st):
@@ -540,13 +540,6 @@ def main():
                    'one_image_at_a_time': {'value': round(n2 * h2 * w2 * 30 / dt1 / 1e6, 3), 'ms_per_step': round(dt1 / 30 * 1e3, 4)},
                    'executed_frac_of_mfma_peak_whole_step': round(flop * k2 / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                    'plan_3x3': plan_name(lib, _lib, n2, h2 // 4, w2 // 4, fl2)['kernel']}
-            if nf2 != n_flight and n_flight > 1:
-                # the Kodak schedule's count on this shape too (what rounds 3-5 reported for it)
-                del sch
-                sch4 = InFlight(torch, ps, dev, n_flight, a.ae_config, rank, graphs=bool(a.graphs))
-                dt4_, _ = run(sch4, 30, 5)
-                ent['with_{}_in_flight'.format(n_flight)] = {'value': round(n2 * h2 * w2 * 30 / dt4_ / 1e6, 3), 'ms_per_step': round(dt4_ / 30 * 1e3, 4)}
-                del sch4
             shapes.append(ent)
             ps.branch.close()
         extra['shapes'] = shapes

@@ -123,6 +123,8 @@ PROTOTYPES = {
     'ic_wino4_3x3_c128_workgroups': (c_longlong, [c_int, c_int, c_int]),
     'ic_wino4_3x3_c128_waves': (c_int, [c_int, c_int, c_int, c_int]),
     'ic_wino4_3x3_c128_bn_act_f32': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
+    'ic_wino4_3x3_c128_stats_parts': (c_longlong, [c_int, c_int, c_int]),
+    'ic_wino4_3x3_c128_raw_stats_f32': (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     'ic_wino4_conv5s2_packed_floats': (c_size_t, []),
     'ic_pack_wino4_conv5s2_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     'ic_wino4_conv5s2_supported': (c_int, [c_int, c_int, c_int]),
@@ -144,6 +146,7 @@ PROTOTYPES = {
     'ic_bn_stats_f32': (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p, c_void_p]),
     'ic_bn_train_stats_f32': (c_int, [c_void_p] * 5 + [c_float] * 2 + [c_void_p] * 4 + [c_int] * 3 + [c_void_p, c_void_p]),
     'ic_bn_train_forward_f32': (c_int, [c_void_p] * 5 + [c_float] * 2 + [c_void_p] * 7 + [c_int] * 4 + [c_void_p, c_void_p]),
+    'ic_bn_train_forward_cstats_f32': (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 4 + [c_float] * 2 + [c_void_p] * 7 + [c_int] * 4 + [c_void_p]),
     'ic_bn_moments_f32': (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p, c_void_p]),
     'ic_bn_train_fold_moments_f32': (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float] +
                                      [c_void_p] * 4 + [c_int, c_void_p]),

@@ -241,7 +241,10 @@ __device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, fl
 // Waves w and w + 4 share a SIMD.  The input transform is made ONCE per segment: the waves 0..3 (group 0) make the k-steps of the even
 // iterations, the waves 4..7 (group 1) those of the odd ones -- every SIMD has one transforming and one MFMA-only wave in every iteration.
 // Same ring, same barrier (now 512 threads), same values in the same order: bit-identical to the 4-wave form.
-template <bool WT, int RES, int CIN, int COUT, bool SHUF, bool SEG2, bool WG8>
+// STATS (round 6, the training step's forward convolutions): the RAW convolution is stored (no BatchNorm fold, activation or residual)
+// and the epilogue also leaves, per output channel and segment, the sum and the sum of squares of the values it stores -- the batch
+// statistics of training-mode BatchNorm (autoencoder.py:106-125) without a pass over the tensor: ic_bn_train_forward_cstats_f32 folds them.
+template <bool WT, int RES, int CIN, int COUT, bool SHUF, bool SEG2, bool WG8, bool STATS = false>
 __global__ __launch_bounds__(WG8 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void wino4_3x3_kernel(const WnArgs a) {
     constexpr int WAVES = WG8 ? 8 : 4;
@@ -491,7 +494,7 @@ void wino4_3x3_kernel(const WnArgs a) {
         unsigned lo[4];
         int kq_e;
         epilogue_lanes(lo, kq_e);
-        if (first == 0) {
+        if (first == 0 && !STATS) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ch = SHUF ? 4 * cot + kq_e : 16 * cot + 4 * kq_e + r;        // SHUF: one real channel per lane, four phases
@@ -732,9 +735,33 @@ void wino4_3x3_kernel(const WnArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int jx = 0; jx < 4; ++jx) o[i][jx] = fmaxf(fmaf(y[i][jx], scv[r], shv[r]), relu_lo);
+            for (int jx = 0; jx < 4; ++jx) o[i][jx] = STATS ? y[i][jx] : fmaxf(fmaf(y[i][jx], scv[r], shv[r]), relu_lo);
             if (has1) o[i] += (r & 1) ? e1b[i] : e1a[i];
             if (has2) o[i] += e2[i];
+        }
+        if (STATS) {
+            // sum and sum of squares of the lane's 16 values that lie inside the map (rows beyond it carry lo[i] = WN_OOB), then over the 16
+            // lanes of the row (= the 16 tiles of the segment, all of this channel): four DPP steps leave the total in the row's last lane.
+            // Fixed order: bit-reproducible.
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = lo[i] != WN_OOB;
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) { const float v = ok ? o[i][jx] : 0.f; s0 += v; s1 = fmaf(v, v, s1); }
+            }
+            // (row_shr:n with bound_ctrl: lanes without a source read 0)
+#define W4_ROW_SHR_ADD(v, n) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + (n), 0xf, 0xf, true))
+            W4_ROW_SHR_ADD(s0, 1); W4_ROW_SHR_ADD(s1, 1);
+            W4_ROW_SHR_ADD(s0, 2); W4_ROW_SHR_ADD(s1, 2);
+            W4_ROW_SHR_ADD(s0, 4); W4_ROW_SHR_ADD(s1, 4);
+            W4_ROW_SHR_ADD(s0, 8); W4_ROW_SHR_ADD(s1, 8);
+#undef W4_ROW_SHR_ADD
+            int lane_t = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            if ((lane_t & 15) == 15) {
+                float* d = a.stats + ((size_t)(co + 4 * (lane_t >> 4)) * a.ngroups + (seg - a.g0)) * 2;
+                d[0] = s0; d[1] = s1;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         // residual 1 of channel r + 2 into the registers channel r just freed -- BEFORE this channel's stores: memory operations
@@ -877,6 +904,35 @@ int icx_wino4_3x3_c128_next(const float* x, const float* w_packed, const float* 
     if (res2) return w4_launch<2, 128, 128, false>(x, w_packed, scale, shift, res1, res2, y, N, H, W, relu, flags, st, w_packed_next);
     return w4_launch<1, 128, 128, false>(x, w_packed, scale, shift, res1, nullptr, y, N, H, W, relu, flags, st, w_packed_next);
 }
+// ---- the training step's forward convolution: raw output + per-segment channel sums for BatchNorm (STATS instantiations) ----
+extern "C" long long ic_wino4_3x3_c128_stats_parts(int N, int H, int W) {
+    if (!ic_wino4_3x3_c128_supported(N, H, W)) return 0;
+    return (long long)N * w4_segments(H, W, w4_seg2(H, W));
+}
+template <bool SEG2>
+static int w4_launch_stats(const float* x, const float* w_packed, float* y, float* stats, int N, int H, int W, int flags, hipStream_t st) {
+    WnArgs a{};
+    a.x = x; a.wp = w_packed; a.y = y; a.stats = stats;
+    a.N = N; a.H = H; a.W = W; a.relu = 0;
+    a.grows = SEG2 ? ic_cdiv(ic_cdiv(H, 4), 2) : ic_cdiv(H, 4);
+    a.gcols = SEG2 ? ic_cdiv(W, 32) : ic_cdiv(W, 64);
+    a.xcd_runs = (flags & IC_CONV3_NO_XCD_RUNS) ? 0 : 1;
+    a.g0 = 0; a.ngroups = N * a.grows * a.gcols;
+    const long long wgs = 2ll * a.ngroups;
+    const dim3 grid((unsigned)wgs), block(256);
+    if (wgs <= W4_WT_MAX) hipLaunchKernelGGL((wino4_3x3_kernel<true, 0, 128, 128, false, SEG2, false, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((wino4_3x3_kernel<false, 0, 128, 128, false, SEG2, false, true>), grid, block, 0, st, a);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+extern "C" int ic_wino4_3x3_c128_raw_stats_f32(const float* x, const float* w_packed, float* y, float* stats, int N, int H, int W,
+                                               int flags, ic_stream_t stream) {
+    IC_CHECK_ARG(x && w_packed && y && stats && N > 0 && H > 0 && W > 0);
+    if (!ic_wino4_3x3_c128_supported(N, H, W)) return IC_ERR_UNSUPPORTED;
+    if (w4_seg2(H, W)) return w4_launch_stats<true>(x, w_packed, y, stats, N, H, W, flags, (hipStream_t)stream);
+    return w4_launch_stats<false>(x, w_packed, y, stats, N, H, W, flags, (hipStream_t)stream);
+}
+
 extern "C" int ic_wino4_3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
                                             const float* res1, const float* res2, float* y, int N, int H, int W, int relu,
                                             int flags, ic_stream_t stream) {

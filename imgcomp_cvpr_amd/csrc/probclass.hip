@@ -485,7 +485,11 @@ __global__ void pc_pack16_kernel(const float* __restrict__ w, float* __restrict_
     out[idx] = co < Cout ? w[((size_t)tap * Cin + ci) * Cout + co] : 0.f;
 }
 
-template <int CIN, int KC>
+// LC: the number of logits when known at compile time (6 centres in every shipped configuration), 0 = a.Cout at run time.  Round 6: with
+// LC = 6 the epilogue gathers 2 values per voxel instead of 16 and its softmax loops are straight-line code over 6 logits (the generic
+// form runs 16-trip loops under run-time bounds on a quarter of the lanes: 3.0 vector instructions per MFMA, r03 counters) -- the same
+// operations in the same order on the same values as LC = 0 (the sequential decoder's round-trip tests pin the logits bit for bit).
+template <int CIN, int KC, int LC = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void pc_final16_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
     constexpr int TR = 8, TC = 16, S = TC + 2, DS = (TR + 2) * S, CHUNK = KC * 2 * DS;
@@ -594,13 +598,40 @@ void pc_final16_kernel(const PcLayerArgs a, const float* __restrict__ wpk) {
             const int co = 4 * kq + r;
             val[r] = fmaxf(acc[r] + (co < a.Cout ? biasp[co] : 0.f), 0.f);    // final layer keeps conv3d's default ReLU
         }
+        const int oy = y0 + 2 * wave + nt, ox = x0 + nn;
+        if (LC == 6) {
+            // channels 0..3 are this lane's own values in the kq = 0 lanes, 4 and 5 come from the kq = 1 lane of the same voxel
+            const float l4 = __shfl(val[0], 16 + nn), l5 = __shfl(val[1], 16 + nn);
+            if (kq == 0 && oy < a.OH && ox < a.OW) {
+                const float lg6[6] = {val[0], val[1], val[2], val[3], l4, l5};
+                const size_t vox = (size_t)n * ovol + ((size_t)od * a.OH + oy) * a.OW + ox;
+                if (a.out) {
+                    pc_f32x2* o2 = reinterpret_cast<pc_f32x2*>(a.out + vox * 6);           // 24 bytes per voxel: 8-byte aligned
+                    o2[0] = pc_f32x2{lg6[0], lg6[1]}; o2[1] = pc_f32x2{lg6[2], lg6[3]}; o2[2] = pc_f32x2{lg6[4], lg6[5]};
+                }
+                if (a.bits) {
+                    float m = lg6[0];
+#pragma unroll
+                    for (int c2 = 1; c2 < 6; ++c2) m = fmaxf(m, lg6[c2]);
+                    float ssum = 0.f, lsym = 0.f;
+                    const int sym = (int)a.symbols[vox];
+#pragma unroll
+                    for (int c2 = 0; c2 < 6; ++c2) {
+                        const float shv = lg6[c2] - m;
+                        ssum += expf(shv);
+                        if (c2 == sym) lsym = shv;
+                    }
+                    a.bits[vox] = __fmul_rn(logf(ssum) - lsym, 1.44269504f);
+                }
+            }
+            continue;
+        }
         // gather the voxel's logits into its kq = 0 lane
         float lg[16];
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
             for (int r = 0; r < 4; ++r) lg[4 * g4 + r] = __shfl(val[r], 16 * g4 + nn);
-        const int oy = y0 + 2 * wave + nt, ox = x0 + nn;
         if (kq == 0 && oy < a.OH && ox < a.OW) {
             const size_t vox = (size_t)n * ovol + ((size_t)od * a.OH + oy) * a.OW + ox;
             if (a.out) {
@@ -760,7 +791,12 @@ static int pc_forward(const float* q, int prepadded, const int64_t* symbols, con
     else if (use_mfma) {
         const float* pk16 = pk3 + pc_packed_floats(k, 32);
         dim3 g(a.OD * ic_cdiv(a.OH, 8) * ic_cdiv(a.OW, 16), 1, a.N);
-        if (k == 24) hipLaunchKernelGGL((pc_final16_kernel<24, 24>), g, dim3(256), 0, st, a, pk16);
+#ifndef PC_FINAL_LC6
+#define PC_FINAL_LC6 1          // 0: A/B builds with the run-time-L epilogue for L = 6 too
+#endif
+        if (k == 24 && L == 6 && PC_FINAL_LC6) hipLaunchKernelGGL((pc_final16_kernel<24, 24, 6>), g, dim3(256), 0, st, a, pk16);
+        else if (k == 24) hipLaunchKernelGGL((pc_final16_kernel<24, 24>), g, dim3(256), 0, st, a, pk16);
+        else if (L == 6 && PC_FINAL_LC6) hipLaunchKernelGGL((pc_final16_kernel<64, 16, 6>), g, dim3(256), 0, st, a, pk16);
         else hipLaunchKernelGGL((pc_final16_kernel<64, 16>), g, dim3(256), 0, st, a, pk16);
         IC_LAUNCH_CHECK();
         rc = IC_OK;

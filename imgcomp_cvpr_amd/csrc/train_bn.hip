@@ -181,15 +181,35 @@ struct BnApplyArgs {
     int N, C, HW, relu;
     const double* partial;    // != nullptr: scale / shift are OUTPUTS -- folded here from the partial sums (BnFoldArgs f, count M)
     long long M;
+    const float* cstats;      // != nullptr (instead of partial): the per-segment (sum, sum of squares) a convolution's epilogue left,
+    int cparts;               //   [C][cparts][2] (ic_wino4_3x3_c128_raw_stats_f32) -- summed here in double, in index order
 };
+// the totals of channel c from a convolution's per-segment sums, by the work-group's first wave: lane l takes the segments l, l + 64, ...
+// in double, a fixed xor tree over the 64 lanes, the result through LDS to the other waves -- the ONE place that defines this order
+// (every work-group of the channel gets the same bits).  Called by ALL threads of the work-group (it holds a barrier).
+// (Round 6, first version: every thread summed all segments itself -- 512 loads per thread in 4096 work-groups: 10 us per layer.)
+__device__ __forceinline__ void bn_totals_cstats(const float* __restrict__ cs, int cparts, int c, double& s0, double& s1) {
+    __shared__ double tot[2];
+    if (threadIdx.x < 64) {
+        const float* p = cs + (size_t)c * cparts * 2;
+        double a0 = 0.0, a1 = 0.0;
+        for (int i = threadIdx.x; i < cparts; i += 64) { a0 += (double)p[2 * i]; a1 += (double)p[2 * i + 1]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); }
+        if (threadIdx.x == 0) { tot[0] = a0; tot[1] = a1; }
+    }
+    __syncthreads();
+    s0 = tot[0]; s1 = tot[1];
+}
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a, const BnFoldArgs f) {
     const int c = blockIdx.y % a.C;
     const int n_first = VEC ? (int)(blockIdx.y / a.C) * BN_PL : (int)(blockIdx.y / a.C);      // (grid.y = C x image groups)
     float sc, sh;
-    if (a.partial) {
+    if (a.partial || a.cstats) {
         double s0, s1;
-        bn_totals(a.partial, c, s0, s1);
+        if (a.cstats) bn_totals_cstats(a.cstats, a.cparts, c, s0, s1);
+        else bn_totals(a.partial, c, s0, s1);
         float mf, vf, is;
         bn_fold_values(s0, s1, a.M, f.gamma[c], f.beta[c], f.eps, mf, vf, is, sc, sh);
         // plane (n = 0, c), first chunk, first thread: the channel's statistics and moving averages, once
@@ -334,8 +354,23 @@ extern "C" int ic_bn_train_forward_f32(const float* x, const float* gamma, const
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(BN_SPLIT, C), dim3(1024), 0, st, a);
     const BnFoldArgs f{gamma, beta, moving_mean, moving_var, decay, eps, mean, invstd, scale, shift};
-    BnApplyArgs ap{x, nullptr, nullptr, res1, res2, y, N, C, HW, relu, a.partial, (long long)N * HW};
+    BnApplyArgs ap{x, nullptr, nullptr, res1, res2, y, N, C, HW, relu, a.partial, (long long)N * HW, nullptr, 0};
     bn_launch_apply(ap, f, N, st);
+    IC_LAUNCH_CHECK();
+    return IC_OK;
+}
+
+// The same layer when the convolution that produced x left its channel sums behind (ic_wino4_3x3_c128_raw_stats_f32: per segment, fp32):
+// ONE launch -- no pass over x for the statistics.  The sums are fp32 over <= 256 values per segment and double across segments:
+// mean and variance agree with the two-pass form to ~1e-7 relative (tests/test_gpu_training.py compares them).
+extern "C" int ic_bn_train_forward_cstats_f32(const float* x, const float* conv_stats, int parts, const float* gamma, const float* beta,
+                                              float* moving_mean, float* moving_var, float decay, float eps, float* mean, float* invstd,
+                                              float* scale, float* shift, const float* res1, const float* res2, float* y, int N, int C,
+                                              int HW, int relu, ic_stream_t stream) {
+    IC_CHECK_ARG(x && conv_stats && parts > 0 && gamma && beta && mean && invstd && scale && shift && y && N > 0 && C > 0 && HW > 0);
+    const BnFoldArgs f{gamma, beta, moving_mean, moving_var, decay, eps, mean, invstd, scale, shift};
+    BnApplyArgs ap{x, nullptr, nullptr, res1, res2, y, N, C, HW, relu, nullptr, (long long)N * HW, conv_stats, parts};
+    bn_launch_apply(ap, f, N, (hipStream_t)stream);
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
@@ -405,7 +440,7 @@ extern "C" int ic_bn_backward_apply_f32(const float* dy, const float* x, const f
 extern "C" int ic_bn_apply_f32(const float* x, const float* scale, const float* shift, const float* res1,
                                const float* res2, float* y, int N, int C, int HW, int relu, ic_stream_t stream) {
     IC_CHECK_ARG(x && scale && shift && y && N > 0 && C > 0 && HW > 0);
-    BnApplyArgs ap{x, scale, shift, res1, res2, y, N, C, HW, relu, nullptr, 0};
+    BnApplyArgs ap{x, scale, shift, res1, res2, y, N, C, HW, relu, nullptr, 0, nullptr, 0};
     bn_launch_apply(ap, BnFoldArgs{}, N, (hipStream_t)stream);
     IC_LAUNCH_CHECK();
     return IC_OK;

@@ -25,6 +25,7 @@ struct WnArgs {
     unsigned mg_cols, mg_rows;  // NB-segment kernels: 2^32 / gcols + 1, 2^32 / grows + 1 (0 for a divisor of 1); set by the launcher
     unsigned long long* prof;   // profiling builds (WN_PROF) only
     const float* wp_next;       // F(4x4) kernel: the NEXT layer's fragments to pull into this XCD's L2 while this layer runs (nullptr: none)
+    float* stats;               // F(4x4) kernel, STATS instantiations: per-segment (sum, sum of squares) of every output channel, [C][ngroups][2]
 };
 
 // conv3x3_wino_stack.hip: a whole residual stack (<= WN_STACK_MAX_LAYERS convs on one shape) as one persistent launch.

@@ -414,16 +414,42 @@ class TrainGraph(object):
         else:
             dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.pg)
 
+    FUSE_BN_STATS = True      # 3x3 layers in F(4x4) form: the convolution's epilogue leaves the per-segment channel sums, BatchNorm is ONE
+                              # launch (ic_wino4_3x3_c128_raw_stats_f32 + ic_bn_train_forward_cstats_f32) instead of statistics pass + apply
+
+    def _conv3x3_with_stats(self, l, x):
+        """the raw 3x3 conv of layer l on the F(4x4) kernel with its BatchNorm sums, or None when this layer / shape / mode does not
+        take that path (then: _raw_forward + the two-pass BatchNorm)"""
+        if not (self.FUSE_BN_STATS and l.kind == 'conv' and l.kh == 3 and l.cin == 128 and l.cout == 128):
+            return None
+        if getattr(self, '_wino_pk', None) is None or not self._w3_f4[0] or self._bn_world() != 1:
+            return None
+        N, _, H, W = x.shape
+        parts = int(lib.ic_wino4_3x3_c128_stats_parts(N, H, W))
+        if parts <= 0:
+            return None
+        raw, cst = self._new(N, 128, H, W), self._new(128, parts, 2)
+        wp = self._wino_pk[0][self._w3_index[l.scope + '/weights']]
+        check(lib.ic_wino4_3x3_c128_raw_stats_f32(ptr(x), ptr(wp), ptr(raw), ptr(cst), N, H, W, 0, self._st()), 'conv3x3 + BatchNorm sums')
+        return raw, cst, parts
+
     def _cba_fwd(self, scope, x, relu, res1=None, res2=None, tape=None):
         l = self.layers[scope]
-        raw = self._raw_forward(l, x)
+        fused = self._conv3x3_with_stats(l, x)
+        raw = fused[0] if fused else self._raw_forward(l, x)
         N, Cc, H, W = raw.shape
         stats = self._new(4, Cc)
         mean, invstd, scale, shift = stats[0], stats[1], stats[2], stats[3]
         P = self.params
         world = self._bn_world()
         y = self._new(N, Cc, H, W)
-        if world == 1:
+        if fused:
+            check(lib.ic_bn_train_forward_cstats_f32(ptr(raw), ptr(fused[1]), fused[2], ptr(P[scope + '/BatchNorm/gamma']),
+                                                     ptr(P[scope + '/BatchNorm/beta']), ptr(P[scope + '/BatchNorm/moving_mean']),
+                                                     ptr(P[scope + '/BatchNorm/moving_variance']), BN_DECAY, BN_EPS, ptr(mean), ptr(invstd),
+                                                     ptr(scale), ptr(shift), ptr(res1), ptr(res2), ptr(y), N, Cc, H * W, int(relu),
+                                                     self._st()), 'bn forward (conv sums)')
+        elif world == 1:
             # batch statistics, folded scale / shift, the moving-average update (decay 0.9) and the normalised, activated output
             # (+ the residual adds) in one call of two launches
             check(lib.ic_bn_train_forward_f32(ptr(raw), ptr(P[scope + '/BatchNorm/gamma']), ptr(P[scope + '/BatchNorm/beta']),

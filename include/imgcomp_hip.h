@@ -337,6 +337,13 @@ int ic_bn_train_forward_f32(const float* x, const float* gamma, const float* bet
                             float decay, float eps, float* mean, float* invstd, float* scale, float* shift,
                             const float* res1, const float* res2, float* y, int N, int C, int HW, int relu,
                             void* workspace, ic_stream_t stream);
+/* The same layer in ONE launch when the convolution that produced x left its per-segment channel sums behind (conv_stats
+ * [C][parts][2], ic_wino4_3x3_c128_raw_stats_f32): summed in double in index order by every work-group of the channel, then folded
+ * and applied exactly as above.  No workspace. */
+int ic_bn_train_forward_cstats_f32(const float* x, const float* conv_stats, int parts, const float* gamma, const float* beta,
+                                   float* moving_mean, float* moving_var, float decay, float eps, float* mean, float* invstd,
+                                   float* scale, float* shift, const float* res1, const float* res2, float* y, int N, int C,
+                                   int HW, int relu, ic_stream_t stream);
 
 /* =============================================================================================
  * Training (train.py:101-106, :303-349): training-mode BatchNorm, backward kernels.
@@ -487,6 +494,14 @@ int ic_wino4_3x3_c128_waves(int N, int H, int W, int flags);
 int ic_wino4_3x3_c128_bn_act_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
                                  const float* res1, const float* res2, float* y, int N, int H, int W, int relu,
                                  int flags, ic_stream_t stream);
+/* The training step's forward convolution (train.py:101-106 runs the graph with is_training=True): y = the RAW convolution (no
+ * BatchNorm fold, activation or residual), and per output channel c and segment s the sum and the sum of squares of the values
+ * stored -- stats[(c * parts + s) * 2 + {0, 1}], parts = ic_wino4_3x3_c128_stats_parts(N, H, W), fp32 over <= 256 values each, in
+ * a fixed order (bit-reproducible).  ic_bn_train_forward_cstats_f32 makes the layer's batch statistics of them: training-mode
+ * BatchNorm (autoencoder.py:106-125) without a pass over y for the statistics. */
+long long ic_wino4_3x3_c128_stats_parts(int N, int H, int W);
+int ic_wino4_3x3_c128_raw_stats_f32(const float* x, const float* w_packed, float* y, float* stats, int N, int H, int W,
+                                    int flags, ic_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The two large 5x5 / stride-2 layers on the same kernel (csrc/conv3x3_wino4.hip): a 5x5 / stride-2 SAME convolution is ONE 3x3 /

@@ -61,6 +61,60 @@ def test_bn_train_forward_backward(cuda):
         assert_close(dx, xt.grad, 'bn dx', 1e-5)
 
 
+@pytest.mark.parametrize('N,H,W', [(32, 32, 32), (2, 37, 68), (1, 128, 192), (3, 30, 44)])
+def test_conv3x3_epilogue_batchnorm_sums(cuda, N, H, W):
+    """Round 6: the training step's forward 3x3 convolution leaves the per-segment channel sums of its RAW output
+    behind (ic_wino4_3x3_c128_raw_stats_f32: both segment shapes, ragged maps -- rows and tiles beyond the map must not count), and
+    ic_bn_train_forward_cstats_f32 makes the layer's training-mode BatchNorm of them in one launch.  Against the two-launch form on the
+    same raw tensor (ic_bn_train_forward_f32: float64 sums): raw output bit-identical to the plain F(4x4) launch, statistics within
+    1e-6, outputs and moving averages within 1e-6 of the tensor scale; repeated launches give the same bits."""
+    L = _L()
+    g = torch.Generator().manual_seed(21 + H)
+    x = (torch.relu(torch.randn((N, 128, H, W), generator=g)) * 1.3).to(cuda)
+    w = (torch.randn((3, 3, 128, 128), generator=g) * 0.04).to(cuda)
+    gamma, beta = (torch.rand(128, generator=g) * 0.8 + 0.6).to(cuda), (torch.randn(128, generator=g) * 0.2).to(cuda)
+    res = torch.randn((N, 128, H, W), generator=g).to(cuda)
+    st = L.current_stream()
+    wp = torch.empty(L.lib.ic_wino4_3x3_c128_packed_floats(), device=cuda)
+    L.check(L.lib.ic_pack_wino4_3x3_c128_f32(L.ptr(w), L.ptr(wp), 0, st))
+    ones, zeros = torch.ones(128, device=cuda), torch.zeros(128, device=cuda)
+    raw_ref = torch.empty((N, 128, H, W), device=cuda)
+    L.check(L.lib.ic_wino4_3x3_c128_bn_act_f32(L.ptr(x), L.ptr(wp), L.ptr(ones), L.ptr(zeros), None, None, L.ptr(raw_ref), N, H, W, 0,
+                                               L.CONV3_WINO4_WG4, st))
+    parts = int(L.lib.ic_wino4_3x3_c128_stats_parts(N, H, W))
+    assert parts == int(L.lib.ic_wino4_3x3_c128_workgroups(N, H, W)) // 2
+    outs = []
+    for _ in range(2):
+        raw = torch.full((N, 128, H, W), float('nan'), device=cuda)
+        cst = torch.full((128, parts, 2), float('nan'), device=cuda)
+        L.check(L.lib.ic_wino4_3x3_c128_raw_stats_f32(L.ptr(x), L.ptr(wp), L.ptr(raw), L.ptr(cst), N, H, W, 0, st))
+        outs.append((raw, cst))
+    torch.cuda.synchronize()
+    raw, cst = outs[0]
+    assert torch.equal(raw, raw_ref), 'the STATS instantiation stores other values than the plain launch'
+    assert torch.equal(outs[1][0], raw) and torch.equal(outs[1][1], cst) and bool(torch.isfinite(cst).all())
+    tot = cst.double().sum(dim=1)
+    assert_close(tot[:, 0], raw.double().sum(dim=(0, 2, 3)), 'conv epilogue: channel sums', 1e-6)
+    assert_close(tot[:, 1], (raw.double() ** 2).sum(dim=(0, 2, 3)), 'conv epilogue: channel sums of squares', 1e-6)
+
+    def bn(fused):
+        mm, mv = torch.full((128,), 0.25, device=cuda), torch.full((128,), 1.5, device=cuda)
+        o = [torch.empty(128, device=cuda) for _ in range(4)]
+        y = torch.empty_like(raw)
+        if fused:
+            L.check(L.lib.ic_bn_train_forward_cstats_f32(L.ptr(raw), L.ptr(cst), parts, L.ptr(gamma), L.ptr(beta), L.ptr(mm), L.ptr(mv), 0.9, 1e-5,
+                                                         L.ptr(o[0]), L.ptr(o[1]), L.ptr(o[2]), L.ptr(o[3]), L.ptr(res), None, L.ptr(y), N, 128, H * W, 1, st))
+        else:
+            ws = torch.empty(L.lib.ic_bn_workspace_bytes(128), dtype=torch.uint8, device=cuda)
+            L.check(L.lib.ic_bn_train_forward_f32(L.ptr(raw), L.ptr(gamma), L.ptr(beta), L.ptr(mm), L.ptr(mv), 0.9, 1e-5, L.ptr(o[0]), L.ptr(o[1]),
+                                                  L.ptr(o[2]), L.ptr(o[3]), L.ptr(res), None, L.ptr(y), N, 128, H * W, 1, L.ptr(ws), st))
+        torch.cuda.synchronize()
+        return [y, mm, mv] + o
+    a_, b_ = bn(True), bn(False)
+    for name, u, v in zip(('y', 'moving mean', 'moving variance', 'mean', 'invstd', 'scale', 'shift'), a_, b_):
+        assert_close(u, v.double(), 'BatchNorm from the conv epilogue sums: ' + name, 2e-6)
+
+
 def test_fused_adam_matches_the_multi_tensor_form(cuda):
     """ic_adam_tf_f32 on flat buffers against TFAdam's seven multi-tensor passes (tf.train.AdamOptimizer: epsilon outside the
     bias correction) over three steps, tensors of odd sizes at 256-byte aligned offsets of the flat buffers."""

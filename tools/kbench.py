@@ -23,7 +23,8 @@ SHAPES = {'kodak': (1, 128, 192), 'kodak_p': (1, 192, 128), '256': (1, 64, 64), 
 FORMS = [('auto', 0), ('leave_idle', _lib.CONV3_LEAVE_IDLE_CUS), ('wholek', _lib.CONV3_WINO_WHOLEK), ('ksplit', _lib.CONV3_WINO_KSPLIT),
          ('t16', _lib.CONV3_WINO_T16), ('seg1', _lib.CONV3_WINO_SEG1), ('seg2', _lib.CONV3_WINO_SEG2), ('seg3', _lib.CONV3_WINO_SEG3), ('pair', _lib.CONV3_WINO_PAIR),
          ('seg3_pk', _lib.CONV3_WINO_SEG3 | _lib.CONV3_PACKED_TRANSFORM), ('seg2_pk', _lib.CONV3_WINO_SEG2 | _lib.CONV3_PACKED_TRANSFORM),
-         ('seg3_noxcd', _lib.CONV3_WINO_SEG3 | _lib.CONV3_NO_XCD_RUNS), ('direct', _lib.CONV3_DIRECT)]
+         ('seg3_noxcd', _lib.CONV3_WINO_SEG3 | _lib.CONV3_NO_XCD_RUNS), ('direct', _lib.CONV3_DIRECT),
+         ('w4', _lib.CONV3_WINO4 | _lib.CONV3_WINO4_WG4), ('w4_wg8', _lib.CONV3_WINO4 | _lib.CONV3_WINO4_WG8)]
 
 
 class Timer(object):
@@ -80,7 +81,8 @@ def cmd_conv3(a, dev):
                 _lib.check(lib.ic_conv3x3_c128_auto_f32(_lib.ptr(x[i & 1]), _lib.ptr(wps[i % nf]), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(r), None,
                                                         _lib.ptr(x[(i + 1) & 1]), N, H, W, 1, flags, t.st))
             return go
-        forms = [(n_, f) for n_, f in FORMS if not (name == '4k' and n_ in ('ksplit', 'direct', 'seg1', 't16'))]
+        forms = [(n_, f) for n_, f in FORMS if not (name == '4k' and n_ in ('ksplit', 'direct', 'seg1', 't16'))
+                 and not (n_ in ('t16', 'pair') and not lib.ic_build_has_tuning_forms())]
         res = {n_: [] for n_, _ in forms}
         for n_, f in forms:              # warm-up (clock ramp, code objects)
             t(launch(f), 10)
@@ -97,7 +99,7 @@ def cmd_conv3(a, dev):
             med = v[len(v) // 2]
             out['us_median'][n_] = round(med, 2)
             out['us_min'][n_] = round(v[0], 2)
-            ex = flop * (1.0 if n_ == 'direct' else 16.0 / 36.0)
+            ex = flop * (1.0 if n_ == 'direct' else (0.25 if n_.startswith('w4') else 16.0 / 36.0))
             out['executed_frac'][n_] = round(ex / med / 1e6 / 157.3, 3)
         emit(out, a.out)
 
