@@ -211,25 +211,10 @@ __device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, fl
     y3 = fmaf(8.f, d2, d1) + m5;
 }
 
-// (Round 5, for launches alone on the chip with one work-group per CU -- a Kodak map one image at a time --: a second build for ONE wave
-// per SIMD and 512 registers, all 36 accumulators in AGPRs, filter ring 18 quads, B ring 6.  Audit clean, correct, and no faster:
-// one image at a time 168.9 against 169.3 Mpix/s at 512 x 768, 201.5 against 201.9 at 640 x 768.  The 6 -> 9 step of the ring had
-// bought 18 % there; beyond 9 a lone wave's loop -- 53.1 k clocks for 36.9 k of MFMA issue, tools/w4prof.py -- is no longer waiting for
-// filter fragments.  What is left per iteration of 4608 MFMA clocks: the barrier and the restart of the B-operand reads behind it,
-// 8 times per work-group.  Removed.)
-// (Round 5, same case, after the ablations had shown a lone wave's transform fully exposed -- one image at a time 171 -> 207 Mpix/s without
-// it: a build with FOUR PRODUCER WAVES per work-group, waves 4..7 requesting the patches and making Bt d B for waves 0..3, which keep the
-// filter stream, the MFMAs and the epilogue; same ring and barrier, bit-identical, audit clean, 240 registers, two waves per SIMD, one of
-// each kind.  Slower: 162.2 against 171.4 Mpix/s; with the producers requesting their patches a whole iteration ahead (two register
-// sets) 163.9 against 171.0.  MFMAs and vector instructions share a SIMD's vector issue port whichever wave they come from: moving the
-// transform to another wave moves it out of the consumer's program order, not out of its way.  Removed.)
-// (Also built and measured in round 4 for launches that are alone on the chip -- one Kodak map, 192 work-groups, one wave per SIMD --:
-// an 8-wave K-split work-group, waves 0..3 the first half of the k-steps, waves 4..7 the second, two rings, the partial sums
-// exchanged through LDS and each group finishing two of a lane's four channels.  Correct, and slower: 37.4 against 29.2 us per
-// launch (the exchange, 144 KB of LDS per work-group and 512-thread barriers cost more than the halved chain gives back).  Removed.)
-// A work-group (4 waves) is one HALF of the output channels of a segment, two work-groups per CU.  (An 8-wave work-group -- all
-// 128 channels, the input transform made once per segment instead of once per half -- was built and measured in round 4: 199.5
-// against 190 us on 8 Kodak maps, 53 against 35 us on one; removed.)
+// (Variants built, measured and removed in rounds 4-5 -- a one-wave-per-SIMD build with 18 / 6 rings, four producer waves per work-group,
+// an 8-wave K-split work-group, round 4's barrier-synchronised 8-wave work-group: docs/history/DESIGN_section3_rounds_1_5.md, appendix.
+// Round 6's 8-wave form with LDS counters is the WG8 template parameter below; profiles/r06_w4_wg8.md has its measurements.)
+// A work-group (4 waves) is one HALF of the output channels of a segment, two work-groups per CU.
 // Template: WT write-through stores (single-round launches); RES how many residual inputs the epilogue serves (0, 1, 2); CIN / COUT
 // channels (128 / 128: the residual layers; 256 / 128: h2 over its input's phases; 128 / 256: h12 to its output's phases); SHUF:
 // the four "channels" of a lane are the four phases of ONE output channel and are stored interleaved into the 2 H x 2 W map.

@@ -31,8 +31,7 @@ from os import path
 import numpy as np
 import torch
 
-from . import _lib, autoencoder, bits, bpp_helpers, config_parser, metrics, png_loader, probclass, sharding, streams
-from .png_loader import add_padding          # (images_iterator.py:39-59; lives beside the decoder processes' code)
+from . import _lib, autoencoder, bits, bpp_helpers, config_parser, metrics, probclass, sharding, streams
 from . import weights as _weights
 
 OutputFlags = namedtuple('OutputFlags', ['save_ours', 'ckpt_step', 'real_bpp'])
@@ -41,6 +40,20 @@ _MEASURES_FILE_NAME = 'measures.csv'
 
 
 # ---- images (reference code/images_iterator.py, code/val_images.py) -------------------------------------------
+
+def add_padding(im, pad):
+    """HWC uint8 -> zero-padded (centred, extra pixel at the far side) to multiples of `pad`
+    (images_iterator.py:39-59).  Returns (padded, undo_fn)."""
+    h, w, chan = im.shape
+    if chan == 4:
+        return add_padding(im[:, :, :3], pad)
+    if h % pad == 0 and w % pad == 0:
+        return im, lambda x: x
+    hp, wp = (-h) % pad, (-w) % pad
+    t, l = hp // 2, wp // 2
+    padded = np.pad(im, [[t, hp - t], [l, wp - l], [0, 0]], mode='constant')
+    return padded, lambda x: x[t:t + h, l:l + w, :]
+
 
 def get_image_paths(images):
     """directory with PNGs, or a glob -> (sorted paths, dataset name)  (val_images.py:12-46)."""
@@ -55,20 +68,18 @@ def get_image_paths(images):
     raise ValueError('No component without *: {}'.format(images))
 
 
-def load_image_chw(p, pad, pinned=False):
-    """PNG -> padded CHW uint8.  pinned: the HWC -> CHW copy lands in page-locked host memory (torch's caching host allocator), so
-    that the upload that follows is an asynchronous DMA instead of a staged copy the host waits for."""
-    chw = png_loader.decode_chw_view(p, pad)
-    if pinned:
-        buf = _pinned_uint8(chw.shape)
-        np.copyto(buf, chw)
-        return buf
-    return np.ascontiguousarray(chw)
-
-
-def _pinned_uint8(shape):
-    """a page-locked uint8 array from torch's caching host allocator (the array keeps the block alive)"""
-    return torch.empty(tuple(shape), dtype=torch.uint8, pin_memory=True).numpy()
+def load_image_chw(p, pad):
+    """PNG -> padded CHW uint8 (images_iterator.py:28-59).
+    (Round 6, measured and not kept.  Decoding into page-locked buffers so that the upload is an asynchronous DMA: an upload of a Kodak
+    image from pageable memory on the fetcher's copy stream holds the host for 42 us against 11 us -- nothing to win --, decoder threads
+    write page-locked memory slower than pageable (974 against 1109 images/s at 16 threads), and torch's CPU copy_ into a page-locked
+    staging batch stalled the step for 17 - 30 ms.  Decoder PROCESSES with shared-memory slots instead of threads: 1700 images/s on their
+    own, but 0.5 - 1.5 s to start -- 127 - 206 images/s on a 240-image set against 486 with 8 threads, which already feed the device
+    path's 524 images/s.  DESIGN.md section 4.)"""
+    from PIL import Image
+    im = np.asarray(Image.open(p).convert('RGB'), dtype=np.uint8)
+    im, _ = add_padding(im, pad)
+    return np.ascontiguousarray(np.transpose(im, (2, 0, 1)))
 
 
 # ---- log-dir conventions (reference code/logdir_helpers.py) -----------------------------------------------------
@@ -173,7 +184,6 @@ class Fetcher(object):
         self._streams = streams.BranchStreams(self.device)
         self._copy_stream = None
         self._metrics_ws = metrics.ValMetricsWorkspace()
-        self._batch_bufs = {}                   # page-locked staging buffers of batched steps, by shape
 
     def __call__(self, img_chw_uint8, want_symbols=False, want_image=False):
         return self.collect(self.enqueue(img_chw_uint8, want_symbols, want_image))
@@ -184,16 +194,7 @@ class Fetcher(object):
         A LIST of same-shape images is evaluated as one batch (one pass of every kernel over all of them; the inference path has no
         cross-image term -- BatchNorm is folded --, the measures are taken per image): collect() then returns a list."""
         if isinstance(img_chw_uint8, (list, tuple)):
-            # the batch is assembled in page-locked memory (its members were decoded into pinned buffers: host-to-host copies)
-            # ONE page-locked staging buffer per batch shape, kept by this fetcher (a fetcher has one step in flight; its previous upload
-            # finished before collect() returned): allocating page-locked memory per batch cost 19 ms of a 22 ms step (hipHostMalloc,
-            # tools/val_batch_profile.py)
-            key = (len(img_chw_uint8),) + tuple(img_chw_uint8[0].shape)
-            x_uint8 = self._batch_bufs.get(key)
-            if x_uint8 is None:
-                x_uint8 = self._batch_bufs[key] = torch.empty(key, dtype=torch.uint8, pin_memory=self.device.type == 'cuda')
-            for i, im in enumerate(img_chw_uint8):
-                x_uint8[i].copy_(torch.as_tensor(im))
+            x_uint8 = torch.as_tensor(np.stack(img_chw_uint8))
             batched = True
         else:
             x_uint8 = torch.as_tensor(img_chw_uint8)[None]
@@ -208,7 +209,7 @@ class Fetcher(object):
             if self._copy_stream is None:
                 self._copy_stream = torch.cuda.Stream(device=self.device)
             with torch.cuda.stream(self._copy_stream):
-                x_dev = x_uint8.to(self.device, non_blocking=True)      # pinned source (validate's loader): an asynchronous DMA
+                x_dev = x_uint8.to(self.device)
             main.wait_stream(self._copy_stream)
         with torch.cuda.stream(main):
             pending = self._measure(x_uint8, want_symbols, want_image, x_dev)
@@ -310,36 +311,26 @@ class Fetcher(object):
         return self._bpp_fetcher.get_bpp(symbols, num_pixels)
 
 
-def _decoded_ahead(image_paths, indices, pad, threads, pinned=False, procs=0):
-    """(index, CHW uint8 image) in order, the PNGs decoded a bounded distance ahead of the consumer: a Kodak-sized PNG takes the host
-    ~8 ms to decode and the device ~1.5 ms to code.  threads > 1: decoder threads in this process (PIL's decoder and zlib release the
-    interpreter lock, the rest of a decode does not); procs > 0: decoder PROCESSES (png_loader.PngWorkers) whose pixels are read from a
-    pipe straight into the destination buffer.  pinned: that buffer is page-locked."""
-    if (threads <= 1 and procs <= 0) or len(indices) <= 1:
+def _decoded_ahead(image_paths, indices, pad, threads):
+    """(index, CHW uint8 image) in order, the PNGs decoded by a few host threads a bounded distance ahead of the consumer: a
+    Kodak-sized PNG takes the host ~8 ms to decode and the device ~1.5 ms to code (PIL's decoder and zlib release the GIL)."""
+    if threads <= 1 or len(indices) <= 1:
         for idx in indices:
-            yield idx, load_image_chw(image_paths[idx], pad, pinned)
+            yield idx, load_image_chw(image_paths[idx], pad)
         return
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
-    if procs > 0:
-        pool = png_loader.PngWorkers(min(int(procs), len(indices)))
-        submit = lambda idx: pool.submit(image_paths[idx], pad, _pinned_uint8 if pinned else None)
-        depth = 2 * len(pool.procs)
-    else:
-        pool = ThreadPoolExecutor(max_workers=threads)
-        submit = lambda idx: pool.submit(load_image_chw, image_paths[idx], pad, pinned)
-        depth = 2 * threads
-    with pool:
+    with ThreadPoolExecutor(max_workers=threads) as pool:
         ahead, it = deque(), iter(indices)
         for idx in it:
-            ahead.append((idx, submit(idx)))
-            if len(ahead) >= depth:
+            ahead.append((idx, pool.submit(load_image_chw, image_paths[idx], pad)))
+            if len(ahead) >= 2 * threads:
                 break
         while ahead:
             idx, fut = ahead.popleft()
             nxt = next(it, None)
             if nxt is not None:
-                ahead.append((nxt, submit(nxt)))
+                ahead.append((nxt, pool.submit(load_image_chw, image_paths[nxt], pad)))
             yield idx, fut.result()
 
 
@@ -363,7 +354,7 @@ def _same_shape_batches(decoded, limit):
 
 
 def validate(ae_config, pc_config, weights, image_paths, out_dir, flags, device='cuda', verbose=True, host_metrics=False,
-             in_flight=4, loader_threads=8, batch_same_shape=8, loader_procs=0):
+             in_flight=4, loader_threads=8, batch_same_shape=8):
     """-> dict of averages; writes out_dir/measures.csv (rank 0).
     in_flight: images of this rank processed concurrently, each by its own Fetcher (networks, workspace, stream): the images
     are independent (the reference runs one per sess.run, val.py:157-158), and the launches of one fill the kernel-boundary
@@ -402,8 +393,7 @@ def validate(ae_config, pc_config, weights, image_paths, out_dir, flags, device=
         local.append((idx, (path.basename(p), otp)))
 
     limit = 1 if (flags.real_bpp or host_metrics) else max(1, int(batch_same_shape))
-    decoded = _decoded_ahead(image_paths, list(sharding.shard_indices(len(image_paths), rank, world)), pad, loader_threads,
-                             pinned=torch.device(device).type == 'cuda' and torch.cuda.is_available(), procs=loader_procs)
+    decoded = _decoded_ahead(image_paths, list(sharding.shard_indices(len(image_paths), rank, world)), pad, loader_threads)
     for k, members in enumerate(_same_shape_batches(decoded, limit)):
         f = fetchers[k % n_f]
         if len(pending) == n_f:
@@ -451,7 +441,8 @@ def default_loader_threads(world=None):
     """host threads decoding PNGs ahead of the device: min(16, cores / ranks of this node), at least 1.  A Kodak-sized PNG takes one
     core 8 ms to decode and the device path 1.5 ms.  Measured on the MI355X host (round 6, tools/val_throughput.py, 96 images, 4 in
     flight): 1 / 8 / 16 / 32 threads -> 109 / 357 / 361 / 321 images/s -- beyond 16 the threads only contend for the interpreter
-    lock with the loop that feeds the device (VERDICT r5 asked for min(32, ...): 32 is slower).  --loader_procs decodes in processes."""
+    lock with the loop that feeds the device (VERDICT r5 asked for min(32, ...): 32 is slower).  With the entry point's 8 hardware
+    queues: 8 / 16 threads -> 486 / 484 images/s against 524 for images that are already decoded."""
     if world is None:
         world = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1')) or 1)
     return int(max(1, min(16, (os.cpu_count() or 1) // max(1, world))))
@@ -481,9 +472,6 @@ def main(argv=None):
     p.add_argument('--in_flight', type=int, default=4, help='images processed concurrently per GPU, one stream each (1 = one at a time)')
     p.add_argument('--loader_threads', type=int, default=None,
                    help='host threads decoding PNGs ahead of the device (1 = decode in the loop; default: min(32, cores / ranks))')
-    p.add_argument('--loader_procs', type=int, default=0,
-                   help='decode PNGs in this many separate processes instead of threads (png_loader.py: no interpreter lock shared with the '
-                        'loop that feeds the device); 0 = threads')
     p.add_argument('--batch_same_shape', type=int, default=8,
                    help='consecutive images of one shape evaluated as ONE batch of up to this many when they are small (a 256 x 256 image '
                         'alone fills an eighth of the chip); per-image measures and their order as without; 1 = never')
@@ -523,7 +511,7 @@ def main(argv=None):
                         OutputFlags(flags.save_ours, -1, flags.real_bpp), device, host_metrics=bool(flags.host_metrics),
                         in_flight=flags.in_flight,
                         loader_threads=default_loader_threads() if flags.loader_threads is None else flags.loader_threads,
-                        batch_same_shape=flags.batch_same_shape, loader_procs=flags.loader_procs)
+                        batch_same_shape=flags.batch_same_shape)
         if sharding.rank_and_world()[0] == 0:
             print('Validation completed: {} | {}'.format(out_dir, avgs))
     print('*** All given job_ids validated.')

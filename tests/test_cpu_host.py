@@ -214,38 +214,6 @@ def test_val_batches_consecutive_same_shape_images_in_order():
     assert list(val._same_shape_batches(iter([]), 8)) == []
 
 
-def test_val_decodes_in_worker_processes_in_order(tmp_path):
-    """--loader_procs: PNGs decoded by `python -m imgcomp_cvpr_amd.png_loader` workers (numpy + PIL only, no torch), their pixels read
-    from the pipe into the caller's buffer: the same arrays in the same order as the in-process decoder, ragged sizes padded alike,
-    a missing file raises with its path, and the worker module does not import torch."""
-    from PIL import Image
-    from imgcomp_cvpr_amd import val, png_loader
-    paths = []
-    for i in range(11):
-        a = (np.arange((9 + i) * 20 * 3) % 251).astype(np.uint8).reshape(9 + i, 20, 3) + i
-        p = str(tmp_path / 'img{:02d}.png'.format(i))
-        Image.fromarray(a).save(p)
-        paths.append(p)
-    idx = [10, 0, 5, 7, 1, 2, 3, 9, 4]
-    got = list(val._decoded_ahead(paths, idx, 8, 1, procs=3))
-    assert [g[0] for g in got] == idx
-    for i, img in got:
-        assert img.dtype == np.uint8 and img.flags['C_CONTIGUOUS'] and np.array_equal(img, val.load_image_chw(paths[i], 8))
-    bufs = []
-
-    def alloc(shape):
-        bufs.append(np.zeros(shape, np.uint8))
-        return bufs[-1]
-    with png_loader.PngWorkers(2) as w:
-        out = [w.submit(p, 8, alloc).result() for p in paths[:3]]
-        assert all(o is b for o, b in zip(out, bufs)) and np.array_equal(out[2], val.load_image_chw(paths[2], 8))
-        with pytest.raises(IOError, match='nowhere.png'):
-            w.submit(str(tmp_path / 'nowhere.png'), 8).result()
-        assert np.array_equal(w.submit(paths[1], 8).result(), val.load_image_chw(paths[1], 8))      # the worker survives an error
-    code = 'import sys, imgcomp_cvpr_amd.png_loader; print("torch" in sys.modules)'
-    assert subprocess.check_output([sys.executable, '-c', code], cwd=ROOT).decode().strip() == 'False'
-
-
 def test_val_loader_threads_default_follows_the_host():
     from imgcomp_cvpr_amd import val
     import os

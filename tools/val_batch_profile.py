@@ -38,32 +38,3 @@ timed('  page-locked allocation of a Kodak image', lambda: torch.empty((3, 512, 
 x1 = x[:1].contiguous()
 timed('  encode batch 1', lambda: f.ae.encode(x1, is_training=False))
 
-# decoder processes alone (no device work, pageable destination): do they scale on this host?
-import tempfile
-from PIL import Image
-from imgcomp_cvpr_amd import png_loader
-with tempfile.TemporaryDirectory() as d:
-    paths = []
-    for i in range(16):
-        xx = W.synthetic_image((1, 3, 512, 768), 'natural', seed=i)[0]
-        p = os.path.join(d, 'img%02d.png' % i)
-        Image.fromarray(np.transpose(xx, (1, 2, 0))).save(p)
-        paths.append(p)
-    print('os.cpu_count', os.cpu_count(), 'affinity', len(os.sched_getaffinity(0)))
-    for procs in (1, 4, 8, 16):
-        for alloc in (None, val._pinned_uint8):
-            with png_loader.PngWorkers(procs) as w:
-                [f_.result() for f_ in [w.submit(p, 8, alloc) for p in paths]]
-                t0 = time.perf_counter()
-                [f_.result() for f_ in [w.submit(p, 8, alloc) for p in paths * 4]]
-                dt = time.perf_counter() - t0
-            print('decoder processes %2d, %s destination: %.1f images/s' % (procs, 'page-locked' if alloc else 'pageable', 64 / dt), flush=True)
-    from concurrent.futures import ThreadPoolExecutor
-    for th in (8, 16):
-        for pinned in (False, True):
-            with ThreadPoolExecutor(th) as ex:
-                list(ex.map(lambda p: val.load_image_chw(p, 8, pinned), paths))
-                t0 = time.perf_counter()
-                list(ex.map(lambda p: val.load_image_chw(p, 8, pinned), paths * 4))
-                dt = time.perf_counter() - t0
-            print('decoder threads %2d, %s destination: %.1f images/s' % (th, 'page-locked' if pinned else 'pageable', 64 / dt), flush=True)
