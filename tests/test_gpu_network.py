@@ -513,6 +513,26 @@ def test_images_in_flight_plan_hint(cuda, nets, configs, syn_weights):
         assert torch.equal(s0, s1) and torch.equal(z0, z1) and torch.equal(o0, o1)
 
 
+def test_next_layer_filter_prefetch_changes_no_bit(cuda, configs, syn_weights):
+    """A lone F(4x4) launch inside ic_ae_encode_f32 / ic_ae_decode_f32 pulls the NEXT layer's filter fragments into its XCD's L2 with
+    LDS-DMA loads into a sink behind the 72 KB B-operand ring (conv3x3_wino4.hip: M0 = an LDS address above 64 KB).  Were the sink to
+    land inside the ring -- a part that honours fewer bits of M0 -- B operands would be corrupted.  The prefetch is on for a
+    call alone on the chip (flags 0) and off when the caller announces calls in flight (IC_CONV3_IN_FLIGHT): same kernel, same plan
+    otherwise, so the whole encoder and decoder must agree bit for bit, at the Kodak shape and on a map with 2 x 8-tile segments."""
+    from imgcomp_cvpr_amd import autoencoder, weights as W, _lib
+    ae_cfg, _ = configs
+    ae = autoencoder.get_network_cls(ae_cfg)(ae_cfg).load_weights(syn_weights, cuda)
+    for (h, w) in ((512, 768), (512, 640)):
+        assert int(_lib.lib.ic_conv3x3_c128_pick_form(1, h // 4, w // 4, 0)) == 2 and int(_lib.lib.ic_conv3x3_c128_pick_form(1, h // 4, w // 4, _lib.CONV3_IN_FLIGHT(4))) == 2
+        x = dev(W.synthetic_image((1, 3, h, w), 'natural', seed=h + w), cuda)
+        e_pf = ae.encode(x, False, plan_flags=0)
+        z, sym, qh = e_pf.z.clone(), e_pf.symbols.clone(), e_pf.qhard.clone()
+        e_no = ae.encode(x, False, plan_flags=_lib.CONV3_IN_FLIGHT(4))
+        assert torch.equal(z, e_no.z) and torch.equal(sym, e_no.symbols), 'the next-layer prefetch changes the encoder output'
+        xo = ae.decode(qh, False, plan_flags=0).clone()
+        assert torch.equal(xo, ae.decode(qh, False, plan_flags=_lib.CONV3_IN_FLIGHT(4))), 'the next-layer prefetch changes the decoder output'
+
+
 def test_val_batches_small_same_shape_images(cuda, tmp_path):
     """a directory of small images of one shape: val.py evaluates consecutive same-shape images as one batch of
     up to 8 -- the rows of measures.csv, their order and the saved reconstructions are those of the one-image-per-step loop
