@@ -66,11 +66,13 @@ def test_persistent_stack_is_bit_identical_to_per_layer_launches(cuda, shape):
     tens, _ = _stack_inputs(cuda, B, seed=shape[1] * 1000 + shape[2])
     N, H, W = shape
     x = torch.relu(torch.randn((N, 128, H, W), generator=torch.Generator().manual_seed(7))).to(cuda)
-    ref, tw0 = _run_stack(cuda, x, tens, B, 0)
+    # the persistent kernel runs the F(2x2) NB-segment jobs: its per-layer twin is the F(2x2) plan (since round 5 the automatic plan takes
+    # F(4x4) from 160 work-groups on -- a Kodak map -- and F(4x4) rounds differently: 1.3e-3 absolute on this input)
+    ref, tw0 = _run_stack(cuda, x, tens, B, _lib.CONV3_NO_WINO4)
     assert tw0 == 0
     assert bool(torch.isfinite(ref).all()) and float(ref.abs().max()) > 0
     for rep in range(4):
-        got, tw = _run_stack(cuda, x, tens, B, _lib.CONV3_STACK_KERNEL)
+        got, tw = _run_stack(cuda, x, tens, B, _lib.CONV3_STACK_KERNEL | _lib.CONV3_NO_WINO4)
         assert tw == 0, 'a hand-off of the persistent stack kernel timed out at layer {}'.format(tw - 1)
         assert torch.equal(got, ref), 'persistent stack != per-layer launches (run {}): {} of {} values differ, max {}'.format(
             rep, int((got != ref).sum()), ref.numel(), float((got - ref).abs().max()))
