@@ -97,6 +97,7 @@ PROTOTYPES = {
                                  c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     'ic_sum_f32': (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p]),
     'ic_mean_f32': (c_int, [c_void_p, c_longlong, c_float, c_void_p, c_void_p, c_void_p]),
+    'ic_mean_rows_f32': (c_int, [c_void_p, c_int, c_longlong, c_float, c_void_p, c_void_p, c_void_p]),
     'ic_ae_workspace_bytes': (c_size_t, [c_int] * 4),
     'ic_ae_sync_pos_bytes': (c_size_t, [c_int] * 4),
     'ic_ae_res_stack_sync_pos_bytes': (c_size_t, [c_int] * 3),
@@ -133,6 +134,7 @@ PROTOTYPES = {
     'ic_wino4_deconv5s2_c128_c64_bn_act_f32': (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     'ic_val_metrics_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'ic_val_metrics_u8_f64': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'ic_val_metrics_per_image_u8_f64': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'ic_space_to_depth2_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ic_conv5s2_both_packed_floats': (c_size_t, [c_int]),
     'ic_pack_conv5s2_both_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),

@@ -1711,3 +1711,15 @@ extern "C" int ic_mean_f32(const float* v, long long count, float denom, float* 
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
+
+// out[r] = sum(v[r * count .. (r + 1) * count)) / denom for every row: ic_mean_f32 per row, one call across the ABI (val.py: the bpp of
+// every image of a batch; `partial` is reused row after row on the one stream)
+extern "C" int ic_mean_rows_f32(const float* v, int rows, long long count, float denom, float* partial, float* out, ic_stream_t stream) {
+    IC_CHECK_ARG(v && partial && out && rows > 0 && count > 0);
+    for (int r = 0; r < rows; ++r) {
+        const int rc = ic_mean_f32(v + (size_t)r * count, count, denom, partial, out + r, stream);
+        if (rc != IC_OK) return rc;
+    }
+    return IC_OK;
+}
+

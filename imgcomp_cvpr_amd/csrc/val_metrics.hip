@@ -214,3 +214,18 @@ extern "C" int ic_val_metrics_u8_f64(const unsigned char* x, const unsigned char
     IC_LAUNCH_CHECK();
     return IC_OK;
 }
+
+// the same for every image of a batch separately (val.py evaluates consecutive small images of one shape as one batch but reports
+// per-image measures): image n's six values at out6n + 6 n, by the single-image sequence above launched N times on `stream` -- the same
+// kernels on the same operands as N calls with N = 1 (bit-identical), one call across the ABI.  workspace: ic_val_metrics_workspace_bytes(1, C, H, W).
+extern "C" int ic_val_metrics_per_image_u8_f64(const unsigned char* x, const unsigned char* y, int N, int C, int H, int W, double* out6n,
+                                               void* workspace, size_t workspace_bytes, ic_stream_t stream) {
+    IC_CHECK_ARG(x && y && out6n && workspace && N > 0 && C > 0 && H > 0 && W > 0);
+    const size_t img = (size_t)C * H * W;
+    for (int n = 0; n < N; ++n) {
+        const int rc = ic_val_metrics_u8_f64(x + n * img, y + n * img, 1, C, H, W, out6n + 6 * (size_t)n, workspace, workspace_bytes, stream);
+        if (rc != IC_OK) return rc;
+    }
+    return IC_OK;
+}
+

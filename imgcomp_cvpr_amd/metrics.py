@@ -179,6 +179,26 @@ def val_metrics_device(x, y, workspace=None):
     return out[:5], out[5]
 
 
+def val_metrics_device_per_image(x, y, workspace=None):
+    """val_metrics_device of every image of a uint8 NCHW batch separately -> (N, 6) float64 device tensor, row n = [the 5 scale values,
+    the mean squared error] of image n: the same kernels on the same operands as N single-image calls (bit-identical), one call of the
+    library; nothing waited for."""
+    import torch
+    from . import _lib
+    assert x.dtype == torch.uint8 and y.dtype == torch.uint8, 'Expected uint8 input'
+    if x.shape != y.shape:
+        raise RuntimeError('Input images must have the same shape ({} vs. {}).'.format(tuple(x.shape), tuple(y.shape)))
+    _lib.require_cuda(x, 'x')
+    x, y = x.contiguous(), y.contiguous()
+    N, C, H, W = x.shape
+    need = _lib.lib.ic_val_metrics_workspace_bytes(1, C, H, W)
+    ws = (workspace or ValMetricsWorkspace()).get(need, x.device)
+    out = torch.empty((N, 6), dtype=torch.float64, device=x.device)
+    _lib.check(_lib.lib.ic_val_metrics_per_image_u8_f64(_lib.ptr(x), _lib.ptr(y), N, C, H, W, _lib.ptr(out), _lib.ptr(ws), need,
+                                                        _lib.current_stream(x.device)), 'ic_val_metrics_per_image_u8_f64')
+    return out
+
+
 def msssim_scale_values_device(x, y):
     """the device half of msssim_nchw_uint8_device: the per-scale contrast terms and the last scale's SSIM as ONE float64 device
     tensor, nothing waited for (val.py keeps several images in flight and reads the values later)"""

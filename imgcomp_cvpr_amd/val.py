@@ -286,22 +286,20 @@ class Fetcher(object):
     def _measure_batch(self, x_uint8_dev, want_symbols, want_image):
         """B same-shape images through ONE pass of the codec; bpp, MS-SSIM terms and squared error per image -> [B, 7] on the device"""
         x = x_uint8_dev.float()
-        B = int(x.shape[0])
         enc = self.ae.encode(x, is_training=False)
         bc = self.pc.bitcost(enc.qbar, enc.symbols, is_training=False, pad_value=self.pc.auto_pad_value(self.ae))
         x_out = self.ae.decode(enc.qhard, is_training=False)
         x_out_uint8_dev = x_out.to(torch.uint8)
-        rows = []
-        for i in range(B):
-            bpp = bits.bitcost_to_bpp(bc[i:i + 1], x[i:i + 1])
-            ms, ps = metrics.val_metrics_device(x_uint8_dev[i:i + 1], x_out_uint8_dev[i:i + 1], self._metrics_ws)
-            rows.append(torch.cat([ms, ps.reshape(1), bpp.reshape(1).to(torch.float64)]))
+        # per image, by the single-image kernels (bit-identical to one image per step), one library call each for the whole batch
+        bpp = bits.bitcost_to_bpp_per_image(bc, x)
+        m6 = metrics.val_metrics_device_per_image(x_uint8_dev, x_out_uint8_dev, self._metrics_ws)
+        rows = torch.cat([m6, bpp.to(torch.float64)[:, None]], dim=1)
         arrays = {}
         if want_symbols:
             arrays['sym'] = enc.symbols
         if want_image:
             arrays['img_out'] = x_out_uint8_dev
-        return {'scalars': {'device7xN': torch.stack(rows)}, 'arrays': arrays}
+        return {'scalars': {'device7xN': rows}, 'arrays': arrays}
 
     def real_bpp(self, symbols, num_pixels):
         if self._bpp_fetcher is None:

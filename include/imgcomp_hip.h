@@ -283,6 +283,8 @@ int ic_pc_decode_f32(const uint8_t* bitstream, long long nbytes, int first_sym, 
 int ic_sum_f32(const float* v, long long count, float* partial, float* out_sum, ic_stream_t stream);
 /* sum(v) / denom with the same reduction (bits.bitcost_to_bpp: bits.py:4-14 whole); the fp32 division is IEEE */
 int ic_mean_f32(const float* v, long long count, float denom, float* partial, float* out, ic_stream_t stream);
+/* the same for `rows` consecutive rows of `count` values (the bpp of every image of a batch, val.py): out[r]; one `partial` for all rows */
+int ic_mean_rows_f32(const float* v, int rows, long long count, float denom, float* partial, float* out, ic_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Whole-network entry points for the CVPR autoencoder (autoencoder.py:218-268): one host call
@@ -538,6 +540,10 @@ int ic_space_to_depth2_f32(const float* x, float* y, int N, int C, int H2, int W
 size_t ic_val_metrics_workspace_bytes(int N, int C, int H, int W);
 int ic_val_metrics_u8_f64(const unsigned char* x, const unsigned char* y, int N, int C, int H, int W, double* out6,
                           void* workspace, size_t workspace_bytes, ic_stream_t stream);
+/* ... for every image of the batch separately: image n's six values at out6n + 6 n (the single-image sequence N times on `stream`,
+ * bit-identical to N calls with N = 1); workspace: ic_val_metrics_workspace_bytes(1, C, H, W) */
+int ic_val_metrics_per_image_u8_f64(const unsigned char* x, const unsigned char* y, int N, int C, int H, int W, double* out6n,
+                                    void* workspace, size_t workspace_bytes, ic_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * MS-SSIM training distortion and its gradient (csrc/msssim.hip).  Reference: code/ms_ssim.py:3-186 (5 scales, separable

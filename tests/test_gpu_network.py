@@ -402,6 +402,16 @@ def test_device_metrics_match_numpy(cuda):
         assert float((vals.cpu() - twin).abs().max()) < 1e-12, (vals.cpu(), twin)
         assert float(mse) == float(metrics.mse_uint8_device(torch.as_tensor(a), torch.as_tensor(b)))
     assert metrics.psnr_uint8_device(ad, ad) == float('inf') and metrics.msssim_nchw_uint8_device(ad, ad) == 1.0
+    # per image of a batch in one call (val.py's batched step): bit-identical to a call per image
+    a = W.synthetic_image((5, 3, 128, 136), 'natural', 9)
+    b = np.clip(a.astype(np.float64) + np.random.RandomState(4).normal(0, 5, a.shape), 0, 255).astype(np.uint8)
+    ad, bd = torch.as_tensor(a).to(cuda), torch.as_tensor(b).to(cuda)
+    m6 = metrics.val_metrics_device_per_image(ad, bd)
+    assert tuple(m6.shape) == (5, 6)
+    for i in range(5):
+        vals, mse = metrics.val_metrics_device(ad[i:i + 1], bd[i:i + 1])
+        assert torch.equal(m6[i, :5], vals) and torch.equal(m6[i, 5], mse), i
+    assert not torch.equal(m6[0], m6[1])
 
 
 def test_against_frozen_oracle_fixture(cuda, configs, syn_weights, nets):

@@ -644,6 +644,12 @@ def test_sum_and_bpp(cuda):
     assert abs(float(bpp) - ref) / ref < 1e-6
     # deterministic
     assert float(bits.bitcost_to_bpp(dev(bc, cuda), x)) == float(bpp)
+    # every image of a batch in one call: the same bits as a call per image
+    bcd = dev(bc, cuda)
+    per = bits.bitcost_to_bpp_per_image(bcd, x)
+    assert tuple(per.shape) == (2,)
+    for i in range(2):
+        assert torch.equal(per[i], bits.bitcost_to_bpp(bcd[i:i + 1], x[i:i + 1]))
 
 
 def test_error_codes(cuda):
