@@ -235,7 +235,9 @@ void wino4_3x3_kernel(const WnArgs a) {
     constexpr int WAVES = WG8 ? 8 : 4;
     constexpr int KS = CIN / 4, IT = KS / 4, PARTS = COUT / (16 * WAVES);   // k-steps, iterations of 4 k-steps, work-groups per segment
     __shared__ f32x4 ring[2 * 4 * W4_QUADS * 64];                 // [half][k-step of the iteration][position quad][lane]: 72 KB
-    __shared__ float pf_sink[64];                                 // where the prefetch below lands (never read)
+    __shared__ float pf_sink[64];                                 // where the prefetch below lands (never read).  It sits BEHIND the 72 KB ring: the LDS-DMA base in M0
+                                                                  // is above 64 KB, which gfx950 honours (a part that kept 16 bits would sink into ring half 0);
+                                                                  // tests/test_gpu_network.py::test_next_layer_filter_prefetch_changes_no_bit compares prefetch on / off bit for bit
     __shared__ unsigned w8_flag[4];                               // WG8: [h] = producer waves that completed ring half h, [2 + h] = waves that finished reading it (running totals)
 #ifdef W4_STAMPS
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
